@@ -1,0 +1,252 @@
+/*
+ * gs2mesh_amd.h -- C ABI of the MI355X-native render -> fuse hot path of GS2Mesh.
+ *
+ * This is the drop-in boundary: a plain C shared library (libgs2mesh_amd.so, HIP/gfx950)
+ * with raw device pointers, sizes and a hipStream_t.  No torch types cross it.  The
+ * Python host side (package gs2mesh_amd) binds it with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Citations are file:line in the reference tree (/root/reference), with
+ *   DGR/ = third_party/gaussian-splatting/submodules/diff-gaussian-rasterization/
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; gs2m_last_error()
+ *     returns a thread-local message for the last failure on the calling thread;
+ *   - all `const float*` / `float*` / `uint8_t*` data arguments are DEVICE pointers
+ *     unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued on it, nothing synchronises the device except the functions that say
+ *     so (gs2m_raster_status, gs2m_tsdf_status, the *_download helpers);
+ *   - handles own persistent, grow-only scratch arenas (the reference re-allocates
+ *     its three byte arenas every call: DGR/rasterize_points.cu:27-33,73-78).  A
+ *     handle may only be used from one stream at a time.
+ */
+#ifndef GS2MESH_AMD_H
+#define GS2MESH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS2M_VERSION 100 /* 0.1.0 */
+
+typedef void* gs2m_stream; /* hipStream_t */
+
+/* ------------------------------------------------------------------------------------ */
+/* library                                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+int gs2m_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* gs2m_last_error(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* rasteriser                                                                           */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct gs2m_raster gs2m_raster;
+
+/* Flags for gs2m_raster_set_option */
+enum {
+    GS2M_OPT_EXACT_TILE_CULL = 1, /* 0 = reference AABB-of-3-sigma-circle instance list
+                                     (DGR/cuda_rasterizer/auxiliary.h:46-56), 1 = also drop
+                                     (Gaussian,tile) instances whose alpha < 1/255 on the
+                                     whole tile (image unchanged, num_rendered smaller)   */
+    GS2M_OPT_BLEND_VARIANT = 2,   /* 0 = 16x16 tile per 256-thread workgroup,
+                                     1 = one wave per 16x16 tile, 4 pixels per lane       */
+    GS2M_OPT_DEBUG_SYNC = 3       /* 1 = synchronise + check after every launch (the
+                                     reference's `debug`: auxiliary.h:166-173)            */
+};
+
+int gs2m_raster_create(gs2m_raster** out, int device);
+int gs2m_raster_destroy(gs2m_raster* r);
+int gs2m_raster_set_option(gs2m_raster* r, int option, int value);
+
+/* Pre-size the arenas (optional; every forward grows them on demand).
+ * P Gaussians, n_views views of W x H rendered per call, `instances` (Gaussian,tile)
+ * pairs per view (the reference's num_rendered). */
+int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, int H, int64_t instances);
+
+/*
+ * Operator-level entry point.  Replaces CudaRasterizer::Rasterizer::forward
+ * (DGR/cuda_rasterizer/rasterizer.h:35-60, rasterizer_impl.cu:198-336) as bound by
+ * RasterizeGaussiansCUDA (DGR/rasterize_points.cu:35-115): same argument meaning and order,
+ * minus the three std::function arena callbacks (arenas live in the handle) plus the
+ * handle and the stream.
+ *
+ *   P, D, M           #Gaussians, active SH degree (0..3), #SH coefficients per channel
+ *   background[3]     device
+ *   means3D[P,3]      device
+ *   shs[P,M,3]        device or NULL (then colors_precomp must be given)
+ *   colors_precomp[P,3] device or NULL
+ *   opacities[P]      device (activated)
+ *   scales[P,3], rotations[P,4] (wxyz)  device (activated) or NULL (then cov3D_precomp)
+ *   cov3D_precomp[P,6] device or NULL
+ *   viewmatrix[16], projmatrix[16], cam_pos[3]   device, the reference's transposed
+ *                     row-major layout (GS/scene/cameras.py:54-57)
+ *   out_color[3,H,W]  device, written completely
+ *   radii[P]          device or NULL
+ *   debug             as the reference: sync + check after every launch
+ *
+ * Asynchronous.  If the instance arena was too small the image is NOT valid; query
+ * gs2m_raster_status() (which synchronises the stream), gs2m_raster_reserve() and
+ * call again -- the Python binding does exactly that.
+ */
+int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const float* background,
+                           int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities,
+                           const float* scales, float scale_modifier, const float* rotations,
+                           const float* cov3D_precomp, const float* viewmatrix,
+                           const float* projmatrix, const float* cam_pos, float tan_fovx,
+                           float tan_fovy, int prefiltered, float* out_color, int* radii,
+                           int debug, gs2m_stream stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:26-31,
+ * rasterizer_impl.cu:54-66,141-153).  present[P]: device, 1 byte per Gaussian. */
+int gs2m_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                      const float* projmatrix, uint8_t* present, gs2m_stream stream);
+
+/* Host-side camera record = the per-view fields of GaussianRasterizationSettings
+ * (DGR/diff_gaussian_rasterization/__init__.py:157-169).  Matrices in the same
+ * transposed row-major layout the reference passes. */
+typedef struct gs2m_camera {
+    int32_t width, height;
+    float tanfovx, tanfovy;
+    float viewmatrix[16];
+    float projmatrix[16];
+    float campos[3];
+} gs2m_camera;
+
+/* Gaussian store handed to the pipeline-level entry point.  `raw` != 0 means the arrays
+ * hold the GaussianModel's pre-activation parameters (GS/scene/gaussian_model.py:95-115):
+ * log-scales, unnormalised quaternions, logit opacities; exp / normalize / sigmoid are
+ * fused into the projection kernel.  shs is [P,M,3] (get_features layout) or, when
+ * shs_rest != NULL, shs = features_dc [P,1,3] and shs_rest = features_rest [P,M-1,3]
+ * (saves the torch.cat of GS/scene/gaussian_model.py:108-111). */
+typedef struct gs2m_gaussians {
+    int32_t P, sh_degree, M, raw;
+    const float* xyz;       /* [P,3] */
+    const float* scales;    /* [P,3] */
+    const float* rotations; /* [P,4] wxyz */
+    const float* opacities; /* [P]   */
+    const float* shs;       /* [P,M,3] or features_dc [P,1,3] */
+    const float* shs_rest;  /* NULL or features_rest [P,M-1,3] */
+} gs2m_gaussians;
+
+/*
+ * Pipeline-level entry point: renders n_views views (a stereo pair = 2) of the same
+ * Gaussians in one fused pass.  Replaces the per-eye loop of Renderer.render_image_pair
+ * (gs2mesh_utils/renderer_utils.py:378-389) -> render() (GS/gaussian_renderer/__init__.py:18-100)
+ * -> rasterizer.  cams and bg are HOST pointers (copied at call time).
+ *   out_color  [n_views,3,H,W] f32 device, or NULL
+ *   out_rgb8   [n_views,H,W,3] u8 device, or NULL: saturate(rint(255*c)), the conversion
+ *              cv2.imwrite applies to the float image (renderer_utils.py:389-390)
+ *   out_radii  [n_views,P] i32 device, or NULL
+ * All views must share width/height.  Asynchronous; same arena/overflow contract as
+ * gs2m_rasterize_forward.
+ */
+int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* g, const gs2m_camera* cams,
+                      int n_views, const float* bg /* host[3] */, float scale_modifier,
+                      float* out_color, uint8_t* out_rgb8, int* out_radii, gs2m_stream stream);
+
+/* Synchronises `stream` and reports, for the last forward/render_views call on the
+ * handle: num_rendered[v] for v < n_views (host array, may be NULL) and whether the
+ * instance arena overflowed (*overflow = 1: results invalid, *required = instances
+ * per view needed). */
+int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_views,
+                       int64_t* num_rendered, int* overflow, int64_t* required);
+
+/* Debug/parity taps: copy the projected per-Gaussian record of view `v` of the last call to
+ * HOST buffers (any may be NULL): means2D[P,2], depths[P], conic_opacity[P,4], rgb[P,3],
+ * rect[P,4] (u16 x0,y0,x1,y1), tiles_touched[P].  Synchronises. */
+int gs2m_raster_download_geometry(gs2m_raster* r, gs2m_stream stream, int v, int P,
+                                  float* means2D, float* depths, float* conic_opacity,
+                                  float* rgb, uint16_t* rect, uint32_t* tiles_touched);
+/* Copy view v's sorted instance list and tile ranges to HOST: point_list[n] (Gaussian ids,
+ * n = num_rendered[v]), ranges[tiles,2].  Synchronises. */
+int gs2m_raster_download_binning(gs2m_raster* r, gs2m_stream stream, int v, int64_t n,
+                                 uint32_t* point_list, int32_t n_tiles, uint32_t* ranges);
+
+/* ------------------------------------------------------------------------------------ */
+/* TSDF fusion                                                                          */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct gs2m_tsdf gs2m_tsdf;
+
+enum { GS2M_TSDF_COLOR_NONE = 0, GS2M_TSDF_COLOR_RGB8 = 1 };
+
+/*
+ * Replaces open3d.pipelines.integration.ScalableTSDFVolume(voxel_length, sdf_trunc,
+ * color_type[, volume_unit_resolution=16, depth_sampling_stride=4]) as constructed at
+ * gs2mesh_utils/tsdf_utils.py:53-56 (Open3D 0.17.0, requirements.txt:15; the C++ is not
+ * in the reference tree -- algorithm restated in oracle/tsdf_oracle.cpp).
+ * max_blocks = capacity of the 16^3-voxel block pool (20 B/voxel = 80 KiB per block).
+ */
+int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf_trunc, int color_type,
+                     int volume_unit_resolution, int depth_sampling_stride, int64_t max_blocks,
+                     int device);
+int gs2m_tsdf_destroy(gs2m_tsdf* t);
+int gs2m_tsdf_reset(gs2m_tsdf* t, gs2m_stream stream);
+
+/*
+ * Replaces RGBDImage.create_from_color_and_depth(color, depth, depth_scale, depth_trunc,
+ * convert_rgb_to_intensity=False) + PinholeCameraIntrinsic(w,h,fx,fy,cx,cy) +
+ * volume.integrate(rgbd, intrinsic, extrinsic)  (tsdf_utils.py:88-93,106-107).
+ *   depth   [H,W] f32 device (raw: the kernel applies d/depth_scale, d >= depth_trunc -> 0)
+ *   color   [H,W,3] u8 device (may be NULL when color_type == NONE)
+ *   mask    [H,W] u8 device or NULL: depth is multiplied by (mask != 0) first
+ *           (tsdf_utils.py:68-81 object/occlusion masks)
+ *   min_depth: depth < min_depth -> 0 before scaling (tsdf_utils.py:83); pass 0 to skip
+ *   extrinsic_w2c: HOST, row-major 4x4 float64 world->camera (what the reference passes:
+ *           np.linalg.inv(extrinsic_matrix))
+ * Asynchronous.
+ */
+int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color,
+                        const uint8_t* mask, int width, int height, double fx, double fy,
+                        double cx, double cy, const double* extrinsic_w2c, double depth_scale,
+                        double depth_trunc, double min_depth, gs2m_stream stream);
+
+/* Synchronises; n_blocks = allocated blocks, block_updates = sum over frames of blocks
+ * integrated (x 4096 = voxel-updates), overflow != 0 if the block pool or hash was full. */
+int gs2m_tsdf_status(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_blocks,
+                     int64_t* block_updates, int* overflow);
+
+/* Copy allocated blocks to HOST (any pointer may be NULL): keys[n,3] (block index),
+ * tsdf[n,4096], weight[n,4096] (voxel x*256+y*16+z, Open3D IndexOf), rgb_sum[n,4096,3] u32
+ * (sum of u8 colours; mean colour = rgb_sum/weight).  n must be >= n_blocks. Synchronises. */
+int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, int32_t* keys,
+                       float* tsdf, float* weight, uint32_t* rgb_sum);
+
+/* Block keys of all allocated blocks to a DEVICE buffer keys[n,3] (i32), in slot order. */
+int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m_stream stream);
+
+/*
+ * Multi-GPU exchange (new; the reference is single-GPU).  pack: for the n canonical block
+ * keys (device [n,3]) write this volume's accumulators in SUM form to device buffers
+ * wsum[n,4096] = tsdf*weight, weight[n,4096], rgb_sum[n,4096,3] (zeros where the block is
+ * not allocated here).  The host all-reduces/reduce-scatters them with RCCL, then unpack
+ * replaces the state of those blocks (allocating as needed) with tsdf = wsum/weight.
+ */
+int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, float* weight,
+                   uint32_t* rgb_sum, gs2m_stream stream);
+int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
+                     const float* weight, const uint32_t* rgb_sum, gs2m_stream stream);
+
+/*
+ * Replaces volume.extract_triangle_mesh() (tsdf_utils.py:108): marching cubes over the
+ * allocated blocks.  Two-call protocol: first call with vertices == NULL returns the
+ * counts (synchronises); second call fills DEVICE buffers vertices[nv,3] f64-as-f32?  no:
+ * vertices[nv,3] f32, colors[nv,3] f32 (0..1), triangles[nt,3] i32 (unwelded: 3 vertices per
+ * triangle; welding is done by the host mirror).
+ */
+int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_triangles);
+int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, float* vertices,
+                      float* colors, int64_t* n_triangles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS2MESH_AMD_H */

@@ -1,0 +1,297 @@
+"""CPU oracle for the render -> fuse hot path (TEST INFRASTRUCTURE ONLY).
+
+ctypes front-end of ``oracle/raster_oracle.c`` (restatement of the reference rasteriser
+forward, DGR/cuda_rasterizer/{forward.cu,rasterizer_impl.cu,auxiliary.h}) and
+``oracle/tsdf_oracle.cpp`` (restatement of Open3D 0.17 ``ScalableTSDFVolume::Integrate``
+as called at gs2mesh_utils/tsdf_utils.py:53-56,88-93,106-107).
+
+Only ``tests/``, ``bench.py``'s ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may
+import this package, and only as the checker.  The product package ``gs2mesh_amd`` never
+does (tests/test_no_oracle_in_product.py greps for it).
+
+Parity status: SH->RGB, Sigma=R S^2 R^T and the camera matrices are pinned by golden
+vectors generated from the reference's own Python (tests/golden/make_golden.py).  The EWA
+projection, binning, compositing and the whole TSDF are "parity unpinned" (no second
+implementation / Open3D absent); they are covered by analytic known-answer tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc/g++ (seconds)."""
+    srcs = [os.path.join(_HERE, "raster_oracle.c"), os.path.join(_HERE, "tsdf_oracle.cpp")]
+    outs = [os.path.join(_BUILD, "liboracle_raster.so"), os.path.join(_BUILD, "liboracle_tsdf.so")]
+    fresh = all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(s) for s, o in zip(srcs, outs))
+    if fresh and not force:
+        return
+    subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+_raster = None
+_tsdf = None
+
+
+def _opt(a, dtype):
+    """None -> NULL pointer, array -> contiguous array of dtype."""
+    if a is None:
+        return None
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def raster_lib():
+    global _raster
+    if _raster is None:
+        build()
+        lib = C.CDLL(os.path.join(_BUILD, "liboracle_raster.so"))
+        vp = C.c_void_p
+        lib.oracle_preprocess.restype = None
+        lib.oracle_preprocess.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_float, vp, vp, vp, vp, vp,
+                                          vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float,
+                                          vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.oracle_mark_visible.restype = None
+        lib.oracle_mark_visible.argtypes = [C.c_int, vp, vp, vp, vp]
+        lib.oracle_bin.restype = C.c_int64
+        lib.oracle_bin.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int64]
+        lib.oracle_render.restype = None
+        lib.oracle_render.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.oracle_rasterize_forward.restype = C.c_int64
+        lib.oracle_rasterize_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
+                                                 vp, C.c_float, vp, vp, vp, vp, vp, C.c_float, C.c_float,
+                                                 C.c_int, vp, vp]
+        lib.oracle_tile_may_contribute.restype = C.c_int
+        lib.oracle_tile_may_contribute.argtypes = [C.c_float] * 6 + [C.c_int, C.c_int]
+        _raster = lib
+    return _raster
+
+
+def tsdf_lib():
+    global _tsdf
+    if _tsdf is None:
+        build()
+        lib = C.CDLL(os.path.join(_BUILD, "liboracle_tsdf.so"))
+        vp = C.c_void_p
+        lib.oracle_tsdf_create.restype = vp
+        lib.oracle_tsdf_create.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+        lib.oracle_tsdf_destroy.argtypes = [vp]
+        lib.oracle_tsdf_set_threads.argtypes = [vp, C.c_int]
+        lib.oracle_tsdf_max_threads.restype = C.c_int
+        lib.oracle_rgbd_convert_depth.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_double]
+        lib.oracle_dist_multiplier.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+        lib.oracle_tsdf_integrate.restype = C.c_int64
+        lib.oracle_tsdf_integrate.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                              C.c_double, vp]
+        lib.oracle_tsdf_num_blocks.restype = C.c_int64
+        lib.oracle_tsdf_num_blocks.argtypes = [vp]
+        lib.oracle_tsdf_block_updates.restype = C.c_int64
+        lib.oracle_tsdf_block_updates.argtypes = [vp]
+        lib.oracle_tsdf_export.argtypes = [vp, vp, vp, vp, vp]
+        _tsdf = lib
+    return _tsdf
+
+
+# --------------------------------------------------------------------------------------
+# rasteriser
+# --------------------------------------------------------------------------------------
+
+def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H,
+               tanfovx, tanfovy, sh_degree=3, scale_modifier=1.0, cov3D_precomp=None,
+               colors_precomp=None):
+    """preprocessCUDA (forward.cu:155-256) -> dict of per-Gaussian arrays."""
+    lib = raster_lib()
+    means3D = np.ascontiguousarray(means3D, np.float32)
+    P = means3D.shape[0]
+    scales = _opt(scales, np.float32)
+    rotations = _opt(rotations, np.float32)
+    opacities = np.ascontiguousarray(opacities, np.float32).reshape(-1)
+    shs = _opt(shs, np.float32)
+    M = 0 if shs is None else shs.shape[1]
+    cov3D_precomp = _opt(cov3D_precomp, np.float32)
+    colors_precomp = _opt(colors_precomp, np.float32)
+    vm = np.ascontiguousarray(viewmatrix, np.float32).reshape(16)
+    pm = np.ascontiguousarray(projmatrix, np.float32).reshape(16)
+    cp = np.ascontiguousarray(campos, np.float32).reshape(3)
+    out = dict(
+        radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32), depths=np.zeros(P, np.float32),
+        cov3D=np.zeros((P, 6), np.float32), rgb=np.zeros((P, 3), np.float32),
+        conic_opacity=np.zeros((P, 4), np.float32), tiles_touched=np.zeros(P, np.uint32),
+        rect=np.zeros((P, 4), np.uint32))
+    lib.oracle_preprocess(P, sh_degree, M, _ptr(means3D), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                          _ptr(opacities), _ptr(shs), _ptr(cov3D_precomp), _ptr(colors_precomp), _ptr(vm),
+                          _ptr(pm), _ptr(cp), int(W), int(H), float(tanfovx), float(tanfovy),
+                          _ptr(out["radii"]), _ptr(out["means2D"]), _ptr(out["depths"]), _ptr(out["cov3D"]),
+                          _ptr(out["rgb"]), _ptr(out["conic_opacity"]), _ptr(out["tiles_touched"]),
+                          _ptr(out["rect"]))
+    return out
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    lib = raster_lib()
+    means3D = np.ascontiguousarray(means3D, np.float32)
+    P = means3D.shape[0]
+    vm = np.ascontiguousarray(viewmatrix, np.float32).reshape(16)
+    pm = np.ascontiguousarray(projmatrix, np.float32).reshape(16)
+    present = np.zeros(P, np.uint8)
+    lib.oracle_mark_visible(P, _ptr(means3D), _ptr(vm), _ptr(pm), _ptr(present))
+    return present.astype(bool)
+
+
+def bin_instances(geom, W, H, exact_cull=False):
+    """duplicateWithKeys + stable sort + identifyTileRanges -> (point_list[n], ranges[tiles,2])."""
+    lib = raster_lib()
+    P = geom["radii"].shape[0]
+    cap = int(geom["tiles_touched"].astype(np.int64).sum())
+    pl = np.zeros(max(cap, 1), np.uint32)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ranges = np.zeros((gx * gy, 2), np.uint32)
+    n = lib.oracle_bin(P, W, H, _ptr(geom["radii"]), _ptr(geom["means2D"]), _ptr(geom["depths"]),
+                       _ptr(geom["conic_opacity"]), int(bool(exact_cull)), _ptr(pl), _ptr(ranges), cap)
+    return pl[:n].copy(), ranges
+
+
+def render(W, H, ranges, point_list, means2D, features, conic_opacity, bg):
+    """renderCUDA (forward.cu:261-374) -> (color[3,H,W], final_T[H,W], n_contrib[H,W])."""
+    lib = raster_lib()
+    out = np.zeros((3, H, W), np.float32)
+    final_T = np.zeros((H, W), np.float32)
+    n_contrib = np.zeros((H, W), np.uint32)
+    pl = np.ascontiguousarray(point_list, np.uint32)
+    if pl.size == 0:
+        pl = np.zeros(1, np.uint32)
+    lib.oracle_render(W, H, _ptr(np.ascontiguousarray(ranges, np.uint32)), _ptr(pl),
+                      _ptr(np.ascontiguousarray(means2D, np.float32)),
+                      _ptr(np.ascontiguousarray(features, np.float32)),
+                      _ptr(np.ascontiguousarray(conic_opacity, np.float32)),
+                      _ptr(np.ascontiguousarray(bg, np.float32)), _ptr(out), _ptr(final_T), _ptr(n_contrib))
+    return out, final_T, n_contrib
+
+
+def rasterize_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, bg,
+                      shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                      sh_degree=3, scale_modifier=1.0, exact_cull=False):
+    """Rasterizer::forward (rasterizer_impl.cu:198-336) -> (color[3,H,W], radii[P], num_rendered)."""
+    lib = raster_lib()
+    means3D = np.ascontiguousarray(means3D, np.float32)
+    P = means3D.shape[0]
+    out = np.zeros((3, H, W), np.float32)  # torch::full({3,H,W}, 0.0): rasterize_points.cu:68
+    radii = np.zeros(P, np.int32)
+    if P == 0:
+        return out, radii, 0
+    shs = _opt(shs, np.float32)
+    M = 0 if shs is None else shs.shape[1]
+    colors_precomp = _opt(colors_precomp, np.float32)
+    scales = _opt(scales, np.float32)
+    rotations = _opt(rotations, np.float32)
+    cov3D_precomp = _opt(cov3D_precomp, np.float32)
+    opacities = np.ascontiguousarray(opacities, np.float32).reshape(-1)
+    vm = np.ascontiguousarray(viewmatrix, np.float32).reshape(16)
+    pm = np.ascontiguousarray(projmatrix, np.float32).reshape(16)
+    cp = np.ascontiguousarray(campos, np.float32).reshape(3)
+    bgc = np.ascontiguousarray(bg, np.float32).reshape(3)
+    n = lib.oracle_rasterize_forward(P, sh_degree, M, _ptr(bgc), int(W), int(H), _ptr(means3D), _ptr(shs),
+                                     _ptr(colors_precomp), _ptr(opacities), _ptr(scales), float(scale_modifier),
+                                     _ptr(rotations), _ptr(cov3D_precomp), _ptr(vm), _ptr(pm), _ptr(cp),
+                                     float(tanfovx), float(tanfovy), int(bool(exact_cull)), _ptr(out),
+                                     _ptr(radii))
+    return out, radii, int(n)
+
+
+def activate(scaling_raw, rotation_raw, opacity_raw):
+    """GaussianModel getters (GS/scene/gaussian_model.py:95-115): exp, F.normalize (eps 1e-12),
+    sigmoid, all in fp32."""
+    s = np.exp(np.asarray(scaling_raw, np.float32)).astype(np.float32)
+    q = np.asarray(rotation_raw, np.float32)
+    n = np.sqrt((q * q).sum(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32)
+    q = (q / np.maximum(n, np.float32(1e-12))).astype(np.float32)
+    o = np.asarray(opacity_raw, np.float32)
+    o = (np.float32(1) / (np.float32(1) + np.exp(-o).astype(np.float32))).astype(np.float32)
+    return s, q, o
+
+
+# --------------------------------------------------------------------------------------
+# TSDF
+# --------------------------------------------------------------------------------------
+
+class ScalableTSDFVolume:
+    """Restated open3d.pipelines.integration.ScalableTSDFVolume (integration only)."""
+
+    def __init__(self, voxel_length, sdf_trunc, color_type=1, volume_unit_resolution=16,
+                 depth_sampling_stride=4):
+        self._lib = tsdf_lib()
+        self.res = volume_unit_resolution
+        self._h = self._lib.oracle_tsdf_create(float(voxel_length), float(sdf_trunc), int(color_type),
+                                               int(volume_unit_resolution), int(depth_sampling_stride))
+
+    def __del__(self):
+        try:
+            self._lib.oracle_tsdf_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_threads(self, n):
+        self._lib.oracle_tsdf_set_threads(self._h, int(n))
+
+    @staticmethod
+    def max_threads():
+        return int(tsdf_lib().oracle_tsdf_max_threads())
+
+    @staticmethod
+    def convert_depth(depth, depth_scale, depth_trunc):
+        d = np.ascontiguousarray(depth, np.float32)
+        out = np.empty_like(d)
+        tsdf_lib().oracle_rgbd_convert_depth(_ptr(d), _ptr(out), d.size, float(depth_scale), float(depth_trunc))
+        return out
+
+    def integrate(self, depth_f, color_u8, width, height, fx, fy, cx, cy, extrinsic_w2c):
+        """depth_f: converted float depth [H,W]; color_u8 [H,W,3] or None."""
+        d = np.ascontiguousarray(depth_f, np.float32)
+        c = None if color_u8 is None else np.ascontiguousarray(color_u8, np.uint8)
+        E = np.ascontiguousarray(extrinsic_w2c, np.float64).reshape(16)
+        n = self._lib.oracle_tsdf_integrate(self._h, _ptr(d), _ptr(c), int(width), int(height), float(fx),
+                                            float(fy), float(cx), float(cy), _ptr(E))
+        if n < 0:
+            raise RuntimeError("singular extrinsic")
+        return int(n)
+
+    @property
+    def num_blocks(self):
+        return int(self._lib.oracle_tsdf_num_blocks(self._h))
+
+    @property
+    def block_updates(self):
+        return int(self._lib.oracle_tsdf_block_updates(self._h))
+
+    def export(self):
+        n = self.num_blocks
+        nv = self.res ** 3
+        keys = np.zeros((n, 3), np.int32)
+        tsdf = np.zeros((n, nv), np.float32)
+        weight = np.zeros((n, nv), np.float32)
+        color = np.zeros((n, nv, 3), np.float64)
+        self._lib.oracle_tsdf_export(self._h, _ptr(keys), _ptr(tsdf), _ptr(weight), _ptr(color))
+        return keys, tsdf, weight, color
+
+
+def dist_multiplier(width, height, fx, fy, cx, cy):
+    out = np.zeros((height, width), np.float32)
+    tsdf_lib().oracle_dist_multiplier(int(width), int(height), float(fx), float(fy), float(cx), float(cy), _ptr(out))
+    return out

@@ -1,0 +1,141 @@
+"""Generate golden vectors from the REFERENCE's own Python (run in the build container only).
+
+    python tests/golden/make_golden.py        # needs /root/reference, writes tests/golden/*.npz
+
+The reference has no unit tests or golden vectors.  What it does have
+are independent pure-Python implementations of sub-steps of the hot path that import on CPU:
+
+  * GS/utils/sh_utils.py:57-112      eval_sh              -> pins SH -> RGB (forward.cu:20-71)
+  * GS/utils/general_utils.py:64-110 build_rotation / build_scaling_rotation / strip_symmetric
+    + GS/scene/gaussian_model.py:27-31 build_covariance_from_scaling_rotation
+                                                            -> pins Sigma = R S^2 R^T packing
+                                                               (forward.cu:118-152)
+  * GS/utils/graphics_utils.py:38-71 getWorld2View2 / getProjectionMatrix, combined as in
+    GS/scene/cameras.py:54-57                              -> pins the per-view uniforms
+  * gs2mesh_utils/transformation_utils.py:23-63,83-141,207-224 (eul2rotm, rotm2eul,
+    convert_R_T_to_GS, RT_from_rot_pos, calculate_right_camera_pose) chained exactly as
+    Renderer.__init__ / render_image_pair do (renderer_utils.py:132-141,178-206,378-386)
+                                                            -> pins the stereo camera poses
+
+`general_utils.build_rotation` hard-codes device='cuda'; we run it with torch.zeros patched
+to ignore the device keyword (CPU container).  cv2 is stubbed (only get_shading uses it).
+The outputs are committed as small .npz fixtures; /root/reference is never read at test time.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+GS = os.path.join(REF, "third_party", "gaussian-splatting")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    sys.path.insert(0, GS)
+    sys.path.insert(0, REF)
+    from utils import sh_utils, graphics_utils, general_utils  # noqa
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_transformation_utils", os.path.join(REF, "gs2mesh_utils", "transformation_utils.py"))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    return sh_utils, graphics_utils, general_utils, tu
+
+
+def main():
+    sh_utils, graphics_utils, general_utils, tu = _import_reference()
+    rng = np.random.default_rng(20240611)
+
+    # ---- 1. SH -> RGB ------------------------------------------------------------------
+    P = 512
+    shs = rng.normal(0, 0.4, size=(P, 16, 3)).astype(np.float32)      # get_features layout [P,16,3]
+    xyz = rng.uniform(-2, 2, size=(P, 3)).astype(np.float32)
+    campos = np.array([0.3, -0.2, 4.0], np.float32)
+    out = {}
+    for deg in range(4):
+        # GS/gaussian_renderer/__init__.py:73-78 (convert_SHs_python path)
+        shs_view = torch.from_numpy(shs).transpose(1, 2).reshape(-1, 3, 16)
+        dir_pp = torch.from_numpy(xyz) - torch.from_numpy(campos)[None].repeat(P, 1)
+        dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+        sh2rgb = sh_utils.eval_sh(deg, shs_view, dir_pp_normalized)
+        out[f"rgb_deg{deg}"] = torch.clamp_min(sh2rgb + 0.5, 0.0).numpy()
+    np.savez_compressed(os.path.join(OUT, "sh_rgb.npz"), shs=shs, xyz=xyz, campos=campos, **out)
+
+    # ---- 2. Sigma = R S^2 R^T -----------------------------------------------------------
+    scales = np.exp(rng.normal(np.log(0.05), 0.6, size=(P, 3))).astype(np.float32)
+    rots_raw = rng.normal(0, 1, size=(P, 4)).astype(np.float32)
+    real_zeros = torch.zeros
+
+    def cpu_zeros(*a, **k):
+        k.pop("device", None)
+        return real_zeros(*a, **k)
+
+    torch.zeros = cpu_zeros
+    try:
+        covs = {}
+        for mod in (1.0, 0.5):
+            # gaussian_model.py:27-31 ; rotation passed is the RAW _rotation (gaussian_model.py:117-118),
+            # build_rotation normalises it internally (general_utils.py:79-81)
+            L = general_utils.build_scaling_rotation(mod * torch.from_numpy(scales), torch.from_numpy(rots_raw))
+            cov = general_utils.strip_symmetric(L @ L.transpose(1, 2))
+            covs[f"cov_mod{mod}"] = cov.numpy()
+    finally:
+        torch.zeros = real_zeros
+    rots_n = torch.nn.functional.normalize(torch.from_numpy(rots_raw)).numpy()
+    np.savez_compressed(os.path.join(OUT, "cov3d.npz"), scales=scales, rots_raw=rots_raw, rots_normalized=rots_n,
+                        **covs)
+
+    # ---- 3 + 4. stereo poses and per-view uniforms ------------------------------------
+    from scipy.spatial.transform import Rotation
+    n = 12
+    Rw2c = Rotation.random(n, random_state=7).as_matrix()
+    t = rng.uniform(-3, 3, size=(n, 3))
+    poses = np.concatenate([Rw2c, t[..., None]], axis=-1)            # [n,3,4] world->cam (poses_from_file)
+    W_, H_ = 1600, 1200
+    fx, fy = 2892.33, 2883.18
+    baseline = 0.245
+    rec = dict(poses=poses, width=W_, height=H_, fx=fx, fy=fy, baseline=baseline)
+    keys = ["left_rot", "left_pos", "right_rot", "right_pos", "extrinsic", "R_gs_left", "T_gs_left", "R_gs_right",
+            "T_gs_right", "wvt_left", "proj", "full_left", "center_left", "wvt_right", "full_right", "center_right"]
+    acc = {k: [] for k in keys}
+    for i in range(n):
+        # renderer_utils.py:134-141
+        pose_inv = np.linalg.inv(np.vstack((poses[i], np.array([0, 0, 0, 1]))))
+        cam_rot = tu.rotm2eul(pose_inv[:3, :3])
+        rotation = tu.eul2rotm(cam_rot)
+        rotation[:, 1:] *= -1
+        cam_rot = tu.rotm2eul(rotation)
+        cam_loc = pose_inv[:3, 3].tolist()
+        # renderer_utils.py:181,192
+        R_right, T_right = tu.calculate_right_camera_pose(cam_rot, cam_loc, baseline)
+        extrinsic = tu.RT_from_rot_pos(tuple(cam_rot), tuple(cam_loc))
+        acc["left_rot"].append(np.asarray(cam_rot, np.float64))
+        acc["left_pos"].append(np.asarray(cam_loc, np.float64))
+        acc["right_rot"].append(np.asarray(R_right, np.float64))
+        acc["right_pos"].append(np.asarray(T_right, np.float64))
+        acc["extrinsic"].append(extrinsic)
+        FoVx = 2 * np.arctan2(W_, 2 * fx)   # renderer_utils.py:384-385
+        FoVy = 2 * np.arctan2(H_, 2 * fy)
+        proj = graphics_utils.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=FoVx, fovY=FoVy).transpose(0, 1)
+        for eye, (rot, pos) in (("left", (tuple(cam_rot.tolist()), tuple(cam_loc))), ("right", (R_right, T_right))):
+            R, T = tu.convert_R_T_to_GS(tuple(rot), tuple(pos))      # renderer_utils.py:381
+            # GS/scene/cameras.py:54-57 on CPU
+            wvt = torch.tensor(graphics_utils.getWorld2View2(R, T, np.array([0.0, 0.0, 0.0]), 1.0)).transpose(0, 1)
+            full = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0)
+            center = wvt.inverse()[3, :3]
+            acc[f"R_gs_{eye}"].append(np.asarray(R, np.float64))
+            acc[f"T_gs_{eye}"].append(np.asarray(T, np.float64))
+            acc[f"wvt_{eye}"].append(wvt.numpy())
+            acc[f"full_{eye}"].append(full.numpy())
+            acc[f"center_{eye}"].append(center.numpy())
+        acc["proj"].append(proj.numpy())
+    np.savez_compressed(os.path.join(OUT, "stereo_cameras.npz"), **rec, **{k: np.stack(v) for k, v in acc.items()})
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
