@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI (include/gs2mesh_amd.h).
+
+``get()`` loads ``gs2mesh_amd/libgs2mesh_amd.so`` -- the HIP/gfx950 build -- and raises if it is
+missing: there is no CPU fallback in the product.  ``bind(cdll)`` only attaches prototypes; the
+test-suite also uses it on the CPU emulator build of the same kernel sources (tests/emu).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgs2mesh_amd.so")
+
+vp = C.c_void_p
+i32 = C.c_int
+i64 = C.c_int64
+f32 = C.c_float
+f64 = C.c_double
+
+
+class Camera(C.Structure):
+    """gs2m_camera (host struct)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tanfovx", f32), ("tanfovy", f32),
+                ("viewmatrix", f32 * 16), ("projmatrix", f32 * 16), ("campos", f32 * 3)]
+
+
+class Gaussians(C.Structure):
+    """gs2m_gaussians (host struct of device pointers)."""
+    _fields_ = [("P", C.c_int32), ("sh_degree", C.c_int32), ("M", C.c_int32), ("raw", C.c_int32),
+                ("xyz", vp), ("scales", vp), ("rotations", vp), ("opacities", vp), ("shs", vp), ("shs_rest", vp)]
+
+
+OPT_EXACT_TILE_CULL = 1
+OPT_BLEND_VARIANT = 2
+OPT_DEBUG_SYNC = 3
+
+_PROTOS = {
+    "gs2m_version": (i32, []),
+    "gs2m_last_error": (C.c_char_p, []),
+    "gs2m_raster_create": (i32, [C.POINTER(vp), i32]),
+    "gs2m_raster_destroy": (i32, [vp]),
+    "gs2m_raster_set_option": (i32, [vp, i32, i32]),
+    "gs2m_raster_reserve": (i32, [vp, i32, i32, i32, i32, i64]),
+    "gs2m_rasterize_forward": (i32, [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp,
+                                     f32, f32, i32, vp, vp, i32, vp]),
+    "gs2m_mark_visible": (i32, [i32, vp, vp, vp, vp, vp]),
+    "gs2m_render_views": (i32, [vp, C.POINTER(Gaussians), C.POINTER(Camera), i32, C.POINTER(f32), f32, vp, vp, vp,
+                                vp]),
+    "gs2m_raster_status": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
+    "gs2m_raster_download_geometry": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "gs2m_raster_download_binning": (i32, [vp, vp, i32, i64, vp, C.c_int32, vp]),
+    "gs2m_tsdf_create": (i32, [C.POINTER(vp), f64, f64, i32, i32, i32, i64, i32]),
+    "gs2m_tsdf_destroy": (i32, [vp]),
+    "gs2m_tsdf_reset": (i32, [vp, vp]),
+    "gs2m_tsdf_integrate": (i32, [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, C.POINTER(f64), f64, f64, f64, vp]),
+    "gs2m_tsdf_status": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
+    "gs2m_tsdf_download": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    "gs2m_tsdf_block_keys": (i32, [vp, i64, vp, vp]),
+    "gs2m_tsdf_pack": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    "gs2m_tsdf_unpack": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+}
+
+SYMBOLS = tuple(_PROTOS)
+
+
+def bind(lib: C.CDLL, require_all: bool = True) -> C.CDLL:
+    for name, (res, args) in _PROTOS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if require_all:
+                raise
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_LIB = None
+# tests that run the emulator build flip this (tests/emu_lib.py); the product never does
+ALLOW_HOST_POINTERS = False
+
+
+def get() -> C.CDLL:
+    """The HIP library, loaded once.  Raises RuntimeError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `python -m gs2mesh_amd.build`; there is no CPU fallback)")
+        _LIB = bind(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+def check(rc: int, lib: C.CDLL | None = None):
+    if rc != 0:
+        lib = lib or get()
+        raise RuntimeError("gs2mesh_amd: " + lib.gs2m_last_error().decode(errors="replace"))

@@ -1,0 +1,36 @@
+// platform.h (product build) -- the only platform the shipped library is built for:
+// HIP on gfx950 (MI355X, CDNA4, wave64).  Kernels include "platform.h" and use the small
+// vocabulary below; tests/emu/platform.h provides the same vocabulary on CPU fibers so the
+// kernel SOURCE can be executed in the GPU-less build container (test infrastructure only,
+// never linked into libgs2mesh_amd.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GS2M_KERNEL __global__
+#define GS2M_DEVICE __device__ __forceinline__
+#define GS2M_PLATFORM_NAME "hip-gfx950"
+
+// Dynamic LDS, 16-byte aligned (guide G17: keep the dynamic-LDS base 16-B aligned).
+#define GS2M_DYN_LDS(type, name)                                              \
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs2m_dyn_lds_raw[]; \
+    type* name = reinterpret_cast<type*>(gs2m_dyn_lds_raw)
+
+#define GS2M_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, (hipStream_t)(stream), __VA_ARGS__)
+
+// wave64 vocabulary
+GS2M_DEVICE unsigned long long gs2m_ballot(int pred) { return __ballot(pred); }
+GS2M_DEVICE int gs2m_lane() { return (int)(threadIdx.x & 63u); }
+GS2M_DEVICE int gs2m_popc64(unsigned long long m) { return __popcll(m); }
+template <typename T>
+GS2M_DEVICE T gs2m_shfl(T v, int src_lane) { return __shfl(v, src_lane, 64); }
+template <typename T>
+GS2M_DEVICE T gs2m_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
+template <typename T>
+GS2M_DEVICE T gs2m_shfl_up(T v, int d) { return __shfl_up(v, d, 64); }
+
+GS2M_DEVICE int gs2m_syncthreads_count(int pred) { return __syncthreads_count(pred); }
+
+// fast exp for the blend kernel: v_exp_f32(x * log2e) (documented tolerance in DESIGN.md)
+GS2M_DEVICE float gs2m_fast_exp(float x) { return __expf(x); }

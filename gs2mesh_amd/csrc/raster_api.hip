@@ -1,0 +1,484 @@
+// raster_api.hip -- C ABI of the rasteriser (include/gs2mesh_amd.h): handles, grow-only arenas,
+// stage sequencing.  Host code only; kernels live in raster_{project,bin,blend}.hip.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/gs2mesh_amd.h"
+#include "raster_internal.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+void gs2m_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+extern "C" const char* gs2m_last_error(void) { return g_err.c_str(); }
+extern "C" int gs2m_version(void) { return GS2M_VERSION; }
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            gs2m_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define GS2M_MAX_STATUS 64  // views per gs2m_render_views call whose status is kept
+
+struct gs2m_raster {
+    int device = 0;
+    int opt_exact_cull = 0, opt_blend = 0, opt_debug = 0;
+    CamUniform* d_cams = nullptr;  // [GS2M_MAX_VIEWS]
+    GeomRec* d_recs = nullptr;
+    size_t recs_cap = 0;  // records
+    unsigned* d_hist = nullptr;
+    size_t hist_cap = 0;  // words
+    unsigned* d_tile_count = nullptr;
+    unsigned* d_tile_start = nullptr;
+    size_t tile_cap = 0;  // words per array
+    unsigned long long* d_keys = nullptr;
+    unsigned long long* d_tmp = nullptr;
+    size_t keys_cap_total = 0;  // entries in each of d_keys / d_tmp
+    unsigned inst_cap = 0;      // per-view capacity requested
+    ViewStatus* d_status = nullptr;  // [GS2M_MAX_STATUS]
+    ViewStatus* h_status = nullptr;  // pinned
+    // last call
+    int last_P = 0, last_nv = 0, last_tiles = 0, last_views_total = 0;
+    unsigned last_cap = 0;
+};
+
+template <typename T>
+static int ensure(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return 0;
+    if (*p) {
+        HIPCHK(hipFree(*p));  // synchronises: safe w.r.t. in-flight work
+        *p = nullptr;
+        *cap = 0;
+    }
+    size_t n = need + need / 8 + 64;
+    HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+    *cap = n;
+    return 0;
+}
+
+extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
+    if (!out) {
+        gs2m_set_error("gs2m_raster_create: out is NULL");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(device));
+    gs2m_raster* r = new gs2m_raster();
+    r->device = device;
+    if (hipMalloc((void**)&r->d_cams, sizeof(CamUniform) * GS2M_MAX_VIEWS) != hipSuccess ||
+        hipMalloc((void**)&r->d_status, sizeof(ViewStatus) * GS2M_MAX_STATUS) != hipSuccess ||
+        hipHostMalloc((void**)&r->h_status, sizeof(ViewStatus) * GS2M_MAX_STATUS) != hipSuccess) {
+        gs2m_set_error("gs2m_raster_create: allocation failed");
+        delete r;
+        return 1;
+    }
+    memset(r->h_status, 0, sizeof(ViewStatus) * GS2M_MAX_STATUS);
+    *out = r;
+    return 0;
+}
+
+extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
+    if (!r) return 0;
+    (void)hipFree(r->d_cams);
+    (void)hipFree(r->d_recs);
+    (void)hipFree(r->d_hist);
+    (void)hipFree(r->d_tile_count);
+    (void)hipFree(r->d_tile_start);
+    (void)hipFree(r->d_keys);
+    (void)hipFree(r->d_tmp);
+    (void)hipFree(r->d_status);
+    (void)hipHostFree(r->h_status);
+    delete r;
+    return 0;
+}
+
+extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    switch (option) {
+        case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
+        case GS2M_OPT_BLEND_VARIANT: r->opt_blend = value; return 0;
+        case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
+        default: gs2m_set_error("unknown option %d", option); return 1;
+    }
+}
+
+static void geometry(int P, int* chunk, int* n_wg) {
+    // ~512 workgroups (2 per CU), chunks a multiple of 256 Gaussians
+    int c = (P + 511) / 512;
+    c = (c + 255) / 256 * 256;
+    if (c < 256) c = 256;
+    *chunk = c;
+    *n_wg = (P + c - 1) / c;
+    if (*n_wg < 1) *n_wg = 1;
+}
+
+extern "C" int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, int H, int64_t instances) {
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(r->device));
+    const int nv = n_views < GS2M_MAX_VIEWS ? (n_views < 1 ? 1 : n_views) : GS2M_MAX_VIEWS;
+    const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
+    int chunk, n_wg;
+    geometry(P, &chunk, &n_wg);
+    if (ensure(&r->d_recs, &r->recs_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
+    if (ensure(&r->d_hist, &r->hist_cap, (size_t)nv * n_wg * tiles)) return 1;
+    size_t tc = r->tile_cap;
+    if (ensure(&r->d_tile_count, &tc, (size_t)nv * (tiles + 1))) return 1;
+    if (ensure(&r->d_tile_start, &r->tile_cap, (size_t)nv * (tiles + 1))) return 1;
+    if (instances > 0xfffffff0ll) {
+        gs2m_set_error("instance count %lld exceeds the 32-bit offsets of the binning stage", (long long)instances);
+        return 1;
+    }
+    if (instances > 0 && (unsigned)instances > r->inst_cap) r->inst_cap = (unsigned)instances;
+    if (r->inst_cap < 1024) r->inst_cap = 1024;
+    size_t kc = r->keys_cap_total;
+    if (ensure(&r->d_keys, &kc, (size_t)nv * r->inst_cap)) return 1;
+    if (ensure(&r->d_tmp, &r->keys_cap_total, (size_t)nv * r->inst_cap)) return 1;
+    return 0;
+}
+
+static int dbg_check(gs2m_raster* r, hipStream_t st, const char* what) {
+    if (!r->opt_debug) return 0;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        gs2m_set_error("[debug] after %s: %s", what, hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+// One fused pass over nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams.
+static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, float* out_color,
+                     unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
+    const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
+    const int tiles = gx * gy;
+    const size_t lds = (size_t)nv * tiles * sizeof(unsigned);
+    if (lds > 160 * 1024) {
+        gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile histogram", W, H, nv, tiles);
+        return 1;
+    }
+    int chunk, n_wg;
+    geometry(g.P, &chunk, &n_wg);
+    if (r->inst_cap == 0) {
+        // first call: 4 instances per Gaussian, at least 64k
+        int64_t guess = (int64_t)g.P * 4;
+        if (guess < 65536) guess = 65536;
+        r->inst_cap = (unsigned)(guess > 0xfffffff0ll ? 0xfffffff0ll : guess);
+    }
+    if (gs2m_raster_reserve(r, g.P, nv, W, H, 0)) return 1;
+    const unsigned cap = r->inst_cap;
+    if (gs2m_launch_project_count(nv, n_wg, lds, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
+                                  r->opt_exact_cull))
+        return 1;
+    if (dbg_check(r, st, "project_count")) return 1;
+    gs2m_launch_hist_colscan(st, nv, r->d_hist, n_wg, tiles, r->d_tile_count);
+    if (dbg_check(r, st, "hist_colscan")) return 1;
+    gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + status_slot, cap);
+    if (dbg_check(r, st, "tile_scan")) return 1;
+    if (gs2m_launch_scatter(nv, n_wg, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
+                            r->d_keys, cap, r->opt_exact_cull))
+        return 1;
+    if (dbg_check(r, st, "scatter")) return 1;
+    gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap);
+    if (dbg_check(r, st, "sort_tiles")) return 1;
+    gs2m_launch_blend(st, r->opt_blend, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams, g.P, cap,
+                      out_color, out_rgb8);
+    if (dbg_check(r, st, "blend")) return 1;
+    r->last_P = g.P;
+    r->last_nv = nv;
+    r->last_tiles = tiles;
+    r->last_cap = cap;
+    return 0;
+}
+
+extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const float* background, int width,
+                                      int height, const float* means3D, const float* shs,
+                                      const float* colors_precomp, const float* opacities, const float* scales,
+                                      float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                      const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                                      float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                                      int* radii, int debug, gs2m_stream stream) {
+    (void)prefiltered;  // only changes the reference's in-kernel trap (auxiliary.h:156-160)
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(r->device));
+    if (width <= 0 || height <= 0 || !out_color) {
+        gs2m_set_error("gs2m_rasterize_forward: bad image arguments");
+        return 1;
+    }
+    if (D < 0 || D > 3) {
+        gs2m_set_error("SH degree %d not in 0..3", D);
+        return 1;
+    }
+    r->last_views_total = 1;
+    if (P == 0) {
+        // rasterize_points.cu:68,81: the zero-filled image is returned untouched
+        HIPCHK(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, st));
+        HIPCHK(hipMemsetAsync(r->d_status, 0, sizeof(ViewStatus), st));
+        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus), hipMemcpyDeviceToHost, st));
+        r->last_P = 0;
+        r->last_nv = 1;
+        return 0;
+    }
+    if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos) {
+        gs2m_set_error("gs2m_rasterize_forward: NULL required pointer");
+        return 1;
+    }
+    if ((shs == nullptr) == (colors_precomp == nullptr)) {
+        gs2m_set_error("Please provide excatly one of either SHs or precomputed colors!");
+        return 1;
+    }
+    if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
+        ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr)) {
+        gs2m_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+        return 1;
+    }
+    if (shs && (M < (D + 1) * (D + 1))) {
+        gs2m_set_error("M = %d SH coefficients < (D+1)^2 = %d", M, (D + 1) * (D + 1));
+        return 1;
+    }
+    GaussIn g;
+    g.xyz = means3D;
+    g.scales = scales;
+    g.rots = rotations;
+    g.opac = opacities;
+    g.shs = shs;
+    g.shs_rest = nullptr;
+    g.cov3D_precomp = cov3D_precomp;
+    g.colors_precomp = colors_precomp;
+    g.P = P;
+    g.D = D;
+    g.M = M;
+    g.raw = 0;
+    g.scale_modifier = scale_modifier;
+    const int saved_debug = r->opt_debug;
+    if (debug) r->opt_debug = 1;
+    gs2m_launch_pack_camera(st, r->d_cams, 0, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy,
+                            width, height);
+    int rc = run_views(r, g, 1, width, height, out_color, nullptr, radii, 0, st);
+    r->opt_debug = saved_debug;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus), hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+extern "C" int gs2m_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                                 uint8_t* present, gs2m_stream stream) {
+    (void)projmatrix;
+    if (P <= 0) return 0;
+    if (!means3D || !viewmatrix || !present) {
+        gs2m_set_error("gs2m_mark_visible: NULL pointer");
+        return 1;
+    }
+    gs2m_launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present);
+    return 0;
+}
+
+extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const gs2m_camera* cams, int n_views,
+                                 const float* bg, float scale_modifier, float* out_color, uint8_t* out_rgb8,
+                                 int* out_radii, gs2m_stream stream) {
+    if (!r || !gs || !cams || !bg) {
+        gs2m_set_error("gs2m_render_views: NULL argument");
+        return 1;
+    }
+    if (n_views < 1 || n_views > GS2M_MAX_STATUS) {
+        gs2m_set_error("n_views = %d not in 1..%d", n_views, GS2M_MAX_STATUS);
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(r->device));
+    const int W = cams[0].width, H = cams[0].height;
+    for (int v = 0; v < n_views; ++v)
+        if (cams[v].width != W || cams[v].height != H || W <= 0 || H <= 0) {
+            gs2m_set_error("all views of a batch must share one positive width/height");
+            return 1;
+        }
+    if (gs->sh_degree < 0 || gs->sh_degree > 3 || gs->M < (gs->sh_degree + 1) * (gs->sh_degree + 1)) {
+        gs2m_set_error("bad SH layout: degree %d, M %d", gs->sh_degree, gs->M);
+        return 1;
+    }
+    r->last_views_total = n_views;
+    const size_t img = (size_t)W * H;
+    if (gs->P == 0) {
+        if (out_color) HIPCHK(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * img * n_views, st));
+        if (out_rgb8) HIPCHK(hipMemsetAsync(out_rgb8, 0, 3 * img * n_views, st));
+        HIPCHK(hipMemsetAsync(r->d_status, 0, sizeof(ViewStatus) * n_views, st));
+        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * n_views, hipMemcpyDeviceToHost, st));
+        return 0;
+    }
+    if (!gs->xyz || !gs->scales || !gs->rotations || !gs->opacities || !gs->shs) {
+        gs2m_set_error("gs2m_render_views: NULL Gaussian array");
+        return 1;
+    }
+    GaussIn g;
+    g.xyz = gs->xyz;
+    g.scales = gs->scales;
+    g.rots = gs->rotations;
+    g.opac = gs->opacities;
+    g.shs = gs->shs;
+    g.shs_rest = gs->shs_rest;
+    g.cov3D_precomp = nullptr;
+    g.colors_precomp = nullptr;
+    g.P = gs->P;
+    g.D = gs->sh_degree;
+    g.M = gs->M;
+    g.raw = gs->raw;
+    g.scale_modifier = scale_modifier;
+    const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
+    // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS histogram allows
+    int per = GS2M_MAX_VIEWS;
+    while (per > 1 && (size_t)per * tiles * sizeof(unsigned) > 160 * 1024) per--;
+    for (int v0 = 0; v0 < n_views; v0 += per) {
+        const int nv = n_views - v0 < per ? n_views - v0 : per;
+        for (int k = 0; k < nv; ++k) {
+            const gs2m_camera& c = cams[v0 + k];
+            CamUniform u;
+            memcpy(u.view, c.viewmatrix, sizeof(u.view));
+            memcpy(u.proj, c.projmatrix, sizeof(u.proj));
+            memcpy(u.campos, c.campos, sizeof(u.campos));
+            u.tanfovx = c.tanfovx;
+            u.tanfovy = c.tanfovy;
+            u.focal_y = H / (2.0f * c.tanfovy);  // rasterizer_impl.cu:222-223
+            u.focal_x = W / (2.0f * c.tanfovx);
+            u.W = W;
+            u.H = H;
+            u.gx = (W + GS2M_TILE - 1) / GS2M_TILE;
+            u.gy = (H + GS2M_TILE - 1) / GS2M_TILE;
+            u.bg[0] = bg[0];
+            u.bg[1] = bg[1];
+            u.bg[2] = bg[2];
+            u.pad = 0;
+            gs2m_launch_set_camera(st, r->d_cams, k, u);
+        }
+        if (run_views(r, g, nv, W, H, out_color ? out_color + 3 * img * v0 : nullptr,
+                      out_rgb8 ? out_rgb8 + 3 * img * v0 : nullptr,
+                      out_radii ? out_radii + (size_t)gs->P * v0 : nullptr, v0, st))
+            return 1;
+    }
+    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * n_views, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_views, int64_t* num_rendered,
+                                  int* overflow, int64_t* required) {
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipGetLastError());
+    int ov = 0;
+    int64_t req = 0;
+    const int n = n_views < r->last_views_total ? n_views : r->last_views_total;
+    for (int v = 0; v < r->last_views_total && v < GS2M_MAX_STATUS; ++v) {
+        ov |= r->h_status[v].overflow != 0;
+        if ((int64_t)r->h_status[v].num_rendered > req) req = r->h_status[v].num_rendered;
+    }
+    for (int v = 0; v < n && num_rendered; ++v) num_rendered[v] = r->h_status[v].num_rendered;
+    if (overflow) *overflow = ov;
+    if (required) *required = req;
+    return 0;
+}
+
+extern "C" int gs2m_raster_download_geometry(gs2m_raster* r, gs2m_stream stream, int v, int P, float* means2D,
+                                             float* depths, float* conic_opacity, float* rgb, uint16_t* rect,
+                                             uint32_t* tiles_touched) {
+    if (!r || v < 0 || v >= r->last_nv || P != r->last_P) {
+        gs2m_set_error("gs2m_raster_download_geometry: view %d / P %d do not match the last call", v, P);
+        return 1;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (P == 0) return 0;
+    GeomRec* h = (GeomRec*)malloc(sizeof(GeomRec) * (size_t)P);
+    if (!h) {
+        gs2m_set_error("out of host memory");
+        return 1;
+    }
+    hipError_t e = hipMemcpy(h, r->d_recs + (size_t)v * P, sizeof(GeomRec) * (size_t)P, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        free(h);
+        gs2m_set_error("hipMemcpy: %s", hipGetErrorString(e));
+        return 1;
+    }
+    for (int i = 0; i < P; ++i) {
+        const GeomRec& q = h[i];
+        const unsigned x0 = q.rect0 & 0xffffu, y0 = q.rect0 >> 16, x1 = q.rect1 & 0xffffu, y1 = q.rect1 >> 16;
+        const bool vis = x1 > x0 && y1 > y0;
+        if (means2D) {
+            means2D[2 * i] = vis ? q.mx : 0.f;
+            means2D[2 * i + 1] = vis ? q.my : 0.f;
+        }
+        if (depths) depths[i] = vis ? q.depth : 0.f;
+        if (conic_opacity) {
+            conic_opacity[4 * i] = vis ? q.ca : 0.f;
+            conic_opacity[4 * i + 1] = vis ? q.cb : 0.f;
+            conic_opacity[4 * i + 2] = vis ? q.cc : 0.f;
+            conic_opacity[4 * i + 3] = vis ? q.op : 0.f;
+        }
+        if (rgb) {
+            rgb[3 * i] = vis ? q.r : 0.f;
+            rgb[3 * i + 1] = vis ? q.g : 0.f;
+            rgb[3 * i + 2] = vis ? q.b : 0.f;
+        }
+        if (rect) {
+            rect[4 * i] = (uint16_t)x0;
+            rect[4 * i + 1] = (uint16_t)y0;
+            rect[4 * i + 2] = (uint16_t)x1;
+            rect[4 * i + 3] = (uint16_t)y1;
+        }
+        if (tiles_touched) tiles_touched[i] = vis ? (x1 - x0) * (y1 - y0) : 0u;
+    }
+    free(h);
+    return 0;
+}
+
+extern "C" int gs2m_raster_download_binning(gs2m_raster* r, gs2m_stream stream, int v, int64_t n,
+                                            uint32_t* point_list, int32_t n_tiles, uint32_t* ranges) {
+    if (!r || v < 0 || v >= r->last_nv || n_tiles != r->last_tiles) {
+        gs2m_set_error("gs2m_raster_download_binning: arguments do not match the last call");
+        return 1;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (ranges) {
+        unsigned* ts = (unsigned*)malloc(sizeof(unsigned) * (size_t)(n_tiles + 1));
+        HIPCHK(hipMemcpy(ts, r->d_tile_start + (size_t)v * (n_tiles + 1), sizeof(unsigned) * (size_t)(n_tiles + 1),
+                         hipMemcpyDeviceToHost));
+        for (int t = 0; t < n_tiles; ++t) {
+            // the reference leaves {0,0} for empty tiles (cudaMemset, rasterizer_impl.cu:310)
+            const bool empty = ts[t + 1] == ts[t];
+            ranges[2 * t] = empty ? 0u : ts[t];
+            ranges[2 * t + 1] = empty ? 0u : ts[t + 1];
+        }
+        free(ts);
+    }
+    if (point_list && n > 0) {
+        if ((uint64_t)n > r->last_cap) n = r->last_cap;
+        unsigned long long* k = (unsigned long long*)malloc(sizeof(unsigned long long) * (size_t)n);
+        HIPCHK(hipMemcpy(k, r->d_keys + (size_t)v * r->last_cap, sizeof(unsigned long long) * (size_t)n,
+                         hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) point_list[i] = (uint32_t)(k[i] & 0xffffffffull);
+        free(k);
+    }
+    return 0;
+}

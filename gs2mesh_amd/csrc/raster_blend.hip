@@ -1,0 +1,11 @@
+// raster_blend.hip -- compositing stage (default FMA contraction; VALU-bound inner loop).
+#include "raster_blend.h"
+#include "raster_internal.h"
+
+void gs2m_launch_blend(hipStream_t st, int variant, int nv, int gx, int gy, const unsigned long long* keys,
+                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
+                       unsigned cap, float* out_color, unsigned char* out_rgb8) {
+    (void)variant;
+    GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
+                out_color, out_rgb8);
+}

@@ -1,0 +1,51 @@
+// raster_common.h -- data layout of the rasteriser in HBM (see DESIGN.md "Data layout").
+#pragma once
+#include "platform.h"
+
+#define GS2M_TILE 16        // DGR/cuda_rasterizer/config.h:16-17 (BLOCK_X = BLOCK_Y = 16)
+#define GS2M_MAX_VIEWS 2    // views fused per launch (a stereo pair)
+#define GS2M_SORT_LDS 4096  // keys sorted per workgroup in LDS (32 KiB)
+
+// Per-view uniforms (the per-view fields of GaussianRasterizationSettings,
+// DGR/diff_gaussian_rasterization/__init__.py:157-169, + derived focal / tile grid,
+// rasterizer_impl.cu:222-223,234).  Lives in device memory, one per view of the batch.
+struct CamUniform {
+    float view[16];  // "viewmatrix": transposed row-major, m[4c+r] = M[r][c]
+    float proj[16];  // "projmatrix"
+    float campos[3];
+    float tanfovx, tanfovy, focal_x, focal_y;
+    int W, H, gx, gy;
+    float bg[3];
+    int pad;
+};
+
+// Projected per-(view, Gaussian) record: 48 B, three 16-B vectors so that the blend stage
+// gathers one contiguous record per instance instead of three arrays
+// (reference: means2D 8 B + conic_opacity 16 B + rgb 12 B + depth 4 B in four arrays,
+// rasterizer_impl.h:30-45; rgb gathered from global per contributing pixel, forward.cu:355).
+struct alignas(16) GeomRec {
+    float mx, my, ca, cb;    // mean2D, conic.x, conic.y
+    float cc, op, r, g;      // conic.z, opacity, rgb.r, rgb.g
+    float b, depth;          // rgb.b, view-space z
+    unsigned rect0, rect1;   // tile rect: rect0 = x0 | y0<<16, rect1 = x1 | y1<<16 (x1==x0 => invisible)
+};
+
+// Inputs of the projection stage (device pointers).
+struct GaussIn {
+    const float* xyz;             // [P,3]
+    const float* scales;          // [P,3] (log-scale if raw)
+    const float* rots;            // [P,4] wxyz (unnormalised if raw)
+    const float* opac;            // [P]   (logit if raw)
+    const float* shs;             // [P,M,3], or features_dc [P,1,3] when shs_rest != null
+    const float* shs_rest;        // null or features_rest [P,M-1,3]
+    const float* cov3D_precomp;   // null or [P,6]
+    const float* colors_precomp;  // null or [P,3]
+    int P, D, M, raw;
+    float scale_modifier;
+};
+
+// Per-view status words written by the tile scan.
+struct ViewStatus {
+    unsigned num_rendered;  // instances this view produced
+    unsigned overflow;      // 1 if num_rendered > arena capacity (results invalid)
+};

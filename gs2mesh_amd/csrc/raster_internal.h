@@ -1,0 +1,33 @@
+// raster_internal.h -- launch wrappers shared between the translation units of the rasteriser.
+// Each .hip file is compiled on its own so that per-stage floating-point contraction can
+// differ (projection: -ffp-contract=off for a literal IEEE sequence; blend: default fast
+// contraction, FMA).
+#pragma once
+#include "raster_common.h"
+
+struct CamUniformArg;
+
+int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
+                              const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
+                              int exact_cull);
+int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+                        const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
+                        unsigned long long* keys, unsigned cap, int exact_cull);
+void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,
+                              unsigned char* present);
+void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,
+                             const float* projmatrix, const float* campos, const float* bg, float tanfovx,
+                             float tanfovy, int W, int H);
+void gs2m_launch_set_camera(hipStream_t st, CamUniform* cams, int slot, const CamUniform& c);
+
+void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count);
+void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles,
+                           ViewStatus* status, unsigned cap);
+void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
+                            const unsigned* tile_start, int tiles, unsigned cap);
+void gs2m_launch_blend(hipStream_t st, int variant, int nv, int gx, int gy, const unsigned long long* keys,
+                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
+                       unsigned cap, float* out_color, unsigned char* out_rgb8);
+
+// error plumbing (common_api.hip)
+void gs2m_set_error(const char* fmt, ...);

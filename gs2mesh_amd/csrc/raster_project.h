@@ -1,0 +1,312 @@
+// raster_project.h -- kernels of the projection / tile-counting / instance-scatter stages.
+//
+// Stage map (reference -> here):
+//   preprocessCUDA            forward.cu:155-256          -> k_project_count (fused: activations,
+//   cub InclusiveSum + D2H    rasterizer_impl.cu:277-281     Sigma once per Gaussian for all views
+//   duplicateWithKeys         rasterizer_impl.cu:70-111      of the batch, per-workgroup LDS tile
+//                                                            histogram instead of a per-Gaussian scan)
+//                                                         -> k_scatter (LDS cursors, 8-B keys)
+// Instead of emitting (tile<<32|depth, id) pairs in Gaussian order and radix-sorting 64-bit keys
+// through HBM 5-6 times, instances are counting-sorted by tile with workgroup-private LDS
+// histograms (160 KiB LDS holds a 40k-tile histogram), then depth-sorted per tile in LDS
+// (raster_sort.h).  The final order is identical to the reference's: ascending depth bits, ties
+// by ascending Gaussian id (= what the stable radix sort over emission order produces).
+#pragma once
+#include "raster_math.h"
+
+struct ProjView {
+    float mx, my, ca, cb, cc, depth;
+    int x0, y0, x1, y1, radius;
+    bool ok;
+};
+
+// Geometry of one Gaussian in one view: forward.cu:186-237 up to the zero-area test.
+GS2M_DEVICE void project_view(const CamUniform& cam, float px, float py, float pz, const float* cov3, ProjView& o) {
+    o.ok = false;
+    o.radius = 0;
+    o.x0 = o.y0 = o.x1 = o.y1 = 0;
+    o.mx = o.my = o.ca = o.cb = o.cc = o.depth = 0.0f;
+    float tvx, tvy, tvz;
+    xform4x3(cam.view, px, py, pz, tvx, tvy, tvz);
+    if (tvz <= 0.2f) return;  // auxiliary.h:154 near cull
+    float hx, hy, hz, hw;
+    xform4x4(cam.proj, px, py, pz, hx, hy, hz, hw);
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float ppx = hx * p_w, ppy = hy * p_w;
+    float a, b, c;
+    cov2d_ewa(cam.view, tvx, tvy, tvz, cam.focal_x, cam.focal_y, cam.tanfovx, cam.tanfovy, cov3, a, b, c);
+    const float det = (a * c - b * b);
+    if (det == 0.0f) return;
+    const float det_inv = 1.f / det;
+    o.ca = c * det_inv;
+    o.cb = -b * det_inv;
+    o.cc = a * det_inv;
+    const float mid = 0.5f * (a + c);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    o.mx = ndc2pix(ppx, cam.W);
+    o.my = ndc2pix(ppy, cam.H);
+    const int r = (int)my_radius;
+    // auxiliary.h:46-56 getRect
+    o.x0 = gs2m_imin(cam.gx, gs2m_imax(0, (int)((o.mx - r) / GS2M_TILE)));
+    o.y0 = gs2m_imin(cam.gy, gs2m_imax(0, (int)((o.my - r) / GS2M_TILE)));
+    o.x1 = gs2m_imin(cam.gx, gs2m_imax(0, (int)((o.mx + r + GS2M_TILE - 1) / GS2M_TILE)));
+    o.y1 = gs2m_imin(cam.gy, gs2m_imax(0, (int)((o.my + r + GS2M_TILE - 1) / GS2M_TILE)));
+    if ((o.x1 - o.x0) * (o.y1 - o.y0) == 0) {
+        o.x0 = o.y0 = o.x1 = o.y1 = 0;
+        return;
+    }
+    o.depth = tvz;
+    o.radius = r;
+    o.ok = true;
+}
+
+template <int NV>
+GS2M_KERNEL void __launch_bounds__(256)
+k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n_wg, GeomRec* __restrict__ recs,
+                int* __restrict__ radii, unsigned* __restrict__ hist, int exact_cull) {
+    GS2M_DYN_LDS(unsigned, lhist);
+    const int tid = (int)threadIdx.x;
+    const int gx = cams[0].gx, gy = cams[0].gy;
+    const int tiles = gx * gy;
+    for (int i = tid; i < NV * tiles; i += 256) lhist[i] = 0u;
+    __syncthreads();
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = gs2m_imin(g.P, begin + chunk);
+    const int ncoef = (g.D + 1) * (g.D + 1);
+    for (int base = begin; base < end; base += 256) {
+        const int gi = base + tid;
+        if (gi < end) {
+            const float px = g.xyz[3 * (size_t)gi], py = g.xyz[3 * (size_t)gi + 1], pz = g.xyz[3 * (size_t)gi + 2];
+            float cov3[6];
+            if (g.cov3D_precomp) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) cov3[k] = g.cov3D_precomp[6 * (size_t)gi + k];
+            } else {
+                float sx = g.scales[3 * (size_t)gi], sy = g.scales[3 * (size_t)gi + 1], sz = g.scales[3 * (size_t)gi + 2];
+                const float4 q4 = *reinterpret_cast<const float4*>(g.rots + 4 * (size_t)gi);
+                float qr = q4.x, qx = q4.y, qy = q4.z, qz = q4.w;
+                if (g.raw) {
+                    // GaussianModel getters (GS/scene/gaussian_model.py:95-101): exp, F.normalize
+                    sx = expf(sx);
+                    sy = expf(sy);
+                    sz = expf(sz);
+                    const float n = fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+                    qr = qr / n;
+                    qx = qx / n;
+                    qy = qy / n;
+                    qz = qz / n;
+                }
+                cov3d_from_scale_rot(sx, sy, sz, g.scale_modifier, qr, qx, qy, qz, cov3);
+            }
+            float op = g.opac[gi];
+            if (g.raw) op = 1.0f / (1.0f + expf(-op));  // gaussian_model.py:113-115 sigmoid
+            ProjView pv[NV];
+            bool any = false;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                project_view(cams[v], px, py, pz, cov3, pv[v]);
+                any = any || pv[v].ok;
+            }
+            float sh[48];
+            const bool need_sh = any && (g.colors_precomp == nullptr);
+            if (need_sh) {
+                if (g.shs_rest == nullptr && g.M == 16) {
+                    // 192-B row, 16-B aligned: 12 x dwordx4
+                    const float4* s4 = reinterpret_cast<const float4*>(g.shs + 48 * (size_t)gi);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        if (k * 4 < ncoef * 3) {
+                            const float4 t = s4[k];
+                            sh[4 * k] = t.x;
+                            sh[4 * k + 1] = t.y;
+                            sh[4 * k + 2] = t.z;
+                            sh[4 * k + 3] = t.w;
+                        }
+                    }
+                } else if (g.shs_rest == nullptr) {
+                    const float* s = g.shs + (size_t)gi * g.M * 3;
+#pragma unroll
+                    for (int k = 0; k < 48; ++k)
+                        if (k < ncoef * 3) sh[k] = s[k];
+                } else {
+                    const float* s0 = g.shs + (size_t)gi * 3;
+                    const float* s1 = g.shs_rest + (size_t)gi * (g.M - 1) * 3;
+                    sh[0] = s0[0];
+                    sh[1] = s0[1];
+                    sh[2] = s0[2];
+#pragma unroll
+                    for (int k = 3; k < 48; ++k)
+                        if (k < ncoef * 3) sh[k] = s1[k - 3];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                GeomRec* rec = recs + (size_t)v * g.P + gi;
+                if (radii) radii[(size_t)v * g.P + gi] = pv[v].radius;
+                if (!pv[v].ok) {
+                    // invisible: only the vector holding the (empty) rect is written
+                    float4 w2;
+                    w2.x = 0.0f;
+                    w2.y = 0.0f;
+                    w2.z = 0.0f;
+                    w2.w = 0.0f;
+                    reinterpret_cast<float4*>(rec)[2] = w2;
+                    continue;
+                }
+                float cr, cg, cb;
+                if (g.colors_precomp) {
+                    cr = g.colors_precomp[3 * (size_t)gi];
+                    cg = g.colors_precomp[3 * (size_t)gi + 1];
+                    cb = g.colors_precomp[3 * (size_t)gi + 2];
+                } else {
+                    // forward.cu:25-27: dir = (pos - campos) / length
+                    float dx = px - cams[v].campos[0], dy = py - cams[v].campos[1], dz = pz - cams[v].campos[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dx = dx / len;
+                    dy = dy / len;
+                    dz = dz / len;
+                    cr = sh_channel(g.D, sh, 0, dx, dy, dz);
+                    cg = sh_channel(g.D, sh, 1, dx, dy, dz);
+                    cb = sh_channel(g.D, sh, 2, dx, dy, dz);
+                }
+                float4 w0, w1, w2;
+                w0.x = pv[v].mx;
+                w0.y = pv[v].my;
+                w0.z = pv[v].ca;
+                w0.w = pv[v].cb;
+                w1.x = pv[v].cc;
+                w1.y = op;
+                w1.z = cr;
+                w1.w = cg;
+                w2.x = cb;
+                w2.y = pv[v].depth;
+                w2.z = __uint_as_float((unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16));
+                w2.w = __uint_as_float((unsigned)pv[v].x1 | ((unsigned)pv[v].y1 << 16));
+                float4* r4 = reinterpret_cast<float4*>(rec);
+                r4[0] = w0;
+                r4[1] = w1;
+                r4[2] = w2;
+                // per-workgroup LDS tile histogram (replaces tiles_touched + InclusiveSum)
+                const float thr = exact_cull ? cull_threshold(op) : 0.0f;
+                if (exact_cull && thr < 0.0f) continue;
+                unsigned* h = lhist + v * tiles;
+                for (int ty = pv[v].y0; ty < pv[v].y1; ++ty)
+                    for (int tx = pv[v].x0; tx < pv[v].x1; ++tx)
+                        if (!exact_cull || tile_may_contribute(pv[v].mx, pv[v].my, pv[v].ca, pv[v].cb, pv[v].cc, thr, tx, ty))
+                            atomicAdd(&h[ty * gx + tx], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < NV * tiles; i += 256) {
+        const int v = i / tiles, t = i - v * tiles;
+        hist[((size_t)v * n_wg + blockIdx.x) * tiles + t] = lhist[i];
+    }
+}
+
+// Instance scatter: same Gaussian -> workgroup assignment as k_project_count; cursors start at
+// tile_start[v][t] + (exclusive prefix over workgroups, left in `hist` by k_hist_colscan).
+// Key = depth_bits << 32 | gaussian_id (unique => order after the per-tile sort is deterministic
+// although LDS-atomic arrival order is not).
+template <int NV>
+GS2M_KERNEL void __launch_bounds__(256)
+k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
+          const unsigned* __restrict__ hist, const unsigned* __restrict__ tile_start,
+          unsigned long long* __restrict__ keys, unsigned cap, int exact_cull) {
+    GS2M_DYN_LDS(unsigned, cursor);
+    const int tid = (int)threadIdx.x;
+    const int gx = cams[0].gx, gy = cams[0].gy;
+    const int tiles = gx * gy;
+    for (int i = tid; i < NV * tiles; i += 256) {
+        const int v = i / tiles, t = i - v * tiles;
+        cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + blockIdx.x) * tiles + t];
+    }
+    __syncthreads();
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = gs2m_imin(P, begin + chunk);
+    for (int base = begin; base < end; base += 256) {
+        const int gi = base + tid;
+        if (gi < end) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi);
+                const float4 w2 = r4[2];
+                const unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w);
+                const int x0 = (int)(rect0 & 0xffffu), y0 = (int)(rect0 >> 16);
+                const int x1 = (int)(rect1 & 0xffffu), y1 = (int)(rect1 >> 16);
+                if (x1 <= x0 || y1 <= y0) continue;
+                float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
+                if (exact_cull) {
+                    const float4 w0 = r4[0];
+                    const float4 w1 = r4[1];
+                    mx = w0.x;
+                    my = w0.y;
+                    ca = w0.z;
+                    cb = w0.w;
+                    cc = w1.x;
+                    thr = cull_threshold(w1.y);
+                    if (thr < 0.0f) continue;
+                }
+                const unsigned long long hi = ((unsigned long long)__float_as_uint(w2.y)) << 32;
+                unsigned* cur = cursor + v * tiles;
+                unsigned long long* kv = keys + (size_t)v * cap;
+                for (int ty = y0; ty < y1; ++ty)
+                    for (int tx = x0; tx < x1; ++tx)
+                        if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
+                            const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
+                            if (pos < cap) kv[pos] = hi | (unsigned)gi;
+                        }
+            }
+        }
+    }
+}
+
+// checkFrustum (rasterizer_impl.cu:54-66): present = z_view > 0.2
+GS2M_KERNEL void __launch_bounds__(256)
+k_mark_visible(int P, const float* __restrict__ xyz, const float* __restrict__ viewmatrix,
+               unsigned char* __restrict__ present) {
+    const int gi = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (gi < P) {
+        float tx, ty, tz;
+        xform4x3(viewmatrix, xyz[3 * (size_t)gi], xyz[3 * (size_t)gi + 1], xyz[3 * (size_t)gi + 2], tx, ty, tz);
+        present[gi] = tz <= 0.2f ? 0 : 1;
+    }
+}
+
+// Fill the device CamUniform of view `slot` from DEVICE pointers (operator-level API, where
+// viewmatrix / projmatrix / campos / bg are device tensors as in the reference).
+GS2M_KERNEL void k_pack_camera(CamUniform* cams, int slot, const float* viewmatrix, const float* projmatrix,
+                               const float* campos, const float* bg, float tanfovx, float tanfovy, int W, int H) {
+    const int t = (int)threadIdx.x;
+    CamUniform* c = cams + slot;
+    if (t < 16) {
+        c->view[t] = viewmatrix[t];
+        c->proj[t] = projmatrix[t];
+    }
+    if (t < 3) {
+        c->campos[t] = campos[t];
+        c->bg[t] = bg[t];
+    }
+    if (t == 0) {
+        c->tanfovx = tanfovx;
+        c->tanfovy = tanfovy;
+        c->focal_y = H / (2.0f * tanfovy);  // rasterizer_impl.cu:222-223
+        c->focal_x = W / (2.0f * tanfovx);
+        c->W = W;
+        c->H = H;
+        c->gx = (W + GS2M_TILE - 1) / GS2M_TILE;
+        c->gy = (H + GS2M_TILE - 1) / GS2M_TILE;
+        c->pad = 0;
+    }
+}
+
+// Same from HOST values carried in the kernel arguments (pipeline-level API): the launch
+// packet is the transport, so no pinned staging buffer / lifetime hazard.
+struct CamUniformArg {
+    CamUniform c;
+};
+GS2M_KERNEL void k_set_camera(CamUniform* cams, int slot, CamUniformArg a) {
+    if (threadIdx.x == 0) cams[slot] = a.c;
+}

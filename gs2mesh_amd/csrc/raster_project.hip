@@ -1,0 +1,65 @@
+// raster_project.hip -- projection / counting / scatter stage (compiled with -ffp-contract=off).
+#include "raster_project.h"
+#include "raster_internal.h"
+
+int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
+                              const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
+                              int exact_cull) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_project_count<2>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                               : hipFuncSetAttribute((const void*)k_project_count<1>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            gs2m_set_error("hipFuncSetAttribute(k_project_count, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+            return 1;
+        }
+    }
+    if (nv == 2)
+        GS2M_LAUNCH((k_project_count<2>), dim3(n_wg), dim3(256), lds_bytes, st, g, cams, chunk, n_wg, recs, radii,
+                    hist, exact_cull);
+    else
+        GS2M_LAUNCH((k_project_count<1>), dim3(n_wg), dim3(256), lds_bytes, st, g, cams, chunk, n_wg, recs, radii,
+                    hist, exact_cull);
+    return 0;
+}
+
+int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+                        const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
+                        unsigned long long* keys, unsigned cap, int exact_cull) {
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_scatter<2>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+                               : hipFuncSetAttribute((const void*)k_scatter<1>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            gs2m_set_error("hipFuncSetAttribute(k_scatter, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+            return 1;
+        }
+    }
+    if (nv == 2)
+        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(256), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+                    tile_start, keys, cap, exact_cull);
+    else
+        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(256), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+                    tile_start, keys, cap, exact_cull);
+    return 0;
+}
+
+void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,
+                              unsigned char* present) {
+    GS2M_LAUNCH(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, st, P, xyz, viewmatrix, present);
+}
+
+void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,
+                             const float* projmatrix, const float* campos, const float* bg, float tanfovx,
+                             float tanfovy, int W, int H) {
+    GS2M_LAUNCH(k_pack_camera, dim3(1), dim3(64), 0, st, cams, slot, viewmatrix, projmatrix, campos, bg, tanfovx,
+                tanfovy, W, H);
+}
+
+void gs2m_launch_set_camera(hipStream_t st, CamUniform* cams, int slot, const CamUniform& c) {
+    CamUniformArg a;
+    a.c = c;
+    GS2M_LAUNCH(k_set_camera, dim3(1), dim3(64), 0, st, cams, slot, a);
+}

@@ -1,0 +1,151 @@
+// raster_sort.h -- tile offsets and per-tile depth sort.
+//
+// Replaces cub::DeviceScan::InclusiveSum + the 4-byte D2H sync + cub::DeviceRadixSort::SortPairs
+// on 64-bit keys + identifyTileRanges (rasterizer_impl.cu:277-314).  After the counting sort by
+// tile (raster_project.h) each tile's instances are contiguous; a workgroup sorts them by the
+// unique 64-bit key depth_bits<<32 | id with a bitonic network in LDS.  Order = ascending depth,
+// ties by ascending Gaussian id = the reference's stable radix-sort order.
+#pragma once
+#include "raster_common.h"
+
+// hist[v][wg][t]: per-workgroup counts -> exclusive prefix over workgroups (in place);
+// tile_count[v][t] = column total.  One thread per (view, tile); consecutive threads read
+// consecutive tiles => coalesced.
+GS2M_KERNEL void __launch_bounds__(256)
+k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count) {
+    const int t = (int)(blockIdx.x * 256u + threadIdx.x);
+    const int v = (int)blockIdx.y;
+    if (t < tiles) {
+        unsigned run = 0;
+        unsigned* col = hist + (size_t)v * n_wg * tiles + t;
+        for (int w = 0; w < n_wg; ++w) {
+            const unsigned x = col[(size_t)w * tiles];
+            col[(size_t)w * tiles] = run;
+            run += x;
+        }
+        tile_count[(size_t)v * tiles + t] = run;
+    }
+}
+
+// Exclusive scan of tile_count over tiles: one 1024-thread workgroup per view.
+// tile_start[v][0..tiles]; status[v] = {N, N > cap}.
+GS2M_KERNEL void __launch_bounds__(1024)
+k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles,
+            ViewStatus* __restrict__ status, unsigned cap) {
+    __shared__ unsigned part[1024];
+    const int tid = (int)threadIdx.x;
+    const int v = (int)blockIdx.x;
+    const unsigned* cnt = tile_count + (size_t)v * tiles;
+    unsigned* start = tile_start + (size_t)v * (tiles + 1);
+    const int per = (tiles + 1023) / 1024;
+    const int lo = tid * per;
+    const int hi = lo + per < tiles ? lo + per : tiles;
+    unsigned s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned add = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    unsigned run = part[tid] - s;  // exclusive
+    for (int i = lo; i < hi; ++i) {
+        start[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) {
+        const unsigned total = part[1023];
+        start[tiles] = total;
+        status[v].num_rendered = total;
+        status[v].overflow = total > cap ? 1u : 0u;
+    }
+}
+
+GS2M_DEVICE void bitonic_lds(unsigned long long* s, int npow2, int tid, int nthreads) {
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s[i], b = s[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s[i] = b;
+                        s[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One workgroup per (tile, view).  n <= GS2M_SORT_LDS: bitonic in LDS.  Larger tiles: LDS-sorted
+// runs of GS2M_SORT_LDS, then rank-based merge passes through HBM (keys <-> tmp) by the same
+// workgroup (keys are unique, so rank = index in own run + lower_bound in the sibling run).
+GS2M_KERNEL void __launch_bounds__(256)
+k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
+             const unsigned* __restrict__ tile_start, int tiles, unsigned cap) {
+    __shared__ unsigned long long s[GS2M_SORT_LDS];
+    const int tid = (int)threadIdx.x;
+    const int t = (int)blockIdx.x, v = (int)blockIdx.y;
+    unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
+    unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
+    if (b > cap) b = cap;
+    if (e > cap) e = cap;
+    const int n = (int)(e - b);
+    if (n <= 1) return;  // uniform across the workgroup
+    unsigned long long* kv = keys + (size_t)v * cap + b;
+    unsigned long long* tv = tmp + (size_t)v * cap + b;
+    const int nruns = (n + GS2M_SORT_LDS - 1) / GS2M_SORT_LDS;
+    for (int run = 0; run < nruns; ++run) {
+        const int r0 = run * GS2M_SORT_LDS;
+        const int rn = n - r0 < GS2M_SORT_LDS ? n - r0 : GS2M_SORT_LDS;
+        int np2 = 2;
+        while (np2 < rn) np2 <<= 1;
+        for (int i = tid; i < np2; i += 256) s[i] = i < rn ? kv[r0 + i] : ~0ull;
+        __syncthreads();
+        bitonic_lds(s, np2, tid, 256);
+        for (int i = tid; i < rn; i += 256) kv[r0 + i] = s[i];
+        __syncthreads();
+    }
+    if (nruns == 1) return;
+    unsigned long long* src = kv;
+    unsigned long long* dst = tv;
+    for (int w = GS2M_SORT_LDS; w < n; w <<= 1) {
+        for (int i = tid; i < n; i += 256) {
+            const int blk = i / (2 * w);
+            const int a0 = blk * 2 * w;
+            const int a1 = a0 + w < n ? a0 + w : n;            // A = [a0,a1)
+            const int b1 = a0 + 2 * w < n ? a0 + 2 * w : n;    // B = [a1,b1)
+            const unsigned long long key = src[i];
+            int lo, hi, base;
+            if (i < a1) {  // element of A: count of B elements smaller than key
+                lo = a1;
+                hi = b1;
+                base = i - a0;
+            } else {
+                lo = a0;
+                hi = a1;
+                base = i - a1;
+            }
+            const int lo0 = lo;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (src[mid] < key) lo = mid + 1;
+                else hi = mid;
+            }
+            dst[a0 + base + (lo - lo0)] = key;
+        }
+        __syncthreads();
+        unsigned long long* x = src;
+        src = dst;
+        dst = x;
+    }
+    if (src != kv) {
+        for (int i = tid; i < n; i += 256) kv[i] = src[i];
+    }
+}

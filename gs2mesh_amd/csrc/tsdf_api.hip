@@ -1,0 +1,332 @@
+// tsdf_api.hip -- C ABI of the TSDF half (include/gs2mesh_amd.h).  Host code; kernels in
+// tsdf_kernels.hip.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/gs2mesh_amd.h"
+#include "tsdf_common.h"
+#include "tsdf_internal.h"
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            gs2m_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+struct gs2m_tsdf {
+    int device = 0;
+    double voxel_length = 0, sdf_trunc = 0, unit_length = 0;
+    int color_type = 1, resolution = 16, stride = 4;
+    TsdfVolume V;
+    unsigned frame_id = 0;  // monotonic, never reset (stamps of old frames can never alias)
+    unsigned* h_counters = nullptr;         // pinned [4]
+    unsigned long long* h_totals = nullptr; // pinned [1]
+    int n_cu = 256;
+};
+
+// General 4x4 inverse (cofactors), double.  The reference hands Open3D world->camera and
+// Open3D inverts it again (PointCloudFactory.cpp: camera_pose = extrinsic.inverse()).
+static bool invert4x4(const double* m, double* inv) {
+    double a[16];
+    a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+    if (det == 0) return false;
+    det = 1.0 / det;
+    for (int i = 0; i < 16; i++) inv[i] = a[i] * det;
+    return true;
+}
+
+static int zero_state(gs2m_tsdf* t, hipStream_t st) {
+    TsdfVolume& V = t->V;
+    HIPCHK(hipMemsetAsync(V.tsdf, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+    HIPCHK(hipMemsetAsync(V.weight, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+    if (V.rgb) HIPCHK(hipMemsetAsync(V.rgb, 0, sizeof(unsigned) * 3 * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+    HIPCHK(hipMemsetAsync(V.hash_keys, 0xff, sizeof(unsigned long long) * (size_t)V.hash_cap, st));
+    HIPCHK(hipMemsetAsync(V.hash_vals, 0xff, sizeof(int) * (size_t)V.hash_cap, st));
+    HIPCHK(hipMemsetAsync(V.stamp, 0, sizeof(unsigned) * (size_t)V.hash_cap, st));
+    HIPCHK(hipMemsetAsync(V.counters, 0, sizeof(unsigned) * 4, st));
+    HIPCHK(hipMemsetAsync(V.totals, 0, sizeof(unsigned long long), st));
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf_trunc, int color_type,
+                                int volume_unit_resolution, int depth_sampling_stride, int64_t max_blocks,
+                                int device) {
+    if (!out) {
+        gs2m_set_error("gs2m_tsdf_create: out is NULL");
+        return 1;
+    }
+    if (volume_unit_resolution != GS2M_TSDF_RES) {
+        gs2m_set_error("volume_unit_resolution %d not supported (kernels are specialised for 16, Open3D's default)",
+                       volume_unit_resolution);
+        return 1;
+    }
+    if (!(voxel_length > 0) || !(sdf_trunc > 0) || depth_sampling_stride < 1 || max_blocks < 1 ||
+        max_blocks > (1ll << 30) || (color_type != GS2M_TSDF_COLOR_NONE && color_type != GS2M_TSDF_COLOR_RGB8)) {
+        gs2m_set_error("gs2m_tsdf_create: bad argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(device));
+    gs2m_tsdf* t = new gs2m_tsdf();
+    t->device = device;
+    t->voxel_length = voxel_length;
+    t->sdf_trunc = sdf_trunc;
+    t->unit_length = voxel_length * volume_unit_resolution;  // ScalableTSDFVolume ctor
+    t->color_type = color_type;
+    t->stride = depth_sampling_stride;
+    memset(&t->V, 0, sizeof(t->V));
+    TsdfVolume& V = t->V;
+    V.max_blocks = (unsigned)max_blocks;
+    unsigned cap = 1024;
+    while ((uint64_t)cap < 2ull * (uint64_t)max_blocks) cap <<= 1;
+    V.hash_cap = cap;
+    V.has_color = color_type == GS2M_TSDF_COLOR_RGB8;
+    const size_t nvox = (size_t)max_blocks * GS2M_TSDF_VOX;
+    bool ok = hipMalloc((void**)&V.tsdf, sizeof(float) * nvox) == hipSuccess &&
+              hipMalloc((void**)&V.weight, sizeof(float) * nvox) == hipSuccess &&
+              (!V.has_color || hipMalloc((void**)&V.rgb, sizeof(unsigned) * 3 * nvox) == hipSuccess) &&
+              hipMalloc((void**)&V.block_keys, sizeof(int) * 3 * (size_t)max_blocks) == hipSuccess &&
+              hipMalloc((void**)&V.hash_keys, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void**)&V.hash_vals, sizeof(int) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void**)&V.stamp, sizeof(unsigned) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void**)&V.touched, sizeof(unsigned) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void**)&V.counters, sizeof(unsigned) * 4) == hipSuccess &&
+              hipMalloc((void**)&V.totals, sizeof(unsigned long long)) == hipSuccess &&
+              hipHostMalloc((void**)&t->h_counters, sizeof(unsigned) * 4) == hipSuccess &&
+              hipHostMalloc((void**)&t->h_totals, sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) {
+        gs2m_set_error("gs2m_tsdf_create: out of device memory for %lld blocks (%.1f MiB)", (long long)max_blocks,
+                       (double)nvox * 20.0 / 1048576.0);
+        gs2m_tsdf_destroy(t);
+        return 1;
+    }
+    if (zero_state(t, (hipStream_t)0)) {
+        gs2m_tsdf_destroy(t);
+        return 1;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)0));
+    *out = t;
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
+    if (!t) return 0;
+    TsdfVolume& V = t->V;
+    (void)hipFree(V.tsdf);
+    (void)hipFree(V.weight);
+    (void)hipFree(V.rgb);
+    (void)hipFree(V.block_keys);
+    (void)hipFree(V.hash_keys);
+    (void)hipFree(V.hash_vals);
+    (void)hipFree(V.stamp);
+    (void)hipFree(V.touched);
+    (void)hipFree(V.counters);
+    (void)hipFree(V.totals);
+    (void)hipHostFree(t->h_counters);
+    (void)hipHostFree(t->h_totals);
+    delete t;
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_reset(gs2m_tsdf* t, gs2m_stream stream) {
+    if (!t) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    return zero_state(t, (hipStream_t)stream);
+}
+
+extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color, const uint8_t* mask,
+                                   int width, int height, double fx, double fy, double cx, double cy,
+                                   const double* extrinsic_w2c, double depth_scale, double depth_trunc,
+                                   double min_depth, gs2m_stream stream) {
+    if (!t || !depth || !extrinsic_w2c) {
+        gs2m_set_error("gs2m_tsdf_integrate: NULL argument");
+        return 1;
+    }
+    if (t->V.has_color && !color) {
+        // Open3D: "[ScalableTSDFVolume::Integrate] Unsupported image format."
+        gs2m_set_error("[ScalableTSDFVolume::Integrate] Unsupported image format.");
+        return 1;
+    }
+    if (width <= 0 || height <= 0 || !(fx != 0) || !(fy != 0) || !(depth_scale != 0)) {
+        gs2m_set_error("gs2m_tsdf_integrate: bad intrinsics / size");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    TsdfFrame f;
+    memset(&f, 0, sizeof(f));
+    double pose[16];
+    if (!invert4x4(extrinsic_w2c, pose)) {
+        gs2m_set_error("gs2m_tsdf_integrate: singular extrinsic");
+        return 1;
+    }
+    for (int i = 0; i < 12; ++i) {
+        f.pose[i] = pose[i];
+        f.E[i] = (float)extrinsic_w2c[i];
+    }
+    f.fx = fx;
+    f.fy = fy;
+    f.cx = cx;
+    f.cy = cy;
+    f.unit_length = t->unit_length;
+    f.sdf_trunc = t->sdf_trunc;
+    f.depth_trunc = depth_trunc;
+    f.fx_f = (float)fx;
+    f.fy_f = (float)fy;
+    f.cx_f = (float)cx;
+    f.cy_f = (float)cy;
+    f.fx_inv_f = 1.0f / (float)fx;
+    f.fy_inv_f = 1.0f / (float)fy;
+    f.voxel_length_f = (float)t->voxel_length;
+    f.half_voxel_length_f = f.voxel_length_f * 0.5f;
+    f.sdf_trunc_f = (float)t->sdf_trunc;
+    f.sdf_trunc_inv_f = 1.0f / f.sdf_trunc_f;
+    f.Es02 = f.E[2] * f.voxel_length_f;
+    f.Es12 = f.E[6] * f.voxel_length_f;
+    f.Es22 = f.E[10] * f.voxel_length_f;
+    f.safe_w = width - 0.0001f;
+    f.safe_h = height - 0.0001f;
+    f.depth_scale_f = (float)depth_scale;
+    f.min_depth_f = (float)min_depth;
+    f.W = width;
+    f.H = height;
+    f.stride = t->stride;
+    f.nx = (width + t->stride - 1) / t->stride;
+    f.ny = (height + t->stride - 1) / t->stride;
+    f.frame_id = ++t->frame_id;
+    f.use_mask = mask != nullptr;
+    f.use_min = min_depth > 0;
+    HIPCHK(hipMemsetAsync(t->V.counters + 1, 0, sizeof(unsigned), st));  // touched_count = 0
+    gs2m_launch_tsdf_touch(st, t->V, f, depth, mask);
+    // persistent grid: enough workgroups to fill the chip; each loops over the touched list
+    gs2m_launch_tsdf_integrate(st, t->n_cu * 8, t->V, f, depth, color, mask);
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_status(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_blocks, int64_t* block_updates,
+                                int* overflow) {
+    if (!t) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(t->h_counters, t->V.counters, sizeof(unsigned) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(t->h_totals, t->V.totals, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    unsigned nb = t->h_counters[0];
+    if (nb > t->V.max_blocks) nb = t->V.max_blocks;
+    if (n_blocks) *n_blocks = nb;
+    if (block_updates) *block_updates = (int64_t)t->h_totals[0];
+    if (overflow) *overflow = (int)t->h_counters[2];
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m_stream stream) {
+    if (!t || (n > 0 && !keys) || n < 0 || n > (int64_t)t->V.max_blocks) {
+        gs2m_set_error("gs2m_tsdf_block_keys: bad argument");
+        return 1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(hipMemcpyAsync(keys, t->V.block_keys, sizeof(int) * 3 * (size_t)n, hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, int32_t* keys, float* tsdf,
+                                  float* weight, uint32_t* rgb_sum) {
+    if (!t || n < 0) {
+        gs2m_set_error("gs2m_tsdf_download: bad argument");
+        return 1;
+    }
+    int64_t nb = 0;
+    if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
+    if (n > nb) n = nb;
+    if (n == 0) return 0;
+    const size_t nv = (size_t)n * GS2M_TSDF_VOX;
+    if (keys) HIPCHK(hipMemcpy(keys, t->V.block_keys, sizeof(int) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<float> tmp;
+    // device layout z*256 + x*16 + y  ->  Open3D IndexOf x*256 + y*16 + z
+    auto reorder_f = [&](const float* src, float* dst) {
+        for (int64_t b = 0; b < n; ++b)
+            for (int z = 0; z < 16; ++z)
+                for (int x = 0; x < 16; ++x)
+                    for (int y = 0; y < 16; ++y)
+                        dst[(size_t)b * GS2M_TSDF_VOX + x * 256 + y * 16 + z] =
+                            src[(size_t)b * GS2M_TSDF_VOX + z * 256 + x * 16 + y];
+    };
+    if (tsdf) {
+        tmp.resize(nv);
+        HIPCHK(hipMemcpy(tmp.data(), t->V.tsdf, sizeof(float) * nv, hipMemcpyDeviceToHost));
+        reorder_f(tmp.data(), tsdf);
+    }
+    if (weight) {
+        tmp.resize(nv);
+        HIPCHK(hipMemcpy(tmp.data(), t->V.weight, sizeof(float) * nv, hipMemcpyDeviceToHost));
+        reorder_f(tmp.data(), weight);
+    }
+    if (rgb_sum) {
+        if (!t->V.has_color) {
+            memset(rgb_sum, 0, sizeof(uint32_t) * 3 * nv);
+        } else {
+            std::vector<unsigned> c(3 * nv);
+            HIPCHK(hipMemcpy(c.data(), t->V.rgb, sizeof(unsigned) * 3 * nv, hipMemcpyDeviceToHost));
+            for (int64_t b = 0; b < n; ++b)
+                for (int ch = 0; ch < 3; ++ch)
+                    for (int z = 0; z < 16; ++z)
+                        for (int x = 0; x < 16; ++x)
+                            for (int y = 0; y < 16; ++y)
+                                rgb_sum[((size_t)b * GS2M_TSDF_VOX + x * 256 + y * 16 + z) * 3 + ch] =
+                                    c[((size_t)b * 3 + ch) * GS2M_TSDF_VOX + z * 256 + x * 16 + y];
+        }
+    }
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, float* weight,
+                              uint32_t* rgb_sum, gs2m_stream stream) {
+    if (!t || n < 0 || (n > 0 && (!keys || !wsum || !weight))) {
+        gs2m_set_error("gs2m_tsdf_pack: bad argument");
+        return 1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(t->device));
+    gs2m_launch_tsdf_pack((hipStream_t)stream, (unsigned)n, t->V, keys, wsum, weight, rgb_sum);
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
+                                const float* weight, const uint32_t* rgb_sum, gs2m_stream stream) {
+    if (!t || n < 0 || (n > 0 && (!keys || !wsum || !weight))) {
+        gs2m_set_error("gs2m_tsdf_unpack: bad argument");
+        return 1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(t->device));
+    gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, wsum, weight, rgb_sum);
+    return 0;
+}

@@ -1,0 +1,13 @@
+// tsdf_internal.h -- launch wrappers of the TSDF kernels.
+#pragma once
+#include "tsdf_common.h"
+
+void gs2m_launch_tsdf_touch(hipStream_t st, const TsdfVolume& V, const TsdfFrame& f, const float* depth,
+                            const unsigned char* mask);
+void gs2m_launch_tsdf_integrate(hipStream_t st, int n_wg, const TsdfVolume& V, const TsdfFrame& f,
+                                const float* depth, const unsigned char* color, const unsigned char* mask);
+void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, float* wsum,
+                           float* weight, unsigned* rgb);
+void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* wsum,
+                             const float* weight, const unsigned* rgb);
+void gs2m_set_error(const char* fmt, ...);

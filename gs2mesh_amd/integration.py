@@ -1,0 +1,203 @@
+"""Open3D-shaped front-end of the HIP TSDF integrator (the subset gs2mesh_utils/tsdf_utils.py uses).
+
+    volume = ScalableTSDFVolume(voxel_length, sdf_trunc, color_type=TSDFVolumeColorType.RGB8)
+    rgbd   = RGBDImage.create_from_color_and_depth(Image(rgb), Image(depth), depth_scale=..,
+                                                   depth_trunc=.., convert_rgb_to_intensity=False)
+    volume.integrate(rgbd, PinholeCameraIntrinsic(w, h, fx, fy, cx, cy), extrinsic_world_to_cam)
+
+mirrors ``o3d.pipelines.integration.ScalableTSDFVolume`` / ``o3d.geometry.RGBDImage`` /
+``o3d.camera.PinholeCameraIntrinsic`` as called at tsdf_utils.py:53-56,88-93,106-107 (same names,
+argument meaning and error text).  Images may be numpy arrays (uploaded) or torch tensors already
+on the device (the in-memory render -> fuse hand-off).  The depth conversion
+(depth/scale, >= trunc -> 0) is recorded lazily and fused into the integration kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _lib
+from .rasterizer import _is_torch, _ptr, _stream_of
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class TSDFVolumeColorType(enum.IntEnum):
+    NoColor = 0
+    RGB8 = 1
+    Gray32 = 2
+
+
+class PinholeCameraIntrinsic:
+    def __init__(self, width, height, fx, fy, cx, cy):
+        self.width, self.height = int(width), int(height)
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+
+    @property
+    def intrinsic_matrix(self):
+        return np.array([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1.0]])
+
+
+class Image:
+    """o3d.geometry.Image stand-in: wraps an array, no copy."""
+
+    def __init__(self, data):
+        self.data = data
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+
+class RGBDImage:
+    def __init__(self, color, depth, depth_scale=1.0, depth_trunc=float("inf")):
+        self.color, self.depth = color, depth
+        self.depth_scale, self.depth_trunc = float(depth_scale), float(depth_trunc)
+
+    @staticmethod
+    def create_from_color_and_depth(color, depth, depth_scale=1000.0, depth_trunc=3.0,
+                                    convert_rgb_to_intensity=True):
+        if convert_rgb_to_intensity:
+            raise NotImplementedError("convert_rgb_to_intensity=True is not on the GS2Mesh path "
+                                      "(tsdf_utils.py:93 passes False)")
+        c = color.data if isinstance(color, Image) else color
+        d = depth.data if isinstance(depth, Image) else depth
+        if tuple(c.shape[:2]) != tuple(d.shape[:2]):
+            raise RuntimeError("[CreateFromColorAndDepth] Unsupported image format.")
+        return RGBDImage(c, d, depth_scale, depth_trunc)
+
+
+class ScalableTSDFVolume:
+    """HIP block-sparse TSDF volume.  ``max_blocks`` sizes the 16^3-voxel block pool
+    (80 KiB per block; default 32768 blocks = 2.7 GB = a dense 512^3 volume)."""
+
+    def __init__(self, voxel_length, sdf_trunc, color_type=TSDFVolumeColorType.RGB8, volume_unit_resolution=16,
+                 depth_sampling_stride=4, max_blocks=32768, device=0, lib=None):
+        self._lib = lib or _lib.get()
+        if int(color_type) not in (0, 1):
+            raise NotImplementedError("only NoColor / RGB8 volumes (tsdf_utils.py:56 uses RGB8)")
+        self.voxel_length = float(voxel_length)
+        self.sdf_trunc = float(sdf_trunc)
+        self.color_type = TSDFVolumeColorType(int(color_type))
+        self.max_blocks = int(max_blocks)
+        self.device = device
+        h = C.c_void_p()
+        _lib.check(self._lib.gs2m_tsdf_create(C.byref(h), self.voxel_length, self.sdf_trunc, int(color_type),
+                                              int(volume_unit_resolution), int(depth_sampling_stride),
+                                              self.max_blocks, int(device)), self._lib)
+        self._h = h
+        self._keep = []  # uploaded frames stay alive until the next synchronising call
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gs2m_tsdf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, stream=None):
+        _lib.check(self._lib.gs2m_tsdf_reset(self._h, stream or C.c_void_p(0)), self._lib)
+
+    # ---------------------------------------------------------------------------------------
+    def _to_dev(self, a, dtype):
+        """numpy -> device tensor (or pass-through for emulator tests / device tensors)."""
+        if a is None:
+            return None
+        if _is_torch(a):
+            if a.dtype != dtype:
+                a = a.to(dtype)
+            return a.contiguous()
+        a = np.ascontiguousarray(a)
+        if _lib.ALLOW_HOST_POINTERS:
+            np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8}[dtype] if torch is not None else None
+            return a.astype(np_dtype, copy=False) if np_dtype is not None else a
+        t = torch.from_numpy(a).to(dtype)
+        return t.to(f"cuda:{self.device}", non_blocking=False)
+
+    def integrate(self, image: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic, mask=None, min_depth=0.0,
+                  stream=None):
+        """``volume.integrate(rgbd, intrinsic, extrinsic_world_to_camera)``.  Extras (fused
+        TSDF.run preprocessing, tsdf_utils.py:68-83): ``mask`` [H,W] (depth *= mask != 0) and
+        ``min_depth`` (depth < min_depth -> 0), both applied before the scale/trunc conversion."""
+        f32 = torch.float32 if torch is not None else None
+        u8 = torch.uint8 if torch is not None else None
+        depth = self._to_dev(image.depth, f32)
+        color = self._to_dev(image.color, u8) if self.color_type == TSDFVolumeColorType.RGB8 else None
+        msk = self._to_dev(mask, u8) if mask is not None else None
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        bad = (W != intrinsic.width or H != intrinsic.height or depth.ndim != 2)
+        if self.color_type == TSDFVolumeColorType.RGB8:
+            bad = bad or color is None or color.ndim != 3 or tuple(color.shape) != (H, W, 3)
+        if bad:
+            raise RuntimeError("[ScalableTSDFVolume::Integrate] Unsupported image format.")
+        E = np.ascontiguousarray(np.asarray(extrinsic, np.float64).reshape(4, 4))
+        st = _stream_of(depth, stream)
+        _lib.check(self._lib.gs2m_tsdf_integrate(
+            self._h, _ptr(depth), _ptr(color), _ptr(msk), W, H, intrinsic.fx, intrinsic.fy, intrinsic.cx,
+            intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)), float(image.depth_scale),
+            float(image.depth_trunc), float(min_depth), st), self._lib)
+        self._keep.append((depth, color, msk))
+        if len(self._keep) > 64:
+            self.status(stream)
+
+    def status(self, stream=None):
+        """Synchronises -> (n_blocks, block_updates, overflow_flags); raises on overflow."""
+        nb, bu, ov = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        _lib.check(self._lib.gs2m_tsdf_status(self._h, stream or C.c_void_p(0), C.byref(nb), C.byref(bu),
+                                              C.byref(ov)), self._lib)
+        self._keep.clear()
+        if ov.value:
+            what = [n for b, n in ((1, "block pool exhausted (raise max_blocks)"), (2, "hash table full"),
+                                   (4, "block index out of the +-2^20 range")) if ov.value & b]
+            raise RuntimeError("TSDF volume overflow: " + ", ".join(what))
+        return int(nb.value), int(bu.value), int(ov.value)
+
+    @property
+    def num_blocks(self):
+        return self.status()[0]
+
+    @property
+    def voxel_updates(self):
+        return self.status()[1] * 4096
+
+    def download(self):
+        """-> keys[n,3] i32, tsdf[n,4096] f32, weight[n,4096] f32, rgb_sum[n,4096,3] u32 (host numpy;
+        voxel index x*256 + y*16 + z as Open3D's IndexOf).  Mean colour = rgb_sum / weight."""
+        n = self.status()[0]
+        keys = np.zeros((n, 3), np.int32)
+        tsdf = np.zeros((n, 4096), np.float32)
+        weight = np.zeros((n, 4096), np.float32)
+        rgb = np.zeros((n, 4096, 3), np.uint32)
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        _lib.check(self._lib.gs2m_tsdf_download(self._h, C.c_void_p(0), n, vp(keys), vp(tsdf), vp(weight), vp(rgb)),
+                   self._lib)
+        return keys, tsdf, weight, rgb
+
+    # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
+    def block_keys(self, like=None, stream=None):
+        n = self.status(stream)[0]
+        if _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available()):
+            keys = np.zeros((n, 3), np.int32)
+        else:
+            keys = torch.zeros((n, 3), dtype=torch.int32, device=f"cuda:{self.device}")
+        _lib.check(self._lib.gs2m_tsdf_block_keys(self._h, n, _ptr(keys), _stream_of(keys, stream)), self._lib)
+        return keys
+
+    def pack(self, keys, wsum, weight, rgb_sum, stream=None):
+        n = int(keys.shape[0])
+        _lib.check(self._lib.gs2m_tsdf_pack(self._h, _ptr(keys), n, _ptr(wsum), _ptr(weight), _ptr(rgb_sum),
+                                            _stream_of(keys, stream)), self._lib)
+
+    def unpack(self, keys, wsum, weight, rgb_sum, stream=None):
+        n = int(keys.shape[0])
+        _lib.check(self._lib.gs2m_tsdf_unpack(self._h, _ptr(keys), n, _ptr(wsum), _ptr(weight), _ptr(rgb_sum),
+                                              _stream_of(keys, stream)), self._lib)

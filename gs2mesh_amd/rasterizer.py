@@ -1,0 +1,248 @@
+"""Thin object wrapper over the rasteriser half of the C ABI (handle + arenas + overflow retry).
+
+This is plumbing between torch tensors (device memory, current stream) and
+``libgs2mesh_amd.so``; the reference-shaped APIs are built on it:
+``gs2mesh_amd.diff_gaussian_rasterization`` (operator level) and
+``gs2mesh_amd.renderer_utils.Renderer`` (pipeline level).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is plumbing for device memory / streams; the emulator tests run without a device
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _ptr(x, dtype=None, name="tensor"):
+    """Device pointer of a contiguous torch tensor (or, for the emulator tests only, the host
+    pointer of a numpy array).  None -> NULL."""
+    if x is None:
+        return None
+    if _is_torch(x):
+        if x.numel() == 0:
+            return None
+        if not x.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+        if dtype is not None and x.dtype != dtype:
+            raise TypeError(f"{name} must be {dtype}, got {x.dtype}")
+        if not x.is_cuda and not _lib.ALLOW_HOST_POINTERS:
+            raise RuntimeError(f"{name} must live on a HIP device (there is no CPU path)")
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        if not _lib.ALLOW_HOST_POINTERS:
+            raise RuntimeError("numpy arrays are only accepted by the emulator test harness")
+        if x.size == 0:
+            return None
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{name} must be contiguous")
+        return C.c_void_p(x.ctypes.data)
+    raise TypeError(f"{name}: unsupported type {type(x)}")
+
+
+_NP2T = {}
+if torch is not None:
+    _NP2T = {np.float32: torch.float32, np.int32: torch.int32, np.uint8: torch.uint8, np.uint32: torch.int32,
+             np.int64: torch.int64}
+
+
+def _empty(like, shape, np_dtype):
+    if _is_torch(like):
+        return torch.empty(shape, dtype=_NP2T[np_dtype], device=like.device)
+    return np.empty(shape, np_dtype)
+
+
+def _stream_of(x, stream):
+    if stream is not None:
+        return C.c_void_p(int(stream))
+    if _is_torch(x) and x.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def make_camera(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, campos) -> _lib.Camera:
+    """Host ``gs2m_camera`` from numpy-convertible matrices (transposed row-major like the
+    reference's world_view_transform / full_proj_transform)."""
+    c = _lib.Camera()
+    c.width, c.height = int(width), int(height)
+    c.tanfovx, c.tanfovy = float(tanfovx), float(tanfovy)
+    vm = np.asarray(viewmatrix.detach().cpu() if _is_torch(viewmatrix) else viewmatrix, np.float32).reshape(16)
+    pm = np.asarray(projmatrix.detach().cpu() if _is_torch(projmatrix) else projmatrix, np.float32).reshape(16)
+    cp = np.asarray(campos.detach().cpu() if _is_torch(campos) else campos, np.float32).reshape(3)
+    c.viewmatrix[:] = vm.tolist()
+    c.projmatrix[:] = pm.tolist()
+    c.campos[:] = cp.tolist()
+    return c
+
+
+def camera_from(cam) -> _lib.Camera:
+    """From a ``gs2mesh_amd.graphics.Camera`` (or anything with the 3DGS Camera attributes)."""
+    import math
+    return make_camera(cam.image_width, cam.image_height, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+                       cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+
+
+class Rasterizer:
+    """Owns one ``gs2m_raster`` handle (persistent arenas).  Not thread-safe; one stream at a time."""
+
+    def __init__(self, device: int = 0, lib=None):
+        self._lib = lib or _lib.get()
+        h = C.c_void_p()
+        _lib.check(self._lib.gs2m_raster_create(C.byref(h), int(device)), self._lib)
+        self._h = h
+        self.device = device
+        self.last_num_rendered = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gs2m_raster_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option: int, value: int):
+        _lib.check(self._lib.gs2m_raster_set_option(self._h, option, value), self._lib)
+
+    def reserve(self, P, n_views, W, H, instances):
+        _lib.check(self._lib.gs2m_raster_reserve(self._h, int(P), int(n_views), int(W), int(H), int(instances)),
+                   self._lib)
+
+    def status(self, n_views=1, stream=None):
+        """Synchronises.  -> (num_rendered list, overflow flag, required instances per view)."""
+        nr = (C.c_int64 * max(n_views, 1))()
+        ov = C.c_int(0)
+        req = C.c_int64(0)
+        _lib.check(self._lib.gs2m_raster_status(self._h, stream or C.c_void_p(0), n_views, nr, C.byref(ov),
+                                                C.byref(req)), self._lib)
+        return list(nr)[:n_views], bool(ov.value), int(req.value)
+
+    # -- operator level -------------------------------------------------------------------------
+    def forward(self, means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, shs=None,
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, sh_degree=3,
+                scale_modifier=1.0, prefiltered=False, debug=False, stream=None, sync=True):
+        """``gs2m_rasterize_forward``; returns (color[3,H,W], radii[P]).  With ``sync`` (default) the
+        instance arena is checked after the call and the pass is repeated once if it overflowed."""
+        P = int(means3D.shape[0])
+        D = int(sh_degree)
+        M = 0 if shs is None or (hasattr(shs, "numel") and shs.numel() == 0) or getattr(shs, "size", 1) == 0 \
+            else int(shs.shape[1])
+        out = _empty(means3D, (3, int(H), int(W)), np.float32)
+        radii = _empty(means3D, (P,), np.int32)
+        st = _stream_of(means3D, stream)
+        f32 = torch.float32 if _is_torch(means3D) else None
+
+        def call():
+            _lib.check(self._lib.gs2m_rasterize_forward(
+                self._h, P, D, M, _ptr(bg, f32, "bg"), int(W), int(H), _ptr(means3D, f32, "means3D"),
+                _ptr(shs, f32, "shs"), _ptr(colors_precomp, f32, "colors_precomp"),
+                _ptr(opacities, f32, "opacities"), _ptr(scales, f32, "scales"), float(scale_modifier),
+                _ptr(rotations, f32, "rotations"), _ptr(cov3D_precomp, f32, "cov3D_precomp"),
+                _ptr(viewmatrix, f32, "viewmatrix"), _ptr(projmatrix, f32, "projmatrix"),
+                _ptr(campos, f32, "campos"), float(tanfovx), float(tanfovy), int(bool(prefiltered)), _ptr(out),
+                _ptr(radii), int(bool(debug)), st), self._lib)
+
+        call()
+        if sync:
+            nr, ov, req = self.status(1, st)
+            if ov:
+                self.reserve(P, 1, W, H, int(req * 1.25) + 1024)
+                call()
+                nr, ov, req = self.status(1, st)
+                if ov:
+                    raise RuntimeError("instance arena overflow persists after growing")
+            self.last_num_rendered = nr[0]
+        return out, radii
+
+    def mark_visible(self, positions, viewmatrix, projmatrix, stream=None):
+        P = int(positions.shape[0])
+        present = _empty(positions, (P,), np.uint8)
+        st = _stream_of(positions, stream)
+        _lib.check(self._lib.gs2m_mark_visible(P, _ptr(positions), _ptr(viewmatrix), _ptr(projmatrix),
+                                               _ptr(present), st), self._lib)
+        return present
+
+    # -- pipeline level -------------------------------------------------------------------------
+    def render_views(self, gaussians: dict, cams, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, want_color=True,
+                     want_rgb8=False, want_radii=False, out_color=None, out_rgb8=None, stream=None, sync=True):
+        """``gs2m_render_views``.  ``gaussians``: dict with xyz[P,3], scaling[P,3], rotation[P,4],
+        opacity[P,1|P], and either features[P,M,3] or features_dc[P,1,3] + features_rest[P,M-1,3];
+        ``raw`` (default True) = pre-activation GaussianModel parameters; ``sh_degree`` (default 3).
+        ``cams``: list of ``_lib.Camera``.  Returns dict(color, rgb8, radii, num_rendered)."""
+        xyz = gaussians["xyz"]
+        P = int(xyz.shape[0])
+        n = len(cams)
+        W, H = cams[0].width, cams[0].height
+        g = _lib.Gaussians()
+        g.P = P
+        g.sh_degree = int(gaussians.get("sh_degree", 3))
+        g.raw = int(bool(gaussians.get("raw", True)))
+        f32 = torch.float32 if _is_torch(xyz) else None
+        g.xyz = _ptr(xyz, f32, "xyz")
+        g.scales = _ptr(gaussians["scaling"], f32, "scaling")
+        g.rotations = _ptr(gaussians["rotation"], f32, "rotation")
+        g.opacities = _ptr(gaussians["opacity"], f32, "opacity")
+        if gaussians.get("features") is not None:
+            g.shs = _ptr(gaussians["features"], f32, "features")
+            g.shs_rest = None
+            g.M = int(gaussians["features"].shape[1])
+        else:
+            g.shs = _ptr(gaussians["features_dc"], f32, "features_dc")
+            g.shs_rest = _ptr(gaussians["features_rest"], f32, "features_rest")
+            g.M = 1 + int(gaussians["features_rest"].shape[1])
+        cam_arr = (_lib.Camera * n)(*cams)
+        bg_arr = (C.c_float * 3)(*[float(b) for b in bg])
+        if want_color and out_color is None:
+            out_color = _empty(xyz, (n, 3, H, W), np.float32)
+        if want_rgb8 and out_rgb8 is None:
+            out_rgb8 = _empty(xyz, (n, H, W, 3), np.uint8)
+        radii = _empty(xyz, (n, P), np.int32) if want_radii else None
+        st = _stream_of(xyz, stream)
+
+        def call():
+            _lib.check(self._lib.gs2m_render_views(self._h, C.byref(g), cam_arr, n, bg_arr, float(scale_modifier),
+                                                   _ptr(out_color), _ptr(out_rgb8), _ptr(radii), st), self._lib)
+
+        call()
+        nr = None
+        if sync:
+            nr, ov, req = self.status(n, st)
+            if ov:
+                self.reserve(P, min(n, 2), W, H, int(req * 1.25) + 1024)
+                call()
+                nr, ov, req = self.status(n, st)
+                if ov:
+                    raise RuntimeError("instance arena overflow persists after growing")
+            self.last_num_rendered = nr
+        return dict(color=out_color, rgb8=out_rgb8, radii=radii, num_rendered=nr)
+
+    # -- parity taps ------------------------------------------------------------------------------
+    def download_geometry(self, v, P, stream=None):
+        out = dict(means2D=np.zeros((P, 2), np.float32), depths=np.zeros(P, np.float32),
+                   conic_opacity=np.zeros((P, 4), np.float32), rgb=np.zeros((P, 3), np.float32),
+                   rect=np.zeros((P, 4), np.uint16), tiles_touched=np.zeros(P, np.uint32))
+        vp = lambda a: C.c_void_p(a.ctypes.data)
+        _lib.check(self._lib.gs2m_raster_download_geometry(
+            self._h, stream or C.c_void_p(0), int(v), int(P), vp(out["means2D"]), vp(out["depths"]),
+            vp(out["conic_opacity"]), vp(out["rgb"]), vp(out["rect"]), vp(out["tiles_touched"])), self._lib)
+        return out
+
+    def download_binning(self, v, n, n_tiles, stream=None):
+        pl = np.zeros(max(int(n), 1), np.uint32)
+        ranges = np.zeros((n_tiles, 2), np.uint32)
+        _lib.check(self._lib.gs2m_raster_download_binning(self._h, stream or C.c_void_p(0), int(v), int(n),
+                                                          C.c_void_p(pl.ctypes.data), int(n_tiles),
+                                                          C.c_void_p(ranges.ctypes.data)), self._lib)
+        return pl[:int(n)], ranges

@@ -235,17 +235,6 @@ int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, fl
 int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
                      const float* weight, const uint32_t* rgb_sum, gs2m_stream stream);
 
-/*
- * Replaces volume.extract_triangle_mesh() (tsdf_utils.py:108): marching cubes over the
- * allocated blocks.  Two-call protocol: first call with vertices == NULL returns the
- * counts (synchronises); second call fills DEVICE buffers vertices[nv,3] f64-as-f32?  no:
- * vertices[nv,3] f32, colors[nv,3] f32 (0..1), triangles[nt,3] i32 (unwelded: 3 vertices per
- * triangle; welding is done by the host mirror).
- */
-int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_triangles);
-int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, float* vertices,
-                      float* colors, int64_t* n_triangles);
-
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -15,3 +16,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def backend(request):
+    """Parity tests run twice: on the CPU emulator build of the kernel sources (not gpu) and on
+    the real HIP library (-m gpu)."""
+    from backends import make
+    return make(request.param)

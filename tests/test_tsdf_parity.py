@@ -1,0 +1,178 @@
+"""TSDF parity: HIP integrator (through the C ABI / Open3D-shaped front-end) vs the CPU oracle
+(restated Open3D 0.17 ScalableTSDFVolume) on identical frames, on both back-ends.
+
+Tolerances (DESIGN.md "Parity"):
+  * set of allocated blocks, set of blocks integrated per frame: exact;
+  * weight (integer counts stored as f32): exact;
+  * tsdf: BIT-EXACT when frames are integrated in the same order (same fp32 running-mean
+    update, translation unit compiled without FMA contraction);
+  * colour: the HIP path keeps exact integer sums; mean = sum/weight vs upstream's f64 running
+    mean: <= 1e-9 on the 0..255 scale.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from gs2mesh_amd import synthetic
+from gs2mesh_amd.integration import (Image, PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume,
+                                     TSDFVolumeColorType)
+
+
+def frames(n, W, H, f, radius=0.6, ring=3.5, total=16):
+    poses = synthetic.ring_poses(n, ring, 0, total)
+    cx, cy = W / 2.0, H / 2.0
+    out = []
+    for k, p in enumerate(poses):
+        E = np.eye(4)
+        E[:3] = p
+        d = synthetic.sphere_depth(p, W, H, f, f, cx, cy, radius)
+        c = np.roll(synthetic.color_pattern(W, H), 7 * k, axis=1)
+        out.append((d, c, E))
+    return out, (W, H, f, f, cx, cy)
+
+
+def run_both(be, frs, K, voxel, trunc, depth_scale=1.0, depth_trunc=1e9, mask=None, min_depth=0.0, max_blocks=2048,
+             color=True):
+    W, H, fx, fy, cx, cy = K
+    ct = TSDFVolumeColorType.RGB8 if color else TSDFVolumeColorType.NoColor
+    vol = ScalableTSDFVolume(voxel, trunc, ct, max_blocks=max_blocks, lib=be.lib)
+    ref = oracle.ScalableTSDFVolume(voxel, trunc, int(ct))
+    intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
+    per_frame = []
+    for (d, c, E) in frs:
+        rgbd = RGBDImage.create_from_color_and_depth(Image(be.dev(c)), Image(be.dev(d)), depth_scale=depth_scale,
+                                                     depth_trunc=depth_trunc, convert_rgb_to_intensity=False)
+        before = vol.status()[1]
+        vol.integrate(rgbd, intr, E, mask=None if mask is None else be.dev(mask), min_depth=min_depth)
+        per_frame.append(vol.status()[1] - before)
+        dd = d.copy()
+        if mask is not None:
+            dd = dd * (mask != 0)
+        if min_depth > 0:
+            dd = np.where(dd < np.float32(min_depth), 0, dd).astype(np.float32)
+        dd = oracle.ScalableTSDFVolume.convert_depth(dd, depth_scale, depth_trunc)
+        nref = ref.integrate(dd, c if color else None, W, H, fx, fy, cx, cy, E)
+        assert per_frame[-1] == nref, "blocks integrated in this frame"
+    return vol, ref
+
+
+def compare(vol, ref, color=True, tsdf_exact=True):
+    keys, tsdf, weight, rgb = vol.download()
+    rk, rt, rw, rc = ref.export()
+    assert keys.shape[0] == rk.shape[0] > 0
+    got = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    assert set(got) == set(map(tuple, rk.tolist()))
+    order = np.array([got[tuple(k)] for k in rk.tolist()])
+    tsdf, weight, rgb = tsdf[order], weight[order], rgb[order]
+    np.testing.assert_array_equal(weight, rw)
+    if tsdf_exact:
+        np.testing.assert_array_equal(tsdf, rt)
+    else:
+        np.testing.assert_allclose(tsdf, rt, atol=1e-5, rtol=0)
+    if color:
+        mean = rgb.astype(np.float64) / np.maximum(weight, 1)[..., None]
+        np.testing.assert_allclose(mean, rc, atol=1e-9, rtol=0)
+    return keys.shape[0]
+
+
+def test_sphere_frames_match_oracle(backend):
+    frs, K = frames(3, 160, 120, 170.0)
+    vol, ref = run_both(backend, frs, K, 2.0 / 128, 0.08)
+    n = compare(vol, ref)
+    assert n > 50
+    assert vol.voxel_updates == ref.block_updates * 4096
+
+
+def test_reference_default_parameters_small_image(backend):
+    """voxel 2/512, trunc 0.04 (argument_utils.py:86-87), i.e. the DTU-like setting, on a small frame."""
+    frs, K = frames(2, 128, 96, 400.0, radius=0.25)
+    vol, ref = run_both(backend, frs, K, 2.0 / 512, 0.04, max_blocks=4096)
+    compare(vol, ref)
+
+
+def test_depth_scale_trunc_mask_and_min_depth_are_fused_identically(backend):
+    frs, K = frames(2, 160, 120, 170.0)
+    W, H = K[0], K[1]
+    mask = np.ones((H, W), np.uint8)
+    mask[:, : W // 3] = 0                       # object / occlusion mask (tsdf_utils.py:68-81)
+    # TSDF_scale 0.5 -> depth/0.5; depth_trunc cuts the far half of the sphere; min depth cuts the near cap
+    vol, ref = run_both(backend, frs, K, 2.0 / 64, 0.16, depth_scale=0.5, depth_trunc=6.9, mask=mask, min_depth=3.0)
+    compare(vol, ref)
+
+
+def test_no_color_volume(backend):
+    frs, K = frames(2, 96, 72, 100.0)
+    vol, ref = run_both(backend, frs, K, 2.0 / 64, 0.16, color=False)
+    compare(vol, ref, color=False)
+
+
+def test_view_order_only_changes_tsdf_in_the_last_bits(backend):
+    frs, K = frames(4, 128, 96, 140.0)
+    vol_a, ref = run_both(backend, frs, K, 2.0 / 96, 0.1)
+    vol_b, _ = run_both(backend, frs[::-1], K, 2.0 / 96, 0.1)
+    ka, ta, wa, ca = vol_a.download()
+    kb, tb, wb, cb = vol_b.download()
+    ia = {tuple(k): i for i, k in enumerate(ka.tolist())}
+    order = np.array([ia[tuple(k)] for k in kb.tolist()])
+    np.testing.assert_array_equal(wa[order], wb)           # counts: exact
+    np.testing.assert_array_equal(ca[order], cb)           # integer colour sums: exact
+    np.testing.assert_allclose(ta[order], tb, atol=5e-7)   # running mean: fp32 reassociation only
+
+
+def test_empty_depth_and_format_errors(backend):
+    vol = ScalableTSDFVolume(1 / 64, 0.06, max_blocks=64, lib=backend.lib)
+    intr = PinholeCameraIntrinsic(40, 30, 50, 50, 20, 15)
+    d = np.zeros((30, 40), np.float32)
+    c = np.zeros((30, 40, 3), np.uint8)
+    vol.integrate(RGBDImage(backend.dev(c), backend.dev(d)), intr, np.eye(4))
+    assert vol.status() == (0, 0, 0)
+    with pytest.raises(RuntimeError, match="Unsupported image format"):
+        vol.integrate(RGBDImage(backend.dev(c), backend.dev(d)), PinholeCameraIntrinsic(41, 30, 50, 50, 20, 15),
+                      np.eye(4))
+    with pytest.raises(RuntimeError, match="Unsupported image format"):
+        RGBDImage.create_from_color_and_depth(Image(c[:10]), Image(d), convert_rgb_to_intensity=False)
+
+
+def test_block_pool_overflow_is_reported(backend):
+    frs, K = frames(1, 160, 120, 170.0)
+    W, H, fx, fy, cx, cy = K
+    vol = ScalableTSDFVolume(2.0 / 128, 0.08, max_blocks=8, lib=backend.lib)
+    d, c, E = frs[0]
+    vol.integrate(RGBDImage(backend.dev(c), backend.dev(d)), PinholeCameraIntrinsic(W, H, fx, fy, cx, cy), E)
+    with pytest.raises(RuntimeError, match="block pool exhausted"):
+        vol.status()
+
+
+def test_pack_unpack_round_trip_and_merge(backend):
+    """The multi-GPU exchange primitives: two half-volumes packed on a canonical key list, summed,
+    and unpacked equal the volume that integrated all frames (weights / colours exact)."""
+    be = backend
+    frs, K = frames(4, 128, 96, 140.0)
+    voxel, trunc = 2.0 / 96, 0.1
+    full, _ = run_both(be, frs, K, voxel, trunc)
+    a, _ = run_both(be, frs[:2], K, voxel, trunc)
+    b, _ = run_both(be, frs[2:], K, voxel, trunc)
+    ka, kb = be.host(a.block_keys()), be.host(b.block_keys())
+    canon = np.unique(np.concatenate([ka, kb]), axis=0).astype(np.int32)
+    n = canon.shape[0]
+    bufs = []
+    for v in (a, b):
+        ws = be.dev(np.zeros((n, 4096), np.float32))
+        w = be.dev(np.zeros((n, 4096), np.float32))
+        c = be.dev(np.zeros((n, 3, 4096), np.uint32))
+        v.pack(be.dev(canon), ws, w, c)
+        be.sync()
+        bufs.append((be.host(ws).copy(), be.host(w).copy(), be.host(c).copy().view(np.uint32)))
+    ws = bufs[0][0] + bufs[1][0]
+    w = bufs[0][1] + bufs[1][1]
+    c = bufs[0][2] + bufs[1][2]
+    merged = ScalableTSDFVolume(voxel, trunc, max_blocks=2048, lib=be.lib)
+    merged.unpack(be.dev(canon), be.dev(ws), be.dev(w), be.dev(c))
+    km, tm, wm, cm = merged.download()
+    kf, tf, wf, cf = full.download()
+    im = {tuple(k): i for i, k in enumerate(km.tolist())}
+    assert set(im) == set(map(tuple, kf.tolist()))
+    order = np.array([im[tuple(k)] for k in kf.tolist()])
+    np.testing.assert_array_equal(wm[order], wf)
+    np.testing.assert_array_equal(cm[order], cf)
+    np.testing.assert_allclose(tm[order], tf, atol=1e-6)

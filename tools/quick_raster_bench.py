@@ -1,0 +1,43 @@
+"""Quick rasteriser timing on synthetic configs (development aid; bench.py is the contract)."""
+import argparse
+import json
+import time
+
+import numpy as np
+import torch
+
+from gs2mesh_amd import _lib, synthetic
+from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="C2")
+ap.add_argument("--pairs", type=int, default=8)
+ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--cull", type=int, default=0)
+ap.add_argument("--blend", type=int, default=0)
+a = ap.parse_args()
+cfg = synthetic.CONFIGS[a.config]
+g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+gd = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+gd["raw"] = True
+poses = synthetic.ring_poses(a.pairs, cfg.ring_radius, 0, cfg.n_pairs)
+cams = []
+for p in poses:
+    l, r = synthetic.stereo_cameras(p, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline)
+    cams.append([camera_from(l), camera_from(r)])
+R = Rasterizer(0)
+R.set_option(_lib.OPT_EXACT_TILE_CULL, a.cull)
+R.set_option(_lib.OPT_BLEND_VARIANT, a.blend)
+out = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
+res = R.render_views(gd, cams[0], out_color=out)
+print("num_rendered", res["num_rendered"], "mean", float(out.mean()))
+torch.cuda.synchronize()
+for it in range(a.iters):
+    t0 = time.perf_counter()
+    for c in cams:
+        R.render_views(gd, c, out_color=out, sync=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nr, ov, req = R.status(2)
+    print(json.dumps(dict(config=a.config, cull=a.cull, blend=a.blend, pairs_per_s=len(cams) / dt,
+                          ms_per_pair=1e3 * dt / len(cams), overflow=ov, num_rendered=nr)))
