@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py -- the render -> fuse hot path on synthetic data, one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W] [--config C2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N
+
+A step = one pass of the hot path over one stereo view: render the L/R pair of the view from the
+(pre-activation) Gaussians, then integrate the view's depth frame + the rendered left image (u8, on
+device) into the block-sparse TSDF.  The workload at N=1 is BASELINE.json configs[1] (C2: 300k Gaussians,
+1600x1200, TSDF 512^3, reference defaults voxel 2/512 / trunc 0.04); depth = analytic sphere (the
+reference's depth comes from the DLNR stereo network, which is outside the path).  All inputs are
+resident in HBM before the timed region.  N>1: weak scaling -- every rank renders+fuses its own K
+views with no data-path collective, then ONE RCCL sum-reduction of the TSDF accumulators inside the
+timed region (gs2mesh_amd/parallel.py).
+
+Prints ONE JSON line (rank 0): value = whole-job stereo pairs rendered+fused per second.
+Extra objects: "tsdf" (Mvoxel-updates/s), "stages" (hipEvent time per kernel launch),
+"roofline" (dominant kernel), "raster_roofline" (whole rasteriser vs SURVEY.md 8d's B_pair),
+"cpu_baseline" (oracle = restated Open3D 0.17 integrate on the host cores, bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); measured float4-copy peak 6.29e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=49)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--cull", type=int, default=int(os.environ.get("GS2M_BENCH_CULL", "1")),
+                    help="exact tile culling (image-preserving); 0 = reference instance lists")
+    ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "0")))
+    ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "reduce_scatter"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gs2mesh_amd import _lib, synthetic
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+    from gs2mesh_amd.parallel import reduce_volume
+    from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    K, Wm = args.steps, args.warmup
+    cfg = synthetic.CONFIGS[args.config]
+    Wd, Ht = cfg.width, cfg.height
+    cx, cy = Wd / 2.0, Ht / 2.0
+
+    # ---- inputs, resident in HBM --------------------------------------------------------------
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+    gd["raw"] = True
+    n_local = K + Wm
+    poses = synthetic.ring_poses(n_local, cfg.ring_radius, first=rank * n_local, total=world * n_local)
+    cams, depths, Es = [], [], []
+    for p in poses:
+        l, r = synthetic.stereo_cameras(p, Wd, Ht, cfg.focal, cfg.focal, cfg.baseline)
+        cams.append([camera_from(l), camera_from(r)])
+        depths.append(synthetic.sphere_depth_torch(p, Wd, Ht, cfg.focal, cfg.focal, cx, cy, cfg.sphere_radius, dev))
+        E = np.eye(4)
+        E[:3] = p
+        Es.append(E)
+    intr = PinholeCameraIntrinsic(Wd, Ht, cfg.focal, cfg.focal, cx, cy)
+    depth_trunc = cfg.baseline * 20          # TSDF_max_depth_baselines (argument_utils.py:37)
+    min_depth = cfg.baseline * 4             # TSDF_min_depth_baselines
+    n_blocks_dense = (cfg.tsdf_n // 16) ** 3
+    R = Rasterizer(local_rank)
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, args.cull)
+    R.set_option(_lib.OPT_BLEND_VARIANT, args.blend)
+    vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=n_blocks_dense, device=local_rank)
+    color = torch.empty((2, 3, Ht, Wd), dtype=torch.float32, device=dev)
+    rgb8 = torch.empty((2, Ht, Wd, 3), dtype=torch.uint8, device=dev)
+
+    def step(i):
+        R.render_views(gd, cams[i], out_color=color, out_rgb8=rgb8, sync=False)
+        vol.integrate(RGBDImage(rgb8[0], depths[i], depth_scale=1.0, depth_trunc=depth_trunc), intr, Es[i],
+                      min_depth=min_depth)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warm-up (also sizes the instance arena: grow + retry happens here, not in the timed loop)
+    res = R.render_views(gd, cams[0], out_color=color, out_rgb8=rgb8, want_radii=True)
+    num_rendered0 = res["num_rendered"]
+    radii0 = res["radii"]
+    p_vis = [(radii0[v] > 0).sum().item() for v in range(2)]
+    p_vis_union = ((radii0[0] > 0) | (radii0[1] > 0)).sum().item()
+    R.reserve(cfg.P, 2, Wd, Ht, int(max(num_rendered0) * 1.3))
+    for i in range(Wm):
+        step(i)
+    if world > 1:
+        reduce_volume(vol, mode=args.reduce)      # warm the RCCL communicator
+    vol.status()
+    vol.reset()
+
+    # ---- timed region: EXACTLY K steps (+ the volume reduction when N > 1) --------------------
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        step(i)
+    red = None
+    if world > 1:
+        torch.cuda.synchronize()
+        t_red0 = time.perf_counter()
+        red = reduce_volume(vol, mode=args.reduce)
+        torch.cuda.synchronize()
+        t_red = time.perf_counter() - t_red0
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    nr, ov, req = R.status(2)
+    assert not ov, "instance arena overflow inside the timed region"
+
+    # ---- instrumented pass (hipEvents around every kernel launch, on the work stream) ---------
+    if world > 1:
+        local_updates = None
+    vol.reset()
+    vol.status()
+    R.set_option(_lib.OPT_STAGE_TIMING, 1)
+    vol.set_stage_timing(True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        step(i)
+    torch.cuda.synchronize()
+    dt_instr = time.perf_counter() - t1
+    st_r = R.stage_times()
+    st_t = vol.stage_times()
+    R.set_option(_lib.OPT_STAGE_TIMING, 0)
+    vol.set_stage_timing(False)
+    n_blocks, block_updates, _ = vol.status()
+    stages = {k: dict(avg_us=1e3 * ms / max(c, 1), launches=int(c)) for k, (ms, c) in {**st_r, **st_t}.items()}
+    # voxels that actually updated (pass sdf > -trunc): every update adds 1 to the voxel's weight
+    keys_h, tsdf_h, weight_h, _ = vol.download()
+    U_total = float(weight_h.sum())
+    U_frame = U_total / K
+    blocks_frame = block_updates / K
+
+    # ---- algorithmic bytes, per kernel launch = per stereo pair ------------------
+    N_eye = [float(x) for x in num_rendered0]           # instances produced by this build (culling mode)
+    img = 12.0 * Wd * Ht
+    alg = {
+        "project_count": 44.0 * cfg.P + 192.0 * p_vis_union + 40.0 * sum(p_vis),
+        "scatter": 12.0 * sum(N_eye),
+        "sort_tiles": 24.0 * sum(N_eye),
+        "blend": 40.0 * sum(N_eye) + 2 * img,
+        "hist_colscan": 0.0, "tile_scan": 0.0,
+        "tsdf_touch": 4.0 * Wd * Ht / 16.0,
+        "tsdf_integrate": 40.0 * U_frame + 7.0 * Wd * Ht,
+    }
+    B_pair = 44.0 * cfg.P + 192.0 * p_vis_union + sum(40.0 * pv + 76.0 * n + img for pv, n in zip(p_vis, N_eye))
+    t_raster = sum(stages[k]["avg_us"] for k in _lib.RASTER_STAGES) * 1e-6
+    t_tsdf = sum(stages[k]["avg_us"] for k in _lib.TSDF_STAGES) * 1e-6
+    dom = max(stages, key=lambda k: stages[k]["avg_us"] * stages[k]["launches"])
+    achieved = alg[dom] / (stages[dom]["avg_us"] * 1e-6)
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            tr = json.load(open(prof))
+            ent = tr.get(args.config, {}).get(dom)
+            if ent and ent.get("cull") == args.cull:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_us=round(stages[dom]["avg_us"], 2),
+                    note="blend is VALU/LDS-bound (12 flop + exp per pixel x instance, data served from LDS); "
+                         "HBM fraction reported as the contract asks, see DESIGN.md")
+    per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launches=v["launches"],
+                          alg_GBps=round(alg[k] / max(v["avg_us"], 1e-9) / 1e3, 1),
+                          frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4))
+                  for k, v in stages.items()}
+    raster_roofline = dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
+                           achieved_GBps=round(B_pair / t_raster / 1e9, 1), frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4),
+                           frac_of_6p29TBps=round(B_pair / t_raster / 6.29e12, 4),
+                           render_only_pairs_per_s=round(1.0 / t_raster, 1))
+    tsdf = dict(mvoxel_updates_per_s_job=round(world * K * blocks_frame * 4096 / dt / 1e6, 1),
+                mvoxel_updates_per_s_kernels=round(blocks_frame * 4096 / t_tsdf / 1e6, 1),
+                blocks_per_frame=round(blocks_frame, 1), updated_voxels_per_frame=round(U_frame, 1),
+                allocated_blocks=int(n_blocks), voxel_length=cfg.voxel_length, sdf_trunc=cfg.sdf_trunc,
+                unit="Mvoxel-updates/s (4096 per touched 16^3 block per frame)")
+    if red is not None:
+        tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 5), union_blocks=int(red["n_blocks_union"]),
+                              bytes_per_rank=int(red["bytes_per_rank"]))
+
+    # ---- CPU baseline: the oracle (restated Open3D integrate), rank 0, N = 1 only ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
+        cores = os.cpu_count() or 1
+        left_u8 = rgb8[0].cpu().numpy()
+        t_cpu, n_cpu, blocks_cpu = 0.0, 0, 0
+        for i in range(Wm, Wm + K):
+            d = depths[i].cpu().numpy()
+            d = np.where(d < np.float32(min_depth), 0, d).astype(np.float32)
+            d = oracle.ScalableTSDFVolume.convert_depth(d, 1.0, depth_trunc)
+            tc = time.perf_counter()
+            blocks_cpu += ref.integrate(d, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[i])
+            t_cpu += time.perf_counter() - tc
+            n_cpu += 1
+            if t_cpu > args.cpu_seconds:
+                break
+        cpu = dict(value=round(blocks_cpu * 4096 / t_cpu / 1e6, 2), unit="Mvoxel-updates/s", cores=cores,
+                   kind="port", label="restated Open3D 0.17 ScalableTSDFVolume::Integrate (oracle/tsdf_oracle.cpp, "
+                                      "OpenMP over the 16 x-slices of a block like upstream)",
+                   sample=f"{n_cpu} of the {K} timed {args.config} frames ({Wd}x{Ht}), integrate() only, {t_cpu:.1f} s")
+
+    if rank == 0:
+        out = dict(
+            metric="stereo-pair renders/sec + TSDF Mvoxel-updates/sec",
+            value=round(world * K / dt, 2), unit="stereo-pairs/s (rendered L+R and fused)",
+            n_gpus=world, steps=K, warmup=Wm, ms_per_step=round(1e3 * dt / K, 4), higher_is_better=True,
+            scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload=f"{args.config}: {cfg.P} synth_v1 Gaussians (SH deg 3), {K} stereo pairs/GPU at "
+                                 f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
+                                 f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
+                        exact_tile_cull=args.cull, blend_variant=args.blend,
+                        parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
+            num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis,
+            tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, cpu_baseline=cpu,
+            instrumented_ms_per_step=round(1e3 * dt_instr / K, 4))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,9 @@ class Gaussians(C.Structure):
 OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_DEBUG_SYNC = 3
+OPT_STAGE_TIMING = 4
+RASTER_STAGES = ("project_count", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend")
+TSDF_STAGES = ("tsdf_touch", "tsdf_integrate")
 
 _PROTOS = {
     "gs2m_version": (i32, []),
@@ -48,12 +51,15 @@ _PROTOS = {
     "gs2m_render_views": (i32, [vp, C.POINTER(Gaussians), C.POINTER(Camera), i32, C.POINTER(f32), f32, vp, vp, vp,
                                 vp]),
     "gs2m_raster_status": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
+    "gs2m_raster_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
     "gs2m_raster_download_geometry": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "gs2m_raster_download_binning": (i32, [vp, vp, i32, i64, vp, C.c_int32, vp]),
     "gs2m_tsdf_create": (i32, [C.POINTER(vp), f64, f64, i32, i32, i32, i64, i32]),
     "gs2m_tsdf_destroy": (i32, [vp]),
     "gs2m_tsdf_reset": (i32, [vp, vp]),
     "gs2m_tsdf_integrate": (i32, [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, C.POINTER(f64), f64, f64, f64, vp]),
+    "gs2m_tsdf_set_stage_timing": (i32, [vp, i32]),
+    "gs2m_tsdf_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
     "gs2m_tsdf_status": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
     "gs2m_tsdf_download": (i32, [vp, vp, i64, vp, vp, vp, vp]),
     "gs2m_tsdf_block_keys": (i32, [vp, i64, vp, vp]),

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/gs2mesh_amd.h"
 #include "raster_internal.h"
@@ -35,7 +36,13 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 0, opt_debug = 0;
+    int opt_exact_cull = 0, opt_blend = 0, opt_debug = 0, opt_timing = 0;
+    struct EvPair {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> ev_live;        // recorded, not yet read
+    std::vector<hipEvent_t> ev_free;    // recycled events
     CamUniform* d_cams = nullptr;  // [GS2M_MAX_VIEWS]
     GeomRec* d_recs = nullptr;
     size_t recs_cap = 0;  // records
@@ -100,6 +107,11 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     (void)hipFree(r->d_tmp);
     (void)hipFree(r->d_status);
     (void)hipHostFree(r->h_status);
+    for (auto& p : r->ev_live) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : r->ev_free) (void)hipEventDestroy(e);
     delete r;
     return 0;
 }
@@ -113,6 +125,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
         case GS2M_OPT_BLEND_VARIANT: r->opt_blend = value; return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
+        case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
     }
 }
@@ -165,6 +178,36 @@ static int dbg_check(gs2m_raster* r, hipStream_t st, const char* what) {
     return 0;
 }
 
+static hipEvent_t ev_get(gs2m_raster* r) {
+    if (!r->ev_free.empty()) {
+        hipEvent_t e = r->ev_free.back();
+        r->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct StageTimer {  // RAII: records an event pair around one stage launch when timing is on
+    gs2m_raster* r;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    int stage;
+    StageTimer(gs2m_raster* r_, hipStream_t st_, int stage_) : r(r_), st(st_), stage(stage_) {
+        if (r->opt_timing) {
+            a = ev_get(r);
+            b = ev_get(r);
+            if (a) (void)hipEventRecord(a, st);
+        }
+    }
+    ~StageTimer() {
+        if (a && b) {
+            (void)hipEventRecord(b, st);
+            r->ev_live.push_back({stage, a, b});
+        }
+    }
+};
+
 // One fused pass over nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams.
 static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, float* out_color,
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
@@ -185,22 +228,40 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     }
     if (gs2m_raster_reserve(r, g.P, nv, W, H, 0)) return 1;
     const unsigned cap = r->inst_cap;
-    if (gs2m_launch_project_count(nv, n_wg, lds, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
-                                  r->opt_exact_cull))
-        return 1;
+    {
+        StageTimer tm(r, st, GS2M_STAGE_PROJECT);
+        if (gs2m_launch_project_count(nv, n_wg, lds, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
+                                      r->opt_exact_cull))
+            return 1;
+    }
     if (dbg_check(r, st, "project_count")) return 1;
-    gs2m_launch_hist_colscan(st, nv, r->d_hist, n_wg, tiles, r->d_tile_count);
+    {
+        StageTimer tm(r, st, GS2M_STAGE_COLSCAN);
+        gs2m_launch_hist_colscan(st, nv, r->d_hist, n_wg, tiles, r->d_tile_count);
+    }
     if (dbg_check(r, st, "hist_colscan")) return 1;
-    gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + status_slot, cap);
+    {
+        StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
+        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + status_slot, cap);
+    }
     if (dbg_check(r, st, "tile_scan")) return 1;
-    if (gs2m_launch_scatter(nv, n_wg, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
-                            r->d_keys, cap, r->opt_exact_cull))
-        return 1;
+    {
+        StageTimer tm(r, st, GS2M_STAGE_SCATTER);
+        if (gs2m_launch_scatter(nv, n_wg, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
+                                r->d_keys, cap, r->opt_exact_cull))
+            return 1;
+    }
     if (dbg_check(r, st, "scatter")) return 1;
-    gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap);
+    {
+        StageTimer tm(r, st, GS2M_STAGE_SORT);
+        gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap);
+    }
     if (dbg_check(r, st, "sort_tiles")) return 1;
-    gs2m_launch_blend(st, r->opt_blend, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams, g.P, cap,
-                      out_color, out_rgb8);
+    {
+        StageTimer tm(r, st, GS2M_STAGE_BLEND);
+        gs2m_launch_blend(st, r->opt_blend, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams, g.P, cap,
+                          out_color, out_rgb8);
+    }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;
     r->last_nv = nv;
@@ -398,6 +459,25 @@ extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_view
     for (int v = 0; v < n && num_rendered; ++v) num_rendered[v] = r->h_status[v].num_rendered;
     if (overflow) *overflow = ov;
     if (required) *required = req;
+    return 0;
+}
+
+extern "C" int gs2m_raster_stage_times(gs2m_raster* r, gs2m_stream stream, double* total_ms, int64_t* launches) {
+    if (!r || !total_ms || !launches) {
+        gs2m_set_error("gs2m_raster_stage_times: NULL argument");
+        return 1;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (auto& p : r->ev_live) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && p.stage >= 0 && p.stage < GS2M_N_STAGES) {
+            total_ms[p.stage] += ms;
+            launches[p.stage] += 1;
+        }
+        r->ev_free.push_back(p.a);
+        r->ev_free.push_back(p.b);
+    }
+    r->ev_live.clear();
     return 0;
 }
 

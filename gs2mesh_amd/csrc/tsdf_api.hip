@@ -28,7 +28,25 @@ struct gs2m_tsdf {
     unsigned* h_counters = nullptr;         // pinned [4]
     unsigned long long* h_totals = nullptr; // pinned [1]
     int n_cu = 256;
+    int timing = 0;
+    struct EvPair {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> ev_live;
+    std::vector<hipEvent_t> ev_free;
 };
+
+static hipEvent_t tsdf_ev_get(gs2m_tsdf* t) {
+    if (!t->ev_free.empty()) {
+        hipEvent_t e = t->ev_free.back();
+        t->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
 
 // General 4x4 inverse (cofactors), double.  The reference hands Open3D world->camera and
 // Open3D inverts it again (PointCloudFactory.cpp: camera_pose = extrinsic.inverse()).
@@ -145,6 +163,11 @@ extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
     (void)hipFree(V.totals);
     (void)hipHostFree(t->h_counters);
     (void)hipHostFree(t->h_totals);
+    for (auto& p : t->ev_live) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : t->ev_free) (void)hipEventDestroy(e);
     delete t;
     return 0;
 }
@@ -221,9 +244,55 @@ extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8
     f.use_mask = mask != nullptr;
     f.use_min = min_depth > 0;
     HIPCHK(hipMemsetAsync(t->V.counters + 1, 0, sizeof(unsigned), st));  // touched_count = 0
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (t->timing) {
+        e0 = tsdf_ev_get(t);
+        e1 = tsdf_ev_get(t);
+        e2 = tsdf_ev_get(t);
+        e3 = tsdf_ev_get(t);
+    }
+    const bool tm = e0 && e1 && e2 && e3;
+    if (tm) (void)hipEventRecord(e0, st);
     gs2m_launch_tsdf_touch(st, t->V, f, depth, mask);
+    if (tm) {
+        (void)hipEventRecord(e1, st);
+        (void)hipEventRecord(e2, st);
+    }
     // persistent grid: enough workgroups to fill the chip; each loops over the touched list
     gs2m_launch_tsdf_integrate(st, t->n_cu * 8, t->V, f, depth, color, mask);
+    if (tm) {
+        (void)hipEventRecord(e3, st);
+        t->ev_live.push_back({0, e0, e1});
+        t->ev_live.push_back({1, e2, e3});
+    }
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_set_stage_timing(gs2m_tsdf* t, int enable) {
+    if (!t) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    t->timing = enable != 0;
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_stage_times(gs2m_tsdf* t, gs2m_stream stream, double* total_ms, int64_t* launches) {
+    if (!t || !total_ms || !launches) {
+        gs2m_set_error("gs2m_tsdf_stage_times: NULL argument");
+        return 1;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (auto& p : t->ev_live) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && (p.stage == 0 || p.stage == 1)) {
+            total_ms[p.stage] += ms;
+            launches[p.stage] += 1;
+        }
+        t->ev_free.push_back(p.a);
+        t->ev_free.push_back(p.b);
+    }
+    t->ev_live.clear();
     return 0;
 }
 

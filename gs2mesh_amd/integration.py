@@ -133,6 +133,10 @@ class ScalableTSDFVolume:
         depth = self._to_dev(image.depth, f32)
         color = self._to_dev(image.color, u8) if self.color_type == TSDFVolumeColorType.RGB8 else None
         msk = self._to_dev(mask, u8) if mask is not None else None
+        # buffers WE created (uploads / dtype conversions) must outlive the asynchronous kernels;
+        # caller-owned device tensors are the caller's to keep alive until it synchronises
+        ours = [t for t, src in ((depth, image.depth), (color, image.color), (msk, mask))
+                if t is not None and t is not src]
         H, W = int(depth.shape[0]), int(depth.shape[1])
         bad = (W != intrinsic.width or H != intrinsic.height or depth.ndim != 2)
         if self.color_type == TSDFVolumeColorType.RGB8:
@@ -145,9 +149,10 @@ class ScalableTSDFVolume:
             self._h, _ptr(depth), _ptr(color), _ptr(msk), W, H, intrinsic.fx, intrinsic.fy, intrinsic.cx,
             intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)), float(image.depth_scale),
             float(image.depth_trunc), float(min_depth), st), self._lib)
-        self._keep.append((depth, color, msk))
-        if len(self._keep) > 64:
-            self.status(stream)
+        if ours:
+            self._keep.append(ours)
+            if len(self._keep) > 64:
+                self.status(stream)
 
     def status(self, stream=None):
         """Synchronises -> (n_blocks, block_updates, overflow_flags); raises on overflow."""
@@ -160,6 +165,15 @@ class ScalableTSDFVolume:
                                    (4, "block index out of the +-2^20 range")) if ov.value & b]
             raise RuntimeError("TSDF volume overflow: " + ", ".join(what))
         return int(nb.value), int(bu.value), int(ov.value)
+
+    def set_stage_timing(self, enable=True):
+        _lib.check(self._lib.gs2m_tsdf_set_stage_timing(self._h, int(bool(enable))), self._lib)
+
+    def stage_times(self, stream=None):
+        ms = (C.c_double * 2)()
+        cnt = (C.c_int64 * 2)()
+        _lib.check(self._lib.gs2m_tsdf_stage_times(self._h, stream or C.c_void_p(0), ms, cnt), self._lib)
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.TSDF_STAGES)}
 
     @property
     def num_blocks(self):

@@ -129,6 +129,15 @@ class Rasterizer:
                                                 C.byref(req)), self._lib)
         return list(nr)[:n_views], bool(ov.value), int(req.value)
 
+    def stage_times(self, stream=None):
+        """With OPT_STAGE_TIMING on: synchronises and returns {stage: (total_ms, launches)} measured with
+        hipEvents on the work stream since the previous query."""
+        n = len(_lib.RASTER_STAGES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _lib.check(self._lib.gs2m_raster_stage_times(self._h, stream or C.c_void_p(0), ms, cnt), self._lib)
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.RASTER_STAGES)}
+
     # -- operator level -------------------------------------------------------------------------
     def forward(self, means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, shs=None,
                 colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, sh_degree=3,

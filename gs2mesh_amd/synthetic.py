@@ -135,3 +135,20 @@ def color_pattern(width, height):
     """Fixed u8 colour image ((u+v)%256, u%256, v%256)."""
     u, v = np.meshgrid(np.arange(width), np.arange(height))
     return np.stack([(u + v) % 256, u % 256, v % 256], axis=-1).astype(np.uint8)
+
+
+def sphere_depth_torch(pose_w2c, width, height, fx, fy, cx, cy, radius, device):
+    """`sphere_depth` evaluated on the device (float64 maths, float32 result)."""
+    import torch
+    t = torch.as_tensor(np.asarray(pose_w2c)[:, 3], dtype=torch.float64, device=device)
+    u = (torch.arange(width, dtype=torch.float64, device=device) - cx) / fx
+    v = (torch.arange(height, dtype=torch.float64, device=device) - cy) / fy
+    dy, dx = torch.meshgrid(v, u, indexing="ij")
+    a = dx * dx + dy * dy + 1.0
+    b = -2.0 * (dx * t[0] + dy * t[1] + t[2])
+    c = float((t * t).sum()) - radius * radius
+    disc = b * b - 4 * a * c
+    hit = disc > 0
+    s = torch.where(hit, (-b - torch.sqrt(torch.clamp(disc, min=0.0))) / (2 * a), torch.zeros_like(a))
+    s = torch.where(s > 0, s, torch.zeros_like(s))
+    return s.to(torch.float32).contiguous()

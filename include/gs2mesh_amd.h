@@ -57,8 +57,21 @@ enum {
                                      whole tile (image unchanged, num_rendered smaller)   */
     GS2M_OPT_BLEND_VARIANT = 2,   /* 0 = 16x16 tile per 256-thread workgroup,
                                      1 = one wave per 16x16 tile, 4 pixels per lane       */
-    GS2M_OPT_DEBUG_SYNC = 3       /* 1 = synchronise + check after every launch (the
+    GS2M_OPT_DEBUG_SYNC = 3,      /* 1 = synchronise + check after every launch (the
                                      reference's `debug`: auxiliary.h:166-173)            */
+    GS2M_OPT_STAGE_TIMING = 4     /* 1 = bracket every stage launch with hipEvents on the
+                                     work stream (read with gs2m_raster_stage_times)      */
+};
+
+/* Stage order of gs2m_raster_stage_times */
+enum {
+    GS2M_STAGE_PROJECT = 0, /* k_project_count */
+    GS2M_STAGE_COLSCAN = 1, /* k_hist_colscan  */
+    GS2M_STAGE_TILESCAN = 2,/* k_tile_scan     */
+    GS2M_STAGE_SCATTER = 3, /* k_scatter       */
+    GS2M_STAGE_SORT = 4,    /* k_sort_tiles    */
+    GS2M_STAGE_BLEND = 5,   /* k_blend_*       */
+    GS2M_N_STAGES = 6
 };
 
 int gs2m_raster_create(gs2m_raster** out, int device);
@@ -159,6 +172,12 @@ int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* g, const gs2m_camera
 int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_views,
                        int64_t* num_rendered, int* overflow, int64_t* required);
 
+/* With GS2M_OPT_STAGE_TIMING on: synchronises `stream`, then adds the hipEvent-measured
+ * GPU time of every stage launch recorded since the last query to total_ms[GS2M_N_STAGES]
+ * and the number of launches to launches[GS2M_N_STAGES] (host arrays, caller-zeroed). */
+int gs2m_raster_stage_times(gs2m_raster* r, gs2m_stream stream, double* total_ms,
+                            int64_t* launches);
+
 /* Debug/parity taps: copy the projected per-Gaussian record of view `v` of the last call to
  * HOST buffers (any may be NULL): means2D[P,2], depths[P], conic_opacity[P,4], rgb[P,3],
  * rect[P,4] (u16 x0,y0,x1,y1), tiles_touched[P].  Synchronises. */
@@ -208,6 +227,12 @@ int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color,
                         const uint8_t* mask, int width, int height, double fx, double fy,
                         double cx, double cy, const double* extrinsic_w2c, double depth_scale,
                         double depth_trunc, double min_depth, gs2m_stream stream);
+
+/* Stage timing as for the rasteriser: enable != 0 brackets k_tsdf_touch (index 0) and
+ * k_tsdf_integrate (index 1) with hipEvents; gs2m_tsdf_stage_times synchronises and
+ * accumulates into total_ms[2] / launches[2]. */
+int gs2m_tsdf_set_stage_timing(gs2m_tsdf* t, int enable);
+int gs2m_tsdf_stage_times(gs2m_tsdf* t, gs2m_stream stream, double* total_ms, int64_t* launches);
 
 /* Synchronises; n_blocks = allocated blocks, block_updates = sum over frames of blocks
  * integrated (x 4096 = voxel-updates), overflow != 0 if the block pool or hash was full. */
