@@ -30,7 +30,15 @@ GS2M_DEVICE T gs2m_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, 64); }
 template <typename T>
 GS2M_DEVICE T gs2m_shfl_up(T v, int d) { return __shfl_up(v, d, 64); }
 
+// Orders LDS traffic of ONE wave (producer lanes -> consumer lanes of the same wave): DS ops of a wave
+// execute in order, so only the compiler must be fenced.
+GS2M_DEVICE void gs2m_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 GS2M_DEVICE int gs2m_syncthreads_count(int pred) { return __syncthreads_count(pred); }
 
 // fast exp for the blend kernel: v_exp_f32(x * log2e) (documented tolerance in DESIGN.md)
 GS2M_DEVICE float gs2m_fast_exp(float x) { return __expf(x); }
+GS2M_DEVICE float gs2m_fast_log(float x) { return __logf(x); }

@@ -96,3 +96,284 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Variant 1 (k_blend_wave4): ONE WAVE PER 16x16 TILE, 4 pixels per lane (column lane&15, rows
+// (lane>>4) + 4k).  A 256-thread workgroup is four independent waves = four consecutive tiles:
+// no __syncthreads at all, a wave leaves as soon as ITS 256 pixels are saturated.
+//   * per instance the wave pays ONE pair of LDS broadcast reads (2 x ds_read_b128) for 256 pixel
+//     evaluations instead of four (variant 0: one pair per 64 pixels) -> VALU-bound, not LDS-bound;
+//   * dx, a*dx*dx and b*dx are shared by the lane's 4 pixels;
+//   * the accumulate path is entered only if some lane of the wave has a contributing pixel;
+//   * the next 64 records are gathered into registers while the current 64 are composited;
+//   * workgroup -> tile-group mapping is XCD-aware (block b runs on XCD b%8: give each XCD a
+//     contiguous run of tiles so neighbouring tiles, which share Gaussians, hit the same L2).
+// ---------------------------------------------------------------------------------------------
+GS2M_KERNEL void __launch_bounds__(256)
+k_blend_wave4(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
+              const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
+              float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
+    __shared__ float4 s_a[4][64];
+    __shared__ float4 s_b[4][64];
+    __shared__ float s_c[4][64];
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int v = (int)blockIdx.y;
+    const CamUniform& cam = cams[v];
+    const int W = cam.W, H = cam.H, gx = cam.gx;
+    const int tiles = gx * cam.gy;
+    // bijective XCD swizzle (guide T1)
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
+    const unsigned grp = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+    const int tile = (int)(grp * 4u) + wave;
+    if (tile >= tiles) return;  // whole wave; no workgroup barriers in this kernel
+    const int tx = tile % gx, ty = tile / gx;
+    const int pxi = tx * GS2M_TILE + (lane & 15);
+    const int py0 = ty * GS2M_TILE + (lane >> 4);
+    const float pxf = (float)pxi;
+    float pyf[4];
+    bool done[4];
+    float T[4], C0[4], C1[4], C2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pyf[k] = (float)(py0 + 4 * k);
+        done[k] = !(pxi < W && py0 + 4 * k < H);
+        T[k] = 1.0f;
+        C0[k] = C1[k] = C2[k] = 0.0f;
+    }
+    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
+    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
+    if (r0 > cap) r0 = cap;
+    if (r1 > cap) r1 = cap;
+    const unsigned long long* kv = keys + (size_t)v * cap;
+    const GeomRec* rv = recs + (size_t)v * P;
+    float4 ra, rb;
+    float rc = 0.0f;
+    ra.x = ra.y = ra.z = ra.w = 0.0f;
+    rb = ra;
+    unsigned base = r0;
+    if (base + (unsigned)lane < r1) {
+        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+        ra = r4[0];
+        rb = r4[1];
+        rc = r4[2].x;
+    }
+    while (base < r1) {
+        const bool all_done = done[0] && done[1] && done[2] && done[3];
+        if (gs2m_ballot(all_done ? 0 : 1) == 0ull) break;
+        gs2m_wave_sync();  // the previous batch has been read by every lane
+        s_a[wave][lane] = ra;
+        s_b[wave][lane] = rb;
+        s_c[wave][lane] = rc;
+        gs2m_wave_sync();
+        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
+        base += 64u;
+        if (base + (unsigned)lane < r1) {  // gather the next batch while this one is composited
+            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+            ra = r4[0];
+            rb = r4[1];
+            rc = r4[2].x;
+        }
+        for (int j = 0; j < nb; ++j) {
+            const float4 A = s_a[wave][j];
+            const float4 B = s_b[wave][j];
+            const float dx = A.x - pxf;
+            const float adx2 = A.z * dx * dx;
+            const float bdx = A.w * dx;
+            float alpha[4];
+            bool hit[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = A.y - pyf[k];
+                const float power = -0.5f * (adx2 + B.x * dy * dy) - bdx * dy;
+                alpha[k] = fminf(0.99f, B.y * gs2m_fast_exp(power));
+                hit[k] = !done[k] && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
+                any = any || hit[k];
+            }
+            if (gs2m_ballot(any ? 1 : 0) != 0ull) {
+                const float cb = s_c[wave][j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (hit[k]) {
+                        const float test_T = T[k] * (1.0f - alpha[k]);
+                        if (test_T < 0.0001f) {
+                            done[k] = true;
+                        } else {
+                            C0[k] += B.z * alpha[k] * T[k];
+                            C1[k] += B.w * alpha[k] * T[k];
+                            C2[k] += cb * alpha[k] * T[k];
+                            T[k] = test_T;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pyi = py0 + 4 * k;
+        if (pxi < W && pyi < H) {
+            const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];
+            const size_t pix = (size_t)pyi * W + pxi;
+            if (out_color) {
+                float* oc = out_color + (size_t)v * 3 * plane;
+                oc[pix] = o0;
+                oc[plane + pix] = o1;
+                oc[2 * plane + pix] = o2;
+            }
+            if (out_rgb8) {
+                unsigned char* o8 = out_rgb8 + ((size_t)v * plane + pix) * 3;
+                o8[0] = quantize_u8(o0);
+                o8[1] = quantize_u8(o1);
+                o8[2] = quantize_u8(o2);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variant 2 (k_blend_wave4p): variant 1's layout with a cheaper inner loop.  The kernel is
+// VALU-bound (measured: ~300 issue cycles per instance x 256 pixels in variant 1), so the loop is
+// rebuilt around instruction count:
+//   * alpha >= 1/255  <=>  power >= -ln(255*opacity).  A per-instance limit lim = -ln(255 o) - 1e-4
+//     (computed once per instance while staging, kept in LDS) gives a conservative one-compare
+//     pre-filter per pixel; exp() and the exact alpha test of the reference run only inside the
+//     accumulate path, and only for the 16x4 strips (the lane's pixel index k) in which some lane
+//     passed the pre-filter;
+//   * a finished pixel is parked at y = 1e18 (its power becomes hugely negative), which removes
+//     every per-pixel "done" flag from the hot path;
+//   * the accumulate path is straight-line predicated arithmetic (weights selected to 0), no
+//     per-pixel exec-mask regions.
+// Decisions are the reference's (same alpha, same thresholds, same order): the pre-filter only
+// skips pixels whose exact test would fail.
+// ---------------------------------------------------------------------------------------------
+#define GS2M_PARKED 1.0e18f
+
+GS2M_KERNEL void __launch_bounds__(256)
+k_blend_wave4p(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
+               const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
+               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
+    __shared__ float4 s_a[4][64];  // mx, my, ca, cb
+    __shared__ float4 s_b[4][64];  // cc, op, r, g
+    __shared__ float2 s_c[4][64];  // b, lim
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int v = (int)blockIdx.y;
+    const CamUniform& cam = cams[v];
+    const int W = cam.W, H = cam.H, gx = cam.gx;
+    const int tiles = gx * cam.gy;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
+    const unsigned grp = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+    const int tile = (int)(grp * 4u) + wave;
+    if (tile >= tiles) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int pxi = tx * GS2M_TILE + (lane & 15);
+    const int py0 = ty * GS2M_TILE + (lane >> 4);
+    const float pxf = (float)pxi;
+    float pyf[4], T[4], C0[4], C1[4], C2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pyf[k] = (pxi < W && py0 + 4 * k < H) ? (float)(py0 + 4 * k) : GS2M_PARKED;
+        T[k] = 1.0f;
+        C0[k] = C1[k] = C2[k] = 0.0f;
+    }
+    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
+    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
+    if (r0 > cap) r0 = cap;
+    if (r1 > cap) r1 = cap;
+    const unsigned long long* kv = keys + (size_t)v * cap;
+    const GeomRec* rv = recs + (size_t)v * P;
+    float4 ra, rb;
+    float rc = 0.0f;
+    ra.x = ra.y = ra.z = ra.w = 0.0f;
+    rb = ra;
+    unsigned base = r0;
+    if (base + (unsigned)lane < r1) {
+        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+        ra = r4[0];
+        rb = r4[1];
+        rc = r4[2].x;
+    }
+    while (base < r1) {
+        const bool live = pyf[0] < 1.0e17f || pyf[1] < 1.0e17f || pyf[2] < 1.0e17f || pyf[3] < 1.0e17f;
+        if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
+        gs2m_wave_sync();
+        s_a[wave][lane] = ra;
+        s_b[wave][lane] = rb;
+        float2 cl;
+        cl.x = rc;
+        // alpha >= 1/255 <=> power >= -ln(255*o); opacity*255 < 1 never contributes (lim > 0 >= power)
+        cl.y = -gs2m_fast_log(rb.y * 255.0f) - 1.0e-4f;
+        s_c[wave][lane] = cl;
+        gs2m_wave_sync();
+        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
+        base += 64u;
+        if (base + (unsigned)lane < r1) {
+            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+            ra = r4[0];
+            rb = r4[1];
+            rc = r4[2].x;
+        }
+        for (int j = 0; j < nb; ++j) {
+            const float4 A = s_a[wave][j];
+            const float4 B = s_b[wave][j];
+            const float2 CL = s_c[wave][j];
+            const float dx = A.x - pxf;
+            const float adx2 = A.z * dx * dx;
+            const float bdx = A.w * dx;
+            float power[4];
+            bool cand[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dy = A.y - pyf[k];
+                power[k] = -0.5f * (adx2 + B.x * dy * dy) - bdx * dy;
+                cand[k] = power[k] >= CL.y && !(power[k] > 0.0f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (gs2m_ballot(cand[k] ? 1 : 0) != 0ull) {  // wave-uniform: strip k has a candidate
+                    const float alpha = fminf(0.99f, B.y * gs2m_fast_exp(power[k]));
+                    const bool hit = cand[k] && !(alpha < 1.0f / 255.0f);
+                    const float test_T = T[k] * (1.0f - alpha);
+                    const bool sat = hit && test_T < 0.0001f;
+                    const bool acc = hit && !sat;
+                    const float w = acc ? alpha : 0.0f;
+                    C0[k] += B.z * w * T[k];
+                    C1[k] += B.w * w * T[k];
+                    C2[k] += CL.x * w * T[k];
+                    T[k] = acc ? test_T : T[k];
+                    pyf[k] = sat ? GS2M_PARKED : pyf[k];
+                }
+            }
+        }
+    }
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pyi = py0 + 4 * k;
+        if (pxi < W && pyi < H) {
+            const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];
+            const size_t pix = (size_t)pyi * W + pxi;
+            if (out_color) {
+                float* oc = out_color + (size_t)v * 3 * plane;
+                oc[pix] = o0;
+                oc[plane + pix] = o1;
+                oc[2 * plane + pix] = o2;
+            }
+            if (out_rgb8) {
+                unsigned char* o8 = out_rgb8 + ((size_t)v * plane + pix) * 3;
+                o8[0] = quantize_u8(o0);
+                o8[1] = quantize_u8(o1);
+                o8[2] = quantize_u8(o2);
+            }
+        }
+    }
+}

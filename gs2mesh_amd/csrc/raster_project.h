@@ -15,7 +15,7 @@
 #include "raster_math.h"
 
 struct ProjView {
-    float mx, my, ca, cb, cc, depth;
+    float mx, my, ca, cb, cc, depth, cova, covc;
     int x0, y0, x1, y1, radius;
     bool ok;
 };
@@ -25,7 +25,7 @@ GS2M_DEVICE void project_view(const CamUniform& cam, float px, float py, float p
     o.ok = false;
     o.radius = 0;
     o.x0 = o.y0 = o.x1 = o.y1 = 0;
-    o.mx = o.my = o.ca = o.cb = o.cc = o.depth = 0.0f;
+    o.mx = o.my = o.ca = o.cb = o.cc = o.depth = o.cova = o.covc = 0.0f;
     float tvx, tvy, tvz;
     xform4x3(cam.view, px, py, pz, tvx, tvy, tvz);
     if (tvz <= 0.2f) return;  // auxiliary.h:154 near cull
@@ -38,6 +38,8 @@ GS2M_DEVICE void project_view(const CamUniform& cam, float px, float py, float p
     const float det = (a * c - b * b);
     if (det == 0.0f) return;
     const float det_inv = 1.f / det;
+    o.cova = a;
+    o.covc = c;
     o.ca = c * det_inv;
     o.cb = -b * det_inv;
     o.cc = a * det_inv;
@@ -171,6 +173,29 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                     cg = sh_channel(g.D, sh, 1, dx, dy, dz);
                     cb = sh_channel(g.D, sh, 2, dx, dy, dz);
                 }
+                // GS2M_OPT_EXACT_TILE_CULL (image-preserving extension): shrink the reference's AABB-of-
+                // the-3-sigma-circle rect to the bounding box of the alpha >= 1/255 ellipse,
+                // |dx| <= sqrt(2 t cov_xx), |dy| <= sqrt(2 t cov_yy), t = ln(255 o) (+ margin).  The
+                // stored rect is what the counting sort and the scatter walk.
+                float thr = 0.0f;
+                if (exact_cull) {
+                    thr = cull_threshold(op);
+                    if (thr < 0.0f) {
+                        pv[v].x1 = pv[v].x0;  // never reaches 1/255 anywhere
+                    } else {
+                        const float hx = sqrtf(2.0f * thr * pv[v].cova) + 0.01f;
+                        const float hy = sqrtf(2.0f * thr * pv[v].covc) + 0.01f;
+                        const int bx0 = (int)ceilf((pv[v].mx - hx - (float)(GS2M_TILE - 1)) / GS2M_TILE);
+                        const int bx1 = (int)floorf((pv[v].mx + hx) / GS2M_TILE) + 1;
+                        const int by0 = (int)ceilf((pv[v].my - hy - (float)(GS2M_TILE - 1)) / GS2M_TILE);
+                        const int by1 = (int)floorf((pv[v].my + hy) / GS2M_TILE) + 1;
+                        pv[v].x0 = gs2m_imax(pv[v].x0, bx0);
+                        pv[v].y0 = gs2m_imax(pv[v].y0, by0);
+                        pv[v].x1 = gs2m_imin(pv[v].x1, bx1);
+                        pv[v].y1 = gs2m_imin(pv[v].y1, by1);
+                        if (pv[v].x1 <= pv[v].x0 || pv[v].y1 <= pv[v].y0) pv[v].x1 = pv[v].x0 = pv[v].y0 = pv[v].y1 = 0;
+                    }
+                }
                 float4 w0, w1, w2;
                 w0.x = pv[v].mx;
                 w0.y = pv[v].my;
@@ -188,13 +213,13 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 r4[0] = w0;
                 r4[1] = w1;
                 r4[2] = w2;
-                // per-workgroup LDS tile histogram (replaces tiles_touched + InclusiveSum)
-                const float thr = exact_cull ? cull_threshold(op) : 0.0f;
-                if (exact_cull && thr < 0.0f) continue;
+                // per-workgroup LDS tile histogram (replaces tiles_touched + InclusiveSum).  The exact
+                // per-tile test only pays for rects with corners to cut (>= 2 x 2 tiles).
                 unsigned* h = lhist + v * tiles;
+                const bool per_tile = exact_cull && (pv[v].x1 - pv[v].x0) >= 2 && (pv[v].y1 - pv[v].y0) >= 2;
                 for (int ty = pv[v].y0; ty < pv[v].y1; ++ty)
                     for (int tx = pv[v].x0; tx < pv[v].x1; ++tx)
-                        if (!exact_cull || tile_may_contribute(pv[v].mx, pv[v].my, pv[v].ca, pv[v].cb, pv[v].cc, thr, tx, ty))
+                        if (!per_tile || tile_may_contribute(pv[v].mx, pv[v].my, pv[v].ca, pv[v].cb, pv[v].cc, thr, tx, ty))
                             atomicAdd(&h[ty * gx + tx], 1u);
             }
         }
@@ -238,7 +263,8 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                 const int x1 = (int)(rect1 & 0xffffu), y1 = (int)(rect1 >> 16);
                 if (x1 <= x0 || y1 <= y0) continue;
                 float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
-                if (exact_cull) {
+                const bool per_tile = exact_cull && (x1 - x0) >= 2 && (y1 - y0) >= 2;  // as in k_project_count
+                if (per_tile) {
                     const float4 w0 = r4[0];
                     const float4 w1 = r4[1];
                     mx = w0.x;
@@ -254,7 +280,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                 unsigned long long* kv = keys + (size_t)v * cap;
                 for (int ty = y0; ty < y1; ++ty)
                     for (int tx = x0; tx < x1; ++tx)
-                        if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
+                        if (!per_tile || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
                             const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
                             if (pos < cap) kv[pos] = hi | (unsigned)gi;
                         }

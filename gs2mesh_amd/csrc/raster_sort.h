@@ -9,21 +9,54 @@
 #include "raster_common.h"
 
 // hist[v][wg][t]: per-workgroup counts -> exclusive prefix over workgroups (in place);
-// tile_count[v][t] = column total.  One thread per (view, tile); consecutive threads read
-// consecutive tiles => coalesced.
+// tile_count[v][t] = column total.  A 256-thread workgroup owns 64 consecutive tiles (lane) x 4
+// segments of the workgroup axis (wave): pass 1 sums each segment with back-to-back independent
+// loads (coalesced: consecutive lanes = consecutive tiles), the 4 segment sums are exchanged through
+// LDS, pass 2 re-reads the segment (L2-resident) and writes the running prefix.
 GS2M_KERNEL void __launch_bounds__(256)
 k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count) {
-    const int t = (int)(blockIdx.x * 256u + threadIdx.x);
+    __shared__ unsigned seg_sum[4][64];
+    const int lane = (int)(threadIdx.x & 63u), seg = (int)(threadIdx.x >> 6);
+    const int t = (int)blockIdx.x * 64 + lane;
     const int v = (int)blockIdx.y;
+    const int per = (n_wg + 3) / 4;
+    const int w0 = seg * per;
+    const int w1 = w0 + per < n_wg ? w0 + per : n_wg;
+    unsigned* col = hist + (size_t)v * n_wg * tiles + t;
+    unsigned s = 0;
+    if (t < tiles) {
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            unsigned x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(w + u) * tiles];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += x[u];
+        }
+        for (; w < w1; ++w) s += col[(size_t)w * tiles];
+    }
+    seg_sum[seg][lane] = s;
+    __syncthreads();
     if (t < tiles) {
         unsigned run = 0;
-        unsigned* col = hist + (size_t)v * n_wg * tiles + t;
-        for (int w = 0; w < n_wg; ++w) {
+        for (int k = 0; k < seg; ++k) run += seg_sum[k][lane];
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            unsigned x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(w + u) * tiles];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                col[(size_t)(w + u) * tiles] = run;
+                run += x[u];
+            }
+        }
+        for (; w < w1; ++w) {
             const unsigned x = col[(size_t)w * tiles];
             col[(size_t)w * tiles] = run;
             run += x;
         }
-        tile_count[(size_t)v * tiles + t] = run;
+        if (seg == 3) tile_count[(size_t)v * tiles + t] = run;
     }
 }
 

@@ -327,9 +327,32 @@ int64_t oracle_bin(int P, int W, int H, const int* radii, const float* means2D,
         if (radii[idx] > 0) {
             uint32_t rmin[2], rmax[2];
             getRect(means2D[2 * idx], means2D[2 * idx + 1], radii[idx], gx, gy, rmin, rmax);
+            int per_tile = 0;
+            if (exact_cull) {
+                /* the HIP path's rule (raster_project.h): shrink the rect to the bbox of the
+                 * alpha >= 1/255 ellipse, then test tiles individually only for >= 2x2 rects */
+                const float ca = conic_opacity[4 * idx], cb = conic_opacity[4 * idx + 1];
+                const float cc = conic_opacity[4 * idx + 2], op = conic_opacity[4 * idx + 3];
+                if (!(op * 255.0f >= 1.0f)) continue;
+                const float thr = logf(op * 255.0f) * 1.0001f + 0.001f;
+                const float detc = ca * cc - cb * cb;
+                const float cova = cc / detc, covc = ca / detc; /* cov = conic^-1 */
+                const float hx = sqrtf(2.0f * thr * cova) + 0.01f, hy = sqrtf(2.0f * thr * covc) + 0.01f;
+                const float mx = means2D[2 * idx], my = means2D[2 * idx + 1];
+                const int bx0 = (int)ceilf((mx - hx - (float)(BLOCK_X - 1)) / BLOCK_X);
+                const int bx1 = (int)floorf((mx + hx) / BLOCK_X) + 1;
+                const int by0 = (int)ceilf((my - hy - (float)(BLOCK_Y - 1)) / BLOCK_Y);
+                const int by1 = (int)floorf((my + hy) / BLOCK_Y) + 1;
+                if ((int)rmin[0] < bx0) rmin[0] = (uint32_t)bx0;
+                if ((int)rmin[1] < by0) rmin[1] = (uint32_t)by0;
+                if ((int)rmax[0] > bx1) rmax[0] = (uint32_t)(bx1 < 0 ? 0 : bx1);
+                if ((int)rmax[1] > by1) rmax[1] = (uint32_t)(by1 < 0 ? 0 : by1);
+                if (rmax[0] <= rmin[0] || rmax[1] <= rmin[1]) continue;
+                per_tile = (rmax[0] - rmin[0]) >= 2 && (rmax[1] - rmin[1]) >= 2;
+            }
             for (uint32_t y = rmin[1]; y < rmax[1]; y++) {
                 for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
-                    if (exact_cull &&
+                    if (per_tile &&
                         !oracle_tile_may_contribute(means2D[2 * idx], means2D[2 * idx + 1],
                                                     conic_opacity[4 * idx], conic_opacity[4 * idx + 1],
                                                     conic_opacity[4 * idx + 2],

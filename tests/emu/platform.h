@@ -40,6 +40,7 @@ struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct int2 { int x, y; };
+struct alignas(8) float2a { float x, y; };
 struct int3 { int x, y, z; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct uint2 { unsigned x, y; };
@@ -78,6 +79,7 @@ static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 static inline int gs2m_syncthreads_count(int pred) { return ::emu::sync_count(pred); }
 static inline unsigned long long gs2m_ballot(int pred) { return ::emu::ballot(pred); }
+static inline void gs2m_wave_sync() { (void)::emu::ballot(0); }
 static inline int gs2m_lane() { return ::emu::lane(); }
 static inline int gs2m_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 template <typename T>
@@ -98,6 +100,7 @@ static inline T gs2m_shfl_up(T v, int d) {
     return gs2m_shfl(v, l - d >= 0 ? l - d : l);
 }
 static inline float gs2m_fast_exp(float x) { return expf(x); }
+static inline float gs2m_fast_log(float x) { return logf(x); }
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 static inline int __ffsll(unsigned long long m) { return __builtin_ffsll((long long)m); }
 

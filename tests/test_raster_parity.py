@@ -257,3 +257,42 @@ def test_argument_validation_errors(backend):
         r.forward(*base, scales=d(np.ones((4, 3), np.float32)), rotations=d(np.ones((4, 4), np.float32)))
     with pytest.raises(RuntimeError, match="exactly one of either scale/rotation pair"):
         r.forward(*base, colors_precomp=d(np.ones((4, 3), np.float32)))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_blend_variants_match_the_oracle(backend, variant):
+    """Every compositing kernel variant (GS2M_OPT_BLEND_VARIANT) on a ragged image, a crowded
+    saturating tile stack and with exact culling on."""
+    be = backend
+    d = be.dev
+    # ragged image, SH colours, non-zero background
+    W, H, f = 200, 136, 180.0
+    g, s, q, o, shs, left, _ = scene(3000, 11, W, H, f)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    for cull in (0, 1):
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_BLEND_VARIANT, variant)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+        img, _ = r.forward(d(g["xyz"]), d(o), d(left.world_view_transform), d(left.full_proj_transform),
+                           d(left.camera_center), d(bg), W, H, left.tanfovx, left.tanfovy, shs=d(shs), scales=d(s),
+                           rotations=d(q))
+        ref_img, _, _ = oracle_forward(left, g["xyz"], o, bg, shs=shs, scales=s, rotations=q)
+        assert_image_close(be.host(img), ref_img)
+    # crowded tiles (early saturation, > 64-instance batches, merge-path sort)
+    W, H, f = 48, 32, 60.0
+    P = 9000
+    rng = np.random.default_rng(3)
+    xyz = rng.normal(0, 0.02, (P, 3)).astype(np.float32)
+    xyz[:, 2] = rng.uniform(-1, 1, P)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    oo = rng.uniform(0.02, 0.4, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    ss = np.full((P, 3), 0.05, np.float32)
+    qq = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    r = Rasterizer(0, lib=be.lib)
+    r.set_option(_lib.OPT_BLEND_VARIANT, variant)
+    img, _ = r.forward(d(xyz), d(oo), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                       d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols),
+                       scales=d(ss), rotations=d(qq))
+    ref_img, _, _ = oracle_forward(cam, xyz, oo, [0, 0, 0], colors_precomp=cols, scales=ss, rotations=qq)
+    assert_image_close(be.host(img), ref_img)
