@@ -46,6 +46,8 @@ struct gs2m_raster {
     CamUniform* d_cams = nullptr;  // [GS2M_MAX_VIEWS]
     GeomRec* d_recs = nullptr;
     size_t recs_cap = 0;  // records
+    unsigned long long* d_tilemask = nullptr;
+    size_t mask_cap = 0;
     unsigned* d_hist = nullptr;
     size_t hist_cap = 0;  // words
     unsigned* d_tile_count = nullptr;
@@ -100,6 +102,7 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     if (!r) return 0;
     (void)hipFree(r->d_cams);
     (void)hipFree(r->d_recs);
+    (void)hipFree(r->d_tilemask);
     (void)hipFree(r->d_hist);
     (void)hipFree(r->d_tile_count);
     (void)hipFree(r->d_tile_start);
@@ -151,6 +154,7 @@ extern "C" int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, in
     int chunk, n_wg;
     geometry(P, &chunk, &n_wg);
     if (ensure(&r->d_recs, &r->recs_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
+    if (ensure(&r->d_tilemask, &r->mask_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
     if (ensure(&r->d_hist, &r->hist_cap, (size_t)nv * n_wg * tiles)) return 1;
     size_t tc = r->tile_cap;
     if (ensure(&r->d_tile_count, &tc, (size_t)nv * (tiles + 1))) return 1;
@@ -213,8 +217,9 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
     const int tiles = gx * gy;
-    const size_t lds = (size_t)nv * tiles * sizeof(unsigned);
-    if (lds > 160 * 1024) {
+    const size_t lds = (size_t)nv * tiles * sizeof(unsigned);        // scatter: cursors only
+    const size_t lds_p = gs2m_project_lds_bytes(nv, tiles);          // project: histogram + wave staging
+    if (lds_p > 160 * 1024) {
         gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile histogram", W, H, nv, tiles);
         return 1;
     }
@@ -230,8 +235,8 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     const unsigned cap = r->inst_cap;
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
-        if (gs2m_launch_project_count(nv, n_wg, lds, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
-                                      r->opt_exact_cull))
+        if (gs2m_launch_project_count(nv, n_wg, lds_p, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
+                                      r->d_tilemask, r->opt_exact_cull))
             return 1;
     }
     if (dbg_check(r, st, "project_count")) return 1;
@@ -248,7 +253,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
         if (gs2m_launch_scatter(nv, n_wg, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
-                                r->d_keys, cap, r->opt_exact_cull))
+                                r->d_tilemask, r->d_keys, cap, r->opt_exact_cull))
             return 1;
     }
     if (dbg_check(r, st, "scatter")) return 1;
@@ -409,7 +414,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
     // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS histogram allows
     int per = GS2M_MAX_VIEWS;
-    while (per > 1 && (size_t)per * tiles * sizeof(unsigned) > 160 * 1024) per--;
+    while (per > 1 && gs2m_project_lds_bytes(per, tiles) > 160 * 1024) per--;
     for (int v0 = 0; v0 < n_views; v0 += per) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
         for (int k = 0; k < nv; ++k) {

@@ -9,10 +9,11 @@ struct CamUniformArg;
 
 int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
                               const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
-                              int exact_cull);
+                              unsigned long long* tilemask, int exact_cull);
+size_t gs2m_project_lds_bytes(int nv, int tiles);
 int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
-                        unsigned long long* keys, unsigned cap, int exact_cull);
+                        const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull);
 void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,
                               unsigned char* present);
 void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,

@@ -64,14 +64,44 @@ GS2M_DEVICE void project_view(const CamUniform& cam, float px, float py, float p
     o.ok = true;
 }
 
+// ---- wave-balanced tile expansion ------------------------------------------------------------
+// Every Gaussian touches a different number of tiles (1 ... thousands).  Walking the rect per lane
+// (as duplicateWithKeys does, rasterizer_impl.cu:98-108) leaves most lanes idle.  Instead the 64
+// Gaussians of a wave publish their rects in LDS, an inclusive wave scan of the rect areas
+// flattens all (Gaussian, tile) pairs of the wave into one index space, and lane l takes pairs
+// l, l+64, ... (owner found by a 6-step binary search in the scan).  Each kept pair bumps the
+// workgroup's LDS tile histogram and, for rects of <= 64 tiles, sets a bit in the owner's tile
+// mask, which the scatter kernel walks instead of re-testing.
+struct WaveStage {
+    float mx[64], my[64], ca[64], cb[64], cc[64], thr[64];
+    unsigned xy0[64];   // x0 | y0 << 16
+    unsigned wh[64];    // w | h << 16
+    unsigned pref[64];  // inclusive scan of w*h
+    unsigned mlo[64], mhi[64];
+};
+#define GS2M_STAGE_BYTES (4 * (int)sizeof(WaveStage))
+
+GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = gs2m_shfl_up(x, d);
+        if (gs2m_lane() >= d) x += y;
+    }
+    return x;
+}
+
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(256)
 k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n_wg, GeomRec* __restrict__ recs,
-                int* __restrict__ radii, unsigned* __restrict__ hist, int exact_cull) {
-    GS2M_DYN_LDS(unsigned, lhist);
+                int* __restrict__ radii, unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask,
+                int exact_cull) {
+    GS2M_DYN_LDS(unsigned, lds);
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int gx = cams[0].gx, gy = cams[0].gy;
     const int tiles = gx * gy;
+    unsigned* lhist = lds;
+    WaveStage* stage = reinterpret_cast<WaveStage*>(lds + ((NV * tiles + 3) & ~3)) + wave;
     for (int i = tid; i < NV * tiles; i += 256) lhist[i] = 0u;
     __syncthreads();
     const int begin = (int)blockIdx.x * chunk;
@@ -79,7 +109,16 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
     const int ncoef = (g.D + 1) * (g.D + 1);
     for (int base = begin; base < end; base += 256) {
         const int gi = base + tid;
-        if (gi < end) {
+        const bool valid = gi < end;
+        ProjView pv[NV];
+        float op = 0.0f, thr = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            pv[v].ok = false;
+            pv[v].x0 = pv[v].y0 = pv[v].x1 = pv[v].y1 = 0;
+            pv[v].mx = pv[v].my = pv[v].ca = pv[v].cb = pv[v].cc = 0.0f;
+        }
+        if (valid) {
             const float px = g.xyz[3 * (size_t)gi], py = g.xyz[3 * (size_t)gi + 1], pz = g.xyz[3 * (size_t)gi + 2];
             float cov3[6];
             if (g.cov3D_precomp) {
@@ -102,9 +141,8 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 }
                 cov3d_from_scale_rot(sx, sy, sz, g.scale_modifier, qr, qx, qy, qz, cov3);
             }
-            float op = g.opac[gi];
+            op = g.opac[gi];
             if (g.raw) op = 1.0f / (1.0f + expf(-op));  // gaussian_model.py:113-115 sigmoid
-            ProjView pv[NV];
             bool any = false;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -143,6 +181,7 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                         if (k < ncoef * 3) sh[k] = s1[k - 3];
                 }
             }
+            if (exact_cull) thr = cull_threshold(op);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 GeomRec* rec = recs + (size_t)v * g.P + gi;
@@ -177,11 +216,9 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 // the-3-sigma-circle rect to the bounding box of the alpha >= 1/255 ellipse,
                 // |dx| <= sqrt(2 t cov_xx), |dy| <= sqrt(2 t cov_yy), t = ln(255 o) (+ margin).  The
                 // stored rect is what the counting sort and the scatter walk.
-                float thr = 0.0f;
                 if (exact_cull) {
-                    thr = cull_threshold(op);
                     if (thr < 0.0f) {
-                        pv[v].x1 = pv[v].x0;  // never reaches 1/255 anywhere
+                        pv[v].x1 = pv[v].x0 = pv[v].y0 = pv[v].y1 = 0;  // never reaches 1/255 anywhere
                     } else {
                         const float hx = sqrtf(2.0f * thr * pv[v].cova) + 0.01f;
                         const float hy = sqrtf(2.0f * thr * pv[v].covc) + 0.01f;
@@ -213,15 +250,61 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 r4[0] = w0;
                 r4[1] = w1;
                 r4[2] = w2;
-                // per-workgroup LDS tile histogram (replaces tiles_touched + InclusiveSum).  The exact
-                // per-tile test only pays for rects with corners to cut (>= 2 x 2 tiles).
-                unsigned* h = lhist + v * tiles;
-                const bool per_tile = exact_cull && (pv[v].x1 - pv[v].x0) >= 2 && (pv[v].y1 - pv[v].y0) >= 2;
-                for (int ty = pv[v].y0; ty < pv[v].y1; ++ty)
-                    for (int tx = pv[v].x0; tx < pv[v].x1; ++tx)
-                        if (!per_tile || tile_may_contribute(pv[v].mx, pv[v].my, pv[v].ca, pv[v].cb, pv[v].cc, thr, tx, ty))
-                            atomicAdd(&h[ty * gx + tx], 1u);
             }
+        }
+        // ---- balanced (Gaussian, tile) expansion, one view at a time (wave collectives: every lane) ----
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
+            const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
+            const unsigned incl = wave_inclusive_scan(area);
+            const unsigned total = gs2m_shfl(incl, 63);
+            if (total == 0u) continue;  // wave-uniform
+            gs2m_wave_sync();
+            stage->mx[lane] = pv[v].mx;
+            stage->my[lane] = pv[v].my;
+            stage->ca[lane] = pv[v].ca;
+            stage->cb[lane] = pv[v].cb;
+            stage->cc[lane] = pv[v].cc;
+            stage->thr[lane] = thr;
+            stage->xy0[lane] = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
+            stage->wh[lane] = w | (h << 16);
+            stage->pref[lane] = incl;
+            stage->mlo[lane] = 0u;
+            stage->mhi[lane] = 0u;
+            gs2m_wave_sync();
+            unsigned* hh = lhist + v * tiles;
+            for (unsigned b0 = 0; b0 < total; b0 += 64u) {
+                const unsigned item = b0 + (unsigned)lane;
+                if (item < total) {
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; ++it) {
+                        const int mid = (lo + hi) >> 1;
+                        if (stage->pref[mid] > item) hi = mid;
+                        else lo = mid + 1;
+                    }
+                    const int o = lo;
+                    const unsigned wh = stage->wh[o];
+                    const unsigned ow = wh & 0xffffu, oh = wh >> 16;
+                    const unsigned li = item - (stage->pref[o] - ow * oh);
+                    const unsigned ry = li / ow, rx = li - ry * ow;
+                    const unsigned xy0 = stage->xy0[o];
+                    const int tx = (int)(xy0 & 0xffffu) + (int)rx, ty = (int)(xy0 >> 16) + (int)ry;
+                    bool keep = true;
+                    if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
+                        keep = tile_may_contribute(stage->mx[o], stage->my[o], stage->ca[o], stage->cb[o], stage->cc[o],
+                                                   stage->thr[o], tx, ty);
+                    if (keep) {
+                        atomicAdd(&hh[ty * gx + tx], 1u);
+                        if (li < 32u) atomicOr(&stage->mlo[o], 1u << li);
+                        else if (li < 64u) atomicOr(&stage->mhi[o], 1u << (li - 32u));
+                    }
+                }
+            }
+            gs2m_wave_sync();
+            if (area > 0u && area <= 64u)
+                tilemask[(size_t)v * g.P + gi] = (unsigned long long)stage->mlo[lane] | ((unsigned long long)stage->mhi[lane] << 32);
         }
     }
     __syncthreads();
@@ -234,12 +317,14 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
 // Instance scatter: same Gaussian -> workgroup assignment as k_project_count; cursors start at
 // tile_start[v][t] + (exclusive prefix over workgroups, left in `hist` by k_hist_colscan).
 // Key = depth_bits << 32 | gaussian_id (unique => order after the per-tile sort is deterministic
-// although LDS-atomic arrival order is not).
+// although LDS-atomic arrival order is not).  Rects of <= 64 tiles replay the tile mask written by
+// k_project_count; larger ones repeat the same per-tile test.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(256)
 k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
           const unsigned* __restrict__ hist, const unsigned* __restrict__ tile_start,
-          unsigned long long* __restrict__ keys, unsigned cap, int exact_cull) {
+          const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
+          int exact_cull) {
     GS2M_DYN_LDS(unsigned, cursor);
     const int tid = (int)threadIdx.x;
     const int gx = cams[0].gx, gy = cams[0].gy;
@@ -262,28 +347,38 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                 const int x0 = (int)(rect0 & 0xffffu), y0 = (int)(rect0 >> 16);
                 const int x1 = (int)(rect1 & 0xffffu), y1 = (int)(rect1 >> 16);
                 if (x1 <= x0 || y1 <= y0) continue;
-                float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
-                const bool per_tile = exact_cull && (x1 - x0) >= 2 && (y1 - y0) >= 2;  // as in k_project_count
-                if (per_tile) {
-                    const float4 w0 = r4[0];
-                    const float4 w1 = r4[1];
-                    mx = w0.x;
-                    my = w0.y;
-                    ca = w0.z;
-                    cb = w0.w;
-                    cc = w1.x;
-                    thr = cull_threshold(w1.y);
-                    if (thr < 0.0f) continue;
-                }
                 const unsigned long long hi = ((unsigned long long)__float_as_uint(w2.y)) << 32;
                 unsigned* cur = cursor + v * tiles;
                 unsigned long long* kv = keys + (size_t)v * cap;
-                for (int ty = y0; ty < y1; ++ty)
-                    for (int tx = x0; tx < x1; ++tx)
-                        if (!per_tile || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
-                            const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
-                            if (pos < cap) kv[pos] = hi | (unsigned)gi;
-                        }
+                const int w = x1 - x0, area = w * (y1 - y0);
+                if (area <= 64) {
+                    unsigned long long m = tilemask[(size_t)v * P + gi];
+                    while (m) {
+                        const int li = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1ull;
+                        const int ry = li / w, rx = li - ry * w;
+                        const unsigned pos = atomicAdd(&cur[(y0 + ry) * gx + x0 + rx], 1u);
+                        if (pos < cap) kv[pos] = hi | (unsigned)gi;
+                    }
+                } else {
+                    float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
+                    if (exact_cull) {
+                        const float4 w0 = r4[0];
+                        const float4 w1 = r4[1];
+                        mx = w0.x;
+                        my = w0.y;
+                        ca = w0.z;
+                        cb = w0.w;
+                        cc = w1.x;
+                        thr = cull_threshold(w1.y);
+                    }
+                    for (int ty = y0; ty < y1; ++ty)
+                        for (int tx = x0; tx < x1; ++tx)
+                            if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
+                                const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
+                                if (pos < cap) kv[pos] = hi | (unsigned)gi;
+                            }
+                }
             }
         }
     }

@@ -2,9 +2,13 @@
 #include "raster_project.h"
 #include "raster_internal.h"
 
+size_t gs2m_project_lds_bytes(int nv, int tiles) {
+    return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + GS2M_STAGE_BYTES;
+}
+
 int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
                               const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
-                              int exact_cull) {
+                              unsigned long long* tilemask, int exact_cull) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_project_count<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -17,16 +21,16 @@ int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st
     }
     if (nv == 2)
         GS2M_LAUNCH((k_project_count<2>), dim3(n_wg), dim3(256), lds_bytes, st, g, cams, chunk, n_wg, recs, radii,
-                    hist, exact_cull);
+                    hist, tilemask, exact_cull);
     else
         GS2M_LAUNCH((k_project_count<1>), dim3(n_wg), dim3(256), lds_bytes, st, g, cams, chunk, n_wg, recs, radii,
-                    hist, exact_cull);
+                    hist, tilemask, exact_cull);
     return 0;
 }
 
 int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
-                        unsigned long long* keys, unsigned cap, int exact_cull) {
+                        const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_scatter<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -39,10 +43,10 @@ int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, cons
     }
     if (nv == 2)
         GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(256), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
-                    tile_start, keys, cap, exact_cull);
+                    tile_start, tilemask, keys, cap, exact_cull);
     else
         GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(256), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
-                    tile_start, keys, cap, exact_cull);
+                    tile_start, tilemask, keys, cap, exact_cull);
     return 0;
 }
 

@@ -97,23 +97,34 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     }
 }
 
+// Bitonic network over s[0..npow2) in LDS, 256 threads.  Thread t owns compare-exchange pairs
+// p = t, t+256, ...; pair p of a stride-j stage is (i, i|j) with i = p with a 0 inserted at bit log2(j),
+// so every thread is busy in every stage.  A wave's 64 consecutive pairs live in one aligned block
+// of 128 elements whenever j <= 64: those stages (the first 28 of any sort, and the last 7 of every
+// merge phase) only need wave-level ordering; workgroup barriers remain for the j >= 128 stages only
+// (10 instead of 66 for 2048 keys).
 GS2M_DEVICE void bitonic_lds(unsigned long long* s, int npow2, int tid, int nthreads) {
+    const int half = npow2 >> 1;
+    bool prev_block_level = true;  // the load that filled s[] was a workgroup-level step
     for (int k = 2; k <= npow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow2; i += nthreads) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s[i], b = s[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        s[i] = b;
-                        s[ixj] = a;
-                    }
+            const bool block_level = j >= 128;
+            if (block_level || prev_block_level) __syncthreads();
+            else gs2m_wave_sync();
+            prev_block_level = block_level;
+            for (int p = tid; p < half; p += nthreads) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int x = i | j;
+                const unsigned long long a = s[i], b = s[x];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s[i] = b;
+                    s[x] = a;
                 }
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 // One workgroup per (tile, view).  n <= GS2M_SORT_LDS: bitonic in LDS.  Larger tiles: LDS-sorted
@@ -140,7 +151,6 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
         int np2 = 2;
         while (np2 < rn) np2 <<= 1;
         for (int i = tid; i < np2; i += 256) s[i] = i < rn ? kv[r0 + i] : ~0ull;
-        __syncthreads();
         bitonic_lds(s, np2, tid, 256);
         for (int i = tid; i < rn; i += 256) kv[r0 + i] = s[i];
         __syncthreads();

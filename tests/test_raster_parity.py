@@ -296,3 +296,41 @@ def test_blend_variants_match_the_oracle(backend, variant):
                        scales=d(ss), rotations=d(qq))
     ref_img, _, _ = oracle_forward(cam, xyz, oo, [0, 0, 0], colors_precomp=cols, scales=ss, rotations=qq)
     assert_image_close(be.host(img), ref_img)
+
+
+@pytest.mark.parametrize("cull", [0, 1])
+def test_huge_and_tiny_gaussians_mixed(backend, cull):
+    """Rect areas from 1 tile to the whole 13 x 9 tile grid in one wave: exercises the balanced tile
+    expansion, the <= 64-tile masks and the > 64-tile re-test path of the scatter."""
+    W, H, f = 200, 136, 180.0
+    rng = np.random.default_rng(77)
+    P = 600
+    xyz = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    s = np.exp(rng.normal(math.log(0.02), 0.5, (P, 3))).astype(np.float32)
+    big = rng.choice(P, 12, replace=False)
+    s[big] = rng.uniform(0.3, 1.5, (12, 3)).astype(np.float32)          # screen-filling, anisotropic
+    q = rng.normal(0, 1, (P, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    o = rng.uniform(0.01, 0.9, P).astype(np.float32)
+    o[big[:3]] = 0.003                                                   # below 1/255: never contributes
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    pose = synthetic.ring_pose(0.7, 3.5)
+    pose = np.concatenate([pose[0], pose[1][:, None]], axis=1)
+    cam, _ = synthetic.stereo_cameras(pose, W, H, f, f, 0.2)
+    be = backend
+    d = be.dev
+    r = Rasterizer(0, lib=be.lib)
+    r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+    r.set_option(_lib.OPT_BLEND_VARIANT, 2)
+    img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform),
+                           d(cam.camera_center), d(np.array([0.2, 0.1, 0.0], np.float32)), W, H, cam.tanfovx,
+                           cam.tanfovy, colors_precomp=d(cols), scales=d(s), rotations=d(q))
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0.2, 0.1, 0.0], colors_precomp=cols, scales=s,
+                                               rotations=q, exact_cull=bool(cull))
+    np.testing.assert_array_equal(be.host(radii), ref_radii)
+    if cull:
+        assert abs(r.last_num_rendered - ref_n) <= max(2, 2e-3 * ref_n)
+    else:
+        assert r.last_num_rendered == ref_n
+    assert ref_n > 2000
+    assert_image_close(be.host(img), ref_img)
