@@ -37,6 +37,8 @@ GS2M_DEVICE void gs2m_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// value known to be identical in all lanes -> SGPR (lets the compiler branch on the scalar unit)
+GS2M_DEVICE int gs2m_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 GS2M_DEVICE int gs2m_syncthreads_count(int pred) { return __syncthreads_count(pred); }
 
 // fast exp for the blend kernel: v_exp_f32(x * log2e) (documented tolerance in DESIGN.md)

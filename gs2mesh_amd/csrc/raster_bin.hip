@@ -11,5 +11,6 @@ void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, u
 }
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap) {
+    GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap);
     GS2M_LAUNCH(k_sort_tiles, dim3(tiles, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap);
 }

@@ -127,6 +127,77 @@ GS2M_DEVICE void bitonic_lds(unsigned long long* s, int npow2, int tid, int nthr
     __syncthreads();
 }
 
+// Small tiles (2 <= n <= GS2M_SORT_WAVE): ONE WAVE per (tile, view), 64-thread workgroups, 4 KiB of
+// LDS -> up to 32 resident waves per CU, and no workgroup barrier anywhere: the whole array belongs
+// to the wave.  NP2 is a template parameter so the pair loop unrolls and the LDS accesses of one
+// stage are issued back to back.
+#define GS2M_SORT_WAVE 512
+template <int NP2>
+GS2M_DEVICE void bitonic_wave(unsigned long long* s, int lane) {
+#pragma unroll 1
+    for (int k = 2; k <= NP2; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            gs2m_wave_sync();
+            constexpr int PAIRS = (NP2 / 2 + 63) / 64;
+            unsigned long long a[PAIRS], b[PAIRS];
+            int ia[PAIRS], ib[PAIRS];
+#pragma unroll
+            for (int m = 0; m < PAIRS; ++m) {
+                const int p = lane + 64 * m;
+                ia[m] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                ib[m] = ia[m] | j;
+                if (p < NP2 / 2) {
+                    a[m] = s[ia[m]];
+                    b[m] = s[ib[m]];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < PAIRS; ++m) {
+                const int p = lane + 64 * m;
+                if (p < NP2 / 2) {
+                    const bool up = (ia[m] & k) == 0;
+                    if ((a[m] > b[m]) == up) {
+                        s[ia[m]] = b[m];
+                        s[ib[m]] = a[m];
+                    }
+                }
+            }
+        }
+    }
+    gs2m_wave_sync();
+}
+
+GS2M_KERNEL void __launch_bounds__(64)
+k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
+                   unsigned cap) {
+    __shared__ unsigned long long s[GS2M_SORT_WAVE];
+    const int lane = (int)threadIdx.x;
+    const int t = (int)blockIdx.x, v = (int)blockIdx.y;
+    unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
+    unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
+    if (b > cap) b = cap;
+    if (e > cap) e = cap;
+    const int n = (int)(e - b);
+    if (n <= 1 || n > GS2M_SORT_WAVE) return;  // larger tiles: k_sort_tiles
+    unsigned long long* kv = keys + (size_t)v * cap + b;
+    int np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    for (int i = lane; i < np2; i += 64) s[i] = i < n ? kv[i] : ~0ull;
+    switch (np2) {
+        case 2: bitonic_wave<2>(s, lane); break;
+        case 4: bitonic_wave<4>(s, lane); break;
+        case 8: bitonic_wave<8>(s, lane); break;
+        case 16: bitonic_wave<16>(s, lane); break;
+        case 32: bitonic_wave<32>(s, lane); break;
+        case 64: bitonic_wave<64>(s, lane); break;
+        case 128: bitonic_wave<128>(s, lane); break;
+        case 256: bitonic_wave<256>(s, lane); break;
+        default: bitonic_wave<512>(s, lane); break;
+    }
+    for (int i = lane; i < n; i += 64) kv[i] = s[i];
+}
+
 // One workgroup per (tile, view).  n <= GS2M_SORT_LDS: bitonic in LDS.  Larger tiles: LDS-sorted
 // runs of GS2M_SORT_LDS, then rank-based merge passes through HBM (keys <-> tmp) by the same
 // workgroup (keys are unique, so rank = index in own run + lower_bound in the sibling run).
@@ -141,7 +212,7 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
     if (b > cap) b = cap;
     if (e > cap) e = cap;
     const int n = (int)(e - b);
-    if (n <= 1) return;  // uniform across the workgroup
+    if (n <= GS2M_SORT_WAVE) return;  // uniform across the workgroup; small tiles: k_sort_tiles_small
     unsigned long long* kv = keys + (size_t)v * cap + b;
     unsigned long long* tv = tmp + (size_t)v * cap + b;
     const int nruns = (n + GS2M_SORT_LDS - 1) / GS2M_SORT_LDS;

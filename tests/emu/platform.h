@@ -80,6 +80,7 @@ static inline void __threadfence_block() {}
 static inline int gs2m_syncthreads_count(int pred) { return ::emu::sync_count(pred); }
 static inline unsigned long long gs2m_ballot(int pred) { return ::emu::ballot(pred); }
 static inline void gs2m_wave_sync() { (void)::emu::ballot(0); }
+static inline int gs2m_uniform(int v) { return v; }
 static inline int gs2m_lane() { return ::emu::lane(); }
 static inline int gs2m_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 template <typename T>
