@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cull", type=int, default=int(os.environ.get("GS2M_BENCH_CULL", "1")),
                     help="exact tile culling (image-preserving); 0 = reference instance lists")
-    ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "0")))
+    ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "3")))
     ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "reduce_scatter"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

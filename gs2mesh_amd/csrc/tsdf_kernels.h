@@ -71,10 +71,18 @@ GS2M_DEVICE int tsdf_lookup(const TsdfVolume& V, unsigned long long key) {
     return -1;
 }
 
+// One thread per (strided pixel, block offset): the +-trunc box of a point spans at most
+// `span` = floor(2 trunc / L) + 2 blocks per axis, so thread idx handles point idx / span^3 and the
+// block lo + offset(idx % span^3) if it lies inside the point's [lo, hi] box.  Every thread runs one
+// short hash probe (2-3 dependent loads) instead of one thread walking 27 of them back to back.
 GS2M_KERNEL void __launch_bounds__(256)
-k_tsdf_touch(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const unsigned char* __restrict__ mask) {
-    const int idx = (int)(blockIdx.x * 256u + threadIdx.x);
+k_tsdf_touch(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const unsigned char* __restrict__ mask,
+             int span) {
+    const int span3 = span * span * span;
+    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int idx = (int)(gidx / span3);
     if (idx >= f.nx * f.ny) return;
+    const int off = (int)(gidx - (long long)idx * span3);
     const int i = (idx / f.nx) * f.stride;  // row
     const int j = (idx % f.nx) * f.stride;  // column
     const float p = tsdf_fetch_depth(depth, mask, f, j, i);
@@ -91,24 +99,25 @@ k_tsdf_touch(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const u
         lo[r] = (int)floor((pw - f.sdf_trunc) / f.unit_length);
         hi[r] = (int)floor((pw + f.sdf_trunc) / f.unit_length);
     }
-    for (int bx = lo[0]; bx <= hi[0]; ++bx)
-        for (int by = lo[1]; by <= hi[1]; ++by)
-            for (int bz = lo[2]; bz <= hi[2]; ++bz) {
-                if (!tsdf_key_in_range(bx, by, bz)) {
-                    atomicOr(&V.counters[2], 4u);
-                    continue;
-                }
-                const unsigned h = tsdf_find_or_insert(V, tsdf_pack_key(bx, by, bz), bx, by, bz);
-                if (h == 0xffffffffu) continue;
-                // first touch in this frame? (touched_volume_units_ of upstream)
-                if (V.stamp[h] == f.frame_id) continue;  // plain read: a stale miss only costs an atomic
-                if (atomicExch(&V.stamp[h], f.frame_id) != f.frame_id) {
-                    const unsigned t = atomicAdd(&V.counters[1], 1u);
-                    V.touched[t] = h;
-                }
-            }
+    const int bx = lo[0] + off / (span * span), by = lo[1] + (off / span) % span, bz = lo[2] + off % span;
+    if (bx > hi[0] || by > hi[1] || bz > hi[2]) return;
+    if (!tsdf_key_in_range(bx, by, bz)) {
+        atomicOr(&V.counters[2], 4u);
+        return;
+    }
+    const unsigned h = tsdf_find_or_insert(V, tsdf_pack_key(bx, by, bz), bx, by, bz);
+    if (h == 0xffffffffu) return;
+    // first touch in this frame? (touched_volume_units_ of upstream)
+    if (V.stamp[h] == f.frame_id) return;  // plain read: a stale miss only costs an atomic
+    if (atomicExch(&V.stamp[h], f.frame_id) != f.frame_id) {
+        const unsigned t = atomicAdd(&V.counters[1], 1u);
+        V.touched[t] = h;
+    }
 }
 
+// One 256-thread workgroup per touched block; thread (x,y) walks z.  The 16 z steps are processed in
+// two groups of 8 with all projections first, then all depth gathers, then all state loads, then the
+// stores: ~4 dependent memory round trips per group instead of 2 per voxel.
 GS2M_KERNEL void __launch_bounds__(256)
 k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const unsigned char* __restrict__ color,
                  const unsigned char* __restrict__ mask) {
@@ -133,32 +142,82 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
         float* bt = V.tsdf + (size_t)slot * GS2M_TSDF_VOX;
         float* bw = V.weight + (size_t)slot * GS2M_TSDF_VOX;
         unsigned* bc = V.rgb + (size_t)slot * 3 * GS2M_TSDF_VOX;
-        for (int z = 0; z < GS2M_TSDF_RES; ++z, pc0 += f.Es02, pc1 += f.Es12, pc2 += f.Es22) {
-            if (pc2 <= 0) continue;
-            const float u_f = pc0 * f.fx_f / pc2 + f.cx_f + 0.5f;
-            const float v_f = pc1 * f.fy_f / pc2 + f.cy_f + 0.5f;
-            if (!(u_f >= 0.0001f && u_f < f.safe_w && v_f >= 0.0001f && v_f < f.safe_h)) continue;
-            const int u = (int)u_f;
-            const int v = (int)v_f;
-            const float d = tsdf_fetch_depth(depth, mask, f, u, v);
-            if (d <= 0.0f) continue;
-            // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated on the fly
-            const float xx = (u - f.cx_f) * f.fx_inv_f;
-            const float yy = (v - f.cy_f) * f.fy_inv_f;
-            const float mult = sqrtf(xx * xx + yy * yy + 1.0f);
-            const float sdf = (d - pc2) * mult;
-            if (sdf > -f.sdf_trunc_f) {
-                const float tnew = fminf(1.0f, sdf * f.sdf_trunc_inv_f);
-                const int vi = z * 256 + tid;
-                const float w = bw[vi];
-                bt[vi] = (bt[vi] * w + tnew) / (w + 1.0f);
-                if (V.has_color) {
-                    const unsigned char* c = color + 3 * ((size_t)v * f.W + u);
-                    bc[vi] += c[0];
-                    bc[GS2M_TSDF_VOX + vi] += c[1];
-                    bc[2 * GS2M_TSDF_VOX + vi] += c[2];
+#pragma unroll 1
+        for (int zg = 0; zg < GS2M_TSDF_RES; zg += 8) {
+            int pix[8];      // pixel index or -1
+            float zc[8], mult[8], d[8], tnew[8];
+            // (a) projections: pure ALU, same incremental fp32 chain as upstream
+#pragma unroll
+            for (int k = 0; k < 8; ++k, pc0 += f.Es02, pc1 += f.Es12, pc2 += f.Es22) {
+                pix[k] = -1;
+                zc[k] = pc2;
+                mult[k] = 0.0f;
+                if (pc2 <= 0) continue;
+                const float u_f = pc0 * f.fx_f / pc2 + f.cx_f + 0.5f;
+                const float v_f = pc1 * f.fy_f / pc2 + f.cy_f + 0.5f;
+                if (!(u_f >= 0.0001f && u_f < f.safe_w && v_f >= 0.0001f && v_f < f.safe_h)) continue;
+                const int u = (int)u_f;
+                const int v = (int)v_f;
+                pix[k] = v * f.W + u;
+                // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated on the fly
+                const float xx = (u - f.cx_f) * f.fx_inv_f;
+                const float yy = (v - f.cy_f) * f.fy_inv_f;
+                mult[k] = sqrtf(xx * xx + yy * yy + 1.0f);
+            }
+            // (b) depth gathers, back to back
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                d[k] = 0.0f;
+                if (pix[k] >= 0) {
+                    float dd = depth[pix[k]];
+                    if (f.use_mask && mask[pix[k]] == 0) dd = dd * 0.0f;
+                    if (f.use_min && dd < f.min_depth_f) dd = 0.0f;
+                    dd /= f.depth_scale_f;
+                    if ((double)dd >= f.depth_trunc) dd = 0.0f;
+                    d[k] = dd;
                 }
-                bw[vi] = w + 1.0f;
+            }
+            // (c) decide
+            bool upd[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float sdf = (d[k] - zc[k]) * mult[k];
+                upd[k] = pix[k] >= 0 && d[k] > 0.0f && sdf > -f.sdf_trunc_f;
+                tnew[k] = fminf(1.0f, sdf * f.sdf_trunc_inv_f);
+            }
+            // (d) state loads
+            float w[8], t[8];
+            unsigned c0[8], c1[8], c2[8], r[8], g[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (upd[k]) {
+                    const int vi = (zg + k) * 256 + tid;
+                    w[k] = bw[vi];
+                    t[k] = bt[vi];
+                    if (V.has_color) {
+                        c0[k] = bc[vi];
+                        c1[k] = bc[GS2M_TSDF_VOX + vi];
+                        c2[k] = bc[2 * GS2M_TSDF_VOX + vi];
+                        const unsigned char* c = color + 3 * (size_t)pix[k];
+                        r[k] = c[0];
+                        g[k] = c[1];
+                        b[k] = c[2];
+                    }
+                }
+            }
+            // (e) update + stores
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (upd[k]) {
+                    const int vi = (zg + k) * 256 + tid;
+                    bt[vi] = (t[k] * w[k] + tnew[k]) / (w[k] + 1.0f);
+                    if (V.has_color) {
+                        bc[vi] = c0[k] + r[k];
+                        bc[GS2M_TSDF_VOX + vi] = c1[k] + g[k];
+                        bc[2 * GS2M_TSDF_VOX + vi] = c2[k] + b[k];
+                    }
+                    bw[vi] = w[k] + 1.0f;
+                }
             }
         }
     }

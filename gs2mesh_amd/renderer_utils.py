@@ -30,6 +30,7 @@ from .gaussian_model import GaussianModel, read_gaussian_ply
 from .graphics import Camera
 from .poses import (RT_from_rot_pos, calculate_right_camera_pose, convert_R_T_to_GS, eul2rotm,
                     intrinsic_from_camera_params, rotm2eul)
+from . import _lib
 from .rasterizer import Rasterizer, camera_from
 
 
@@ -157,6 +158,7 @@ class Renderer:
         self.background = torch.tensor(bg, dtype=torch.float32, device=dev)
         self._bg_host = tuple(float(b) for b in bg)
         self._raster = Rasterizer(torch.device(dev).index or 0)
+        self._raster.set_option(_lib.OPT_EXACT_TILE_CULL, 1)      # image-preserving; fewer instances to sort/blend
         self._views = {}
 
     def _pair(self, camera_number):

@@ -55,8 +55,10 @@ enum {
                                      (DGR/cuda_rasterizer/auxiliary.h:46-56), 1 = also drop
                                      (Gaussian,tile) instances whose alpha < 1/255 on the
                                      whole tile (image unchanged, num_rendered smaller)   */
-    GS2M_OPT_BLEND_VARIANT = 2,   /* 0 = 16x16 tile per 256-thread workgroup,
-                                     1 = one wave per 16x16 tile, 4 pixels per lane       */
+    GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 0 = 16x16 tile per 256-thread workgroup
+                                     (1 px/lane); 1 = one wave per tile, 4 px/lane; 2 = 1 with
+                                     the alpha pre-filter; 3 (default) = 2 with the quadrant
+                                     layout + per-instance quadrant mask.  Same image.       */
     GS2M_OPT_DEBUG_SYNC = 3,      /* 1 = synchronise + check after every launch (the
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4     /* 1 = bracket every stage launch with hipEvents on the
