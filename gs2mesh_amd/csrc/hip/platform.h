@@ -37,6 +37,19 @@ GS2M_DEVICE void gs2m_wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// Loads that bypass the (non-coherent) per-CU L1: see the latest value another CU published with an
+// atomic (guide: relaxed agent-scope load = global_load sc1).
+GS2M_DEVICE unsigned gs2m_load_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+GS2M_DEVICE unsigned long long gs2m_load_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 4 bytes at an arbitrary byte address (gfx9+ global loads need no alignment)
+GS2M_DEVICE unsigned gs2m_load_u32_unaligned(const unsigned char* p) {
+    typedef unsigned __attribute__((aligned(1))) u32_u;
+    return *reinterpret_cast<const u32_u*>(p);
+}
 // value known to be identical in all lanes -> SGPR (lets the compiler branch on the scalar unit)
 GS2M_DEVICE int gs2m_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 GS2M_DEVICE int gs2m_syncthreads_count(int pred) { return __syncthreads_count(pred); }

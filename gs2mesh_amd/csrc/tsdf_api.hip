@@ -259,7 +259,7 @@ extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8
         (void)hipEventRecord(e2, st);
     }
     // persistent grid: enough workgroups to fill the chip; each loops over the touched list
-    gs2m_launch_tsdf_integrate(st, t->n_cu * 8, t->V, f, depth, color, mask);
+    gs2m_launch_tsdf_integrate(st, t->n_cu * 7, t->V, f, depth, color, mask);
     if (tm) {
         (void)hipEventRecord(e3, st);
         t->ev_live.push_back({0, e0, e1});
@@ -339,14 +339,14 @@ extern "C" int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, i
     const size_t nv = (size_t)n * GS2M_TSDF_VOX;
     if (keys) HIPCHK(hipMemcpy(keys, t->V.block_keys, sizeof(int) * 3 * (size_t)n, hipMemcpyDeviceToHost));
     std::vector<float> tmp;
-    // device layout z*256 + x*16 + y  ->  Open3D IndexOf x*256 + y*16 + z
+    // device layout (4x4x4 micro-blocks, tsdf_common.h)  ->  Open3D IndexOf x*256 + y*16 + z
     auto reorder_f = [&](const float* src, float* dst) {
         for (int64_t b = 0; b < n; ++b)
             for (int z = 0; z < 16; ++z)
                 for (int x = 0; x < 16; ++x)
                     for (int y = 0; y < 16; ++y)
                         dst[(size_t)b * GS2M_TSDF_VOX + x * 256 + y * 16 + z] =
-                            src[(size_t)b * GS2M_TSDF_VOX + z * 256 + x * 16 + y];
+                            src[(size_t)b * GS2M_TSDF_VOX + GS2M_TSDF_VINDEX(x, y, z)];
     };
     if (tsdf) {
         tmp.resize(nv);
@@ -370,7 +370,7 @@ extern "C" int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, i
                         for (int x = 0; x < 16; ++x)
                             for (int y = 0; y < 16; ++y)
                                 rgb_sum[((size_t)b * GS2M_TSDF_VOX + x * 256 + y * 16 + z) * 3 + ch] =
-                                    c[((size_t)b * 3 + ch) * GS2M_TSDF_VOX + z * 256 + x * 16 + y];
+                                    c[((size_t)b * 3 + ch) * GS2M_TSDF_VOX + GS2M_TSDF_VINDEX(x, y, z)];
         }
     }
     return 0;

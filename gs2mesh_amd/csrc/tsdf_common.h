@@ -7,8 +7,11 @@
 //   * per voxel: tsdf f32 (running mean, same fp32 update as upstream), weight f32, and the colour
 //     as an exact integer SUM of the u8 samples (3 x u32; upstream keeps a float64 running mean --
 //     mean = sum / weight);
-//   * SoA, block-major, and inside a block z-major: voxel (x,y,z) at z*256 + x*16 + y, so that the
-//     256 threads (x,y) of a workgroup read/write 1 KiB contiguous per z step.
+//   * SoA, block-major; inside a block the 4096 voxels are stored as 64 micro-blocks of 4x4x4:
+//     voxel (x,y,z) at ((z>>2)*16 + (x>>2)*4 + (y>>2))*64 + (z&3)*16 + (x&3)*4 + (y&3).  A wave owns
+//     one micro-block per step: its 64 state words are 256 contiguous bytes (one coalesced access per
+//     array) AND its 64 voxel centres project into a ~14x14-pixel patch, so the depth / colour gathers
+//     touch ~4x fewer cache lines than a 4x16 slice of a z-plane would.
 #pragma once
 #include "platform.h"
 
@@ -47,6 +50,9 @@ struct TsdfFrame {  // per-frame uniforms, passed by value in the launch packet
     unsigned frame_id;
     int use_mask, use_min;
 };
+
+// device-internal voxel index (see header); host code uses the same formula in gs2m_tsdf_download
+#define GS2M_TSDF_VINDEX(x, y, z) (((((z) >> 2) * 16 + ((x) >> 2) * 4 + ((y) >> 2)) * 64) + ((z)&3) * 16 + ((x)&3) * 4 + ((y)&3))
 
 GS2M_DEVICE unsigned long long tsdf_pack_key(int bx, int by, int bz) {
     return ((unsigned long long)(unsigned)(bx + GS2M_TSDF_KEY_BIAS) << 42) |

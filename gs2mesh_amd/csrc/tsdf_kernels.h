@@ -71,84 +71,202 @@ GS2M_DEVICE int tsdf_lookup(const TsdfVolume& V, unsigned long long key) {
     return -1;
 }
 
-// One thread per (strided pixel, block offset): the +-trunc box of a point spans at most
-// `span` = floor(2 trunc / L) + 2 blocks per axis, so thread idx handles point idx / span^3 and the
-// block lo + offset(idx % span^3) if it lies inside the point's [lo, hi] box.  Every thread runs one
-// short hash probe (2-3 dependent loads) instead of one thread walking 27 of them back to back.
+// k_tsdf_touch: one thread per strided pixel back-projects its point (fp64, as upstream) and gets the
+// block box [lo, hi] of its +-trunc cube (up to 27 blocks with the reference defaults).  Neighbouring
+// pixels share almost all of those blocks -- a frame marks ~2 k distinct blocks out of ~3 M
+// (point, block) pairs -- and every hash probe is a random L2 request, so the pairs are deduplicated
+// per wave first: the 64 boxes go to LDS, the wave takes the union box, lane l tests candidate
+// block base + l of the union against the 64 boxes (LDS broadcast reads) and only then probes the
+// hash table.  ~50x fewer probes / stamp atomics than one probe per (point, block).
+struct TouchStage {
+    int lo[3][64];
+    int hi[3][64];
+};
+
+GS2M_DEVICE int wave_min_i(int v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const int o = gs2m_shfl_xor(v, m);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+GS2M_DEVICE int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const int o = gs2m_shfl_xor(v, m);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 GS2M_KERNEL void __launch_bounds__(256)
-k_tsdf_touch(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const unsigned char* __restrict__ mask,
-             int span) {
-    const int span3 = span * span * span;
-    const long long gidx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int idx = (int)(gidx / span3);
-    if (idx >= f.nx * f.ny) return;
-    const int off = (int)(gidx - (long long)idx * span3);
-    const int i = (idx / f.nx) * f.stride;  // row
-    const int j = (idx % f.nx) * f.stride;  // column
-    const float p = tsdf_fetch_depth(depth, mask, f, j, i);
-    if (!(p > 0.0f)) return;
-    // PointCloudFactory.cpp CreatePointCloudFromFloatDepthImage (fp64)
-    const double z = (double)p;
-    const double x = (j - f.cx) * z / f.fx;
-    const double y = (i - f.cy) * z / f.fy;
-    int lo[3], hi[3];
+k_tsdf_touch(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const unsigned char* __restrict__ mask) {
+    __shared__ TouchStage stage_all[4];
+    const int lane = (int)(threadIdx.x & 63u);
+    TouchStage* stg = &stage_all[threadIdx.x >> 6];
+    const int idx = (int)(blockIdx.x * 256u + threadIdx.x);
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    bool valid = false;
+    if (idx < f.nx * f.ny) {
+        const int i = (idx / f.nx) * f.stride;  // row
+        const int j = (idx % f.nx) * f.stride;  // column
+        const float p = tsdf_fetch_depth(depth, mask, f, j, i);
+        if (p > 0.0f) {
+            valid = true;
+            // PointCloudFactory.cpp CreatePointCloudFromFloatDepthImage (fp64)
+            const double z = (double)p;
+            const double x = (j - f.cx) * z / f.fx;
+            const double y = (i - f.cy) * z / f.fy;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double pw = f.pose[4 * r + 0] * x + f.pose[4 * r + 1] * y + f.pose[4 * r + 2] * z + f.pose[4 * r + 3] * 1.0;
+                // ScalableTSDFVolume::LocateVolumeUnit: floor(p / volume_unit_length)
+                lo[r] = (int)floor((pw - f.sdf_trunc) / f.unit_length);
+                hi[r] = (int)floor((pw + f.sdf_trunc) / f.unit_length);
+            }
+        }
+    }
+    if (gs2m_ballot(valid ? 1 : 0) == 0ull) return;  // wave-uniform
+    int wlo[3], whi[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        const double pw = f.pose[4 * r + 0] * x + f.pose[4 * r + 1] * y + f.pose[4 * r + 2] * z + f.pose[4 * r + 3] * 1.0;
-        // ScalableTSDFVolume::LocateVolumeUnit: floor(p / volume_unit_length)
-        lo[r] = (int)floor((pw - f.sdf_trunc) / f.unit_length);
-        hi[r] = (int)floor((pw + f.sdf_trunc) / f.unit_length);
+        stg->lo[r][lane] = lo[r];
+        stg->hi[r][lane] = hi[r];
+        wlo[r] = wave_min_i(lo[r]);
+        whi[r] = wave_max_i(hi[r]);
     }
-    const int bx = lo[0] + off / (span * span), by = lo[1] + (off / span) % span, bz = lo[2] + off % span;
-    if (bx > hi[0] || by > hi[1] || bz > hi[2]) return;
-    if (!tsdf_key_in_range(bx, by, bz)) {
-        atomicOr(&V.counters[2], 4u);
+    gs2m_wave_sync();
+    const long long total_ll = ((long long)whi[0] - wlo[0] + 1) * ((long long)whi[1] - wlo[1] + 1) *
+                               ((long long)whi[2] - wlo[2] + 1);
+    if (total_ll > (1ll << 24)) {  // a wave spanning > 16 M blocks: not a depth map of this volume
+        if (lane == 0) atomicOr(&V.counters[2], 4u);
         return;
     }
-    const unsigned h = tsdf_find_or_insert(V, tsdf_pack_key(bx, by, bz), bx, by, bz);
-    if (h == 0xffffffffu) return;
-    // first touch in this frame? (touched_volume_units_ of upstream)
-    if (V.stamp[h] == f.frame_id) return;  // plain read: a stale miss only costs an atomic
-    if (atomicExch(&V.stamp[h], f.frame_id) != f.frame_id) {
-        const unsigned t = atomicAdd(&V.counters[1], 1u);
-        V.touched[t] = h;
+    const int ny = whi[1] - wlo[1] + 1, nz = whi[2] - wlo[2] + 1;
+    const int nyz = ny * nz;
+    const int total = (int)total_ll;
+    for (int base = 0; base < total; base += 64) {
+        const int c = base + lane;
+        if (c >= total) continue;
+        const int cx = c / nyz, rem = c - cx * nyz;
+        const int cy = rem / nz;
+        const int bx = wlo[0] + cx, by = wlo[1] + cy, bz = wlo[2] + (rem - cy * nz);
+        // containment in ANY lane's box: branch-free so the 384 broadcast LDS reads pipeline
+        int in_any = 0;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k)
+            in_any |= (int)(bx >= stg->lo[0][k]) & (int)(bx <= stg->hi[0][k]) & (int)(by >= stg->lo[1][k]) &
+                      (int)(by <= stg->hi[1][k]) & (int)(bz >= stg->lo[2][k]) & (int)(bz <= stg->hi[2][k]);
+        const bool inside = in_any != 0;
+        if (!inside) continue;
+        if (!tsdf_key_in_range(bx, by, bz)) {
+            atomicOr(&V.counters[2], 4u);
+            continue;
+        }
+        const unsigned h = tsdf_find_or_insert(V, tsdf_pack_key(bx, by, bz), bx, by, bz);
+        if (h == 0xffffffffu) continue;
+        // mark "touched in this frame" (touched_volume_units_ of upstream).  No list append here: ~2 k
+        // returning atomics on ONE counter serialise at ~12 ns each (guide: fanin); k_tsdf_compact builds
+        // the list with one atomic per 1024 hash cells instead.
+        if (V.stamp[h] != f.frame_id) V.stamp[h] = f.frame_id;
     }
 }
 
-// One 256-thread workgroup per touched block; thread (x,y) walks z.  The 16 z steps are processed in
-// two groups of 8 with all projections first, then all depth gathers, then all state loads, then the
-// stores: ~4 dependent memory round trips per group instead of 2 per voxel.
+// Compacts the hash cells stamped in this frame into V.touched (order = hash order).
+GS2M_KERNEL void __launch_bounds__(1024)
+k_tsdf_compact(TsdfVolume V, unsigned frame_id) {
+    __shared__ unsigned wave_cnt[16];
+    __shared__ unsigned wg_base;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned h = blockIdx.x * 1024u + (unsigned)tid;
+    const bool t = h < V.hash_cap && V.stamp[h] == frame_id;
+    const unsigned long long m = gs2m_ballot(t ? 1 : 0);
+    if (lane == 0) wave_cnt[wave] = (unsigned)gs2m_popc64(m);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned s = 0;
+        for (int k = 0; k < 16; ++k) {
+            const unsigned c = wave_cnt[k];
+            wave_cnt[k] = s;
+            s += c;
+        }
+        wg_base = s ? atomicAdd(&V.counters[1], s) : 0u;
+    }
+    __syncthreads();
+    if (t) {
+        const unsigned rank = (unsigned)gs2m_popc64(m & ((1ull << lane) - 1ull));
+        V.touched[wg_base + wave_cnt[wave] + rank] = h;
+    }
+}
+
+// k_tsdf_integrate: one 256-thread workgroup per touched block (grid-stride over the device-side
+// list).  Wave w, lane l sweep the block's 64 micro-blocks of 4x4x4 voxels (tsdf_common.h), four
+// micro-blocks in flight per wave: all projections first (pure ALU), then all depth gathers, then all
+// state loads + colour gathers, then the stores = ~4 dependent memory round trips per 4 micro-blocks.
+// The camera-space point of a voxel is advanced along z by repeated fp32 addition exactly as upstream
+// does (rounding accumulates along z), so a lane replays the z steps below its voxel.
 GS2M_KERNEL void __launch_bounds__(256)
 k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, const unsigned char* __restrict__ color,
                  const unsigned char* __restrict__ mask) {
+    __shared__ float s_p0[16], s_p1[16];
     const int tid = (int)threadIdx.x;
-    const int x = tid >> 4, y = tid & 15;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lz = lane >> 4, lx = (lane >> 2) & 3, ly = lane & 3;
     const unsigned n_touched = V.counters[1];
+    const int last_pix = f.W * f.H - 1;
     for (unsigned it = blockIdx.x; it < n_touched; it += gridDim.x) {
         const unsigned h = V.touched[it];
+        // block index from the hash key itself (no dependent block_keys load); slot in parallel
+        const unsigned long long key = V.hash_keys[h];
         const int slot = V.hash_vals[h];
-        if (slot < 0) continue;  // pool overflow (flagged)
-        const int bx = V.block_keys[3 * (size_t)slot], by = V.block_keys[3 * (size_t)slot + 1],
-                  bz = V.block_keys[3 * (size_t)slot + 2];
+        if (slot < 0) continue;  // pool overflow (flagged); uniform across the workgroup
+        const int bx = (int)((key >> 42) & 0x1fffffull) - GS2M_TSDF_KEY_BIAS;
+        const int by = (int)((key >> 21) & 0x1fffffull) - GS2M_TSDF_KEY_BIAS;
+        const int bz = (int)(key & 0x1fffffull) - GS2M_TSDF_KEY_BIAS;
         // OpenVolumeUnit: origin = index.cast<double>() * volume_unit_length
         const double ox = (double)bx * f.unit_length, oy = (double)by * f.unit_length, oz = (double)bz * f.unit_length;
-        // UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier
-        const float p0 = (float)(f.half_voxel_length_f + f.voxel_length_f * x + ox);
-        const float p1 = (float)(f.half_voxel_length_f + f.voxel_length_f * y + oy);
         const float p2 = (float)(f.half_voxel_length_f + oz);
-        float pc0 = f.E[0] * p0 + f.E[1] * p1 + f.E[2] * p2 + f.E[3] * 1.f;
-        float pc1 = f.E[4] * p0 + f.E[5] * p1 + f.E[6] * p2 + f.E[7] * 1.f;
-        float pc2 = f.E[8] * p0 + f.E[9] * p1 + f.E[10] * p2 + f.E[11] * 1.f;
+        // voxel-centre coordinates of the 16 x / y indices, once per block (fp64 add + casts as upstream:
+        // float(half + vl*i + origin)), shared through LDS
+        __syncthreads();  // previous block's readers are done
+        if (tid < 16) s_p0[tid] = (float)(f.half_voxel_length_f + f.voxel_length_f * tid + ox);
+        else if (tid < 32) s_p1[tid - 16] = (float)(f.half_voxel_length_f + f.voxel_length_f * (tid - 16) + oy);
+        __syncthreads();
         float* bt = V.tsdf + (size_t)slot * GS2M_TSDF_VOX;
         float* bw = V.weight + (size_t)slot * GS2M_TSDF_VOX;
         unsigned* bc = V.rgb + (size_t)slot * 3 * GS2M_TSDF_VOX;
 #pragma unroll 1
-        for (int zg = 0; zg < GS2M_TSDF_RES; zg += 8) {
-            int pix[8];      // pixel index or -1
-            float zc[8], mult[8], d[8], tnew[8];
-            // (a) projections: pure ALU, same incremental fp32 chain as upstream
+        for (int g = 0; g < 4; ++g) {
+            int pix[4], vi[4];
+            float zc[4], mult[4], d[4], tnew[4];
+            // (a) projections.  g is the micro-block z index for all four k: mb = g*16 + wave*4 + k
+            const int z0 = g * 4;
 #pragma unroll
-            for (int k = 0; k < 8; ++k, pc0 += f.Es02, pc1 += f.Es12, pc2 += f.Es22) {
+            for (int k = 0; k < 4; ++k) {
+                const int mb = g * 16 + wave * 4 + k;  // micro-block (mz = g, mx = wave, my = k)
+                const int x = wave * 4 + lx, y = k * 4 + ly;
+                vi[k] = mb * 64 + lane;
+                // UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier
+                const float p0 = s_p0[x];
+                const float p1 = s_p1[y];
+                float pc0 = f.E[0] * p0 + f.E[1] * p1 + f.E[2] * p2 + f.E[3] * 1.f;
+                float pc1 = f.E[4] * p0 + f.E[5] * p1 + f.E[6] * p2 + f.E[7] * 1.f;
+                float pc2 = f.E[8] * p0 + f.E[9] * p1 + f.E[10] * p2 + f.E[11] * 1.f;
+                // replay the z steps below this voxel: z0 wave-uniform steps, then lz (0..3) of its own
+                for (int s = 0; s < z0; ++s) {
+                    pc0 += f.Es02;
+                    pc1 += f.Es12;
+                    pc2 += f.Es22;
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    if (s < lz) {
+                        pc0 += f.Es02;
+                        pc1 += f.Es12;
+                        pc2 += f.Es22;
+                    }
+                }
                 pix[k] = -1;
                 zc[k] = pc2;
                 mult[k] = 0.0f;
@@ -166,7 +284,7 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
             }
             // (b) depth gathers, back to back
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 d[k] = 0.0f;
                 if (pix[k] >= 0) {
                     float dd = depth[pix[k]];
@@ -178,45 +296,44 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
                 }
             }
             // (c) decide
-            bool upd[8];
+            bool upd[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 const float sdf = (d[k] - zc[k]) * mult[k];
                 upd[k] = pix[k] >= 0 && d[k] > 0.0f && sdf > -f.sdf_trunc_f;
                 tnew[k] = fminf(1.0f, sdf * f.sdf_trunc_inv_f);
             }
-            // (d) state loads
-            float w[8], t[8];
-            unsigned c0[8], c1[8], c2[8], r[8], g[8], b[8];
+            // (d) state loads + colour gathers
+            float w[4], t[4];
+            unsigned c0[4], c1[4], c2[4], rgbp[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 if (upd[k]) {
-                    const int vi = (zg + k) * 256 + tid;
-                    w[k] = bw[vi];
-                    t[k] = bt[vi];
+                    w[k] = bw[vi[k]];
+                    t[k] = bt[vi[k]];
                     if (V.has_color) {
-                        c0[k] = bc[vi];
-                        c1[k] = bc[GS2M_TSDF_VOX + vi];
-                        c2[k] = bc[2 * GS2M_TSDF_VOX + vi];
+                        c0[k] = bc[vi[k]];
+                        c1[k] = bc[GS2M_TSDF_VOX + vi[k]];
+                        c2[k] = bc[2 * GS2M_TSDF_VOX + vi[k]];
+                        // r | g<<8 | b<<16 in ONE gather (the 4th byte belongs to the next pixel; the last pixel of
+                        // the image is read bytewise so that nothing past the buffer is touched)
                         const unsigned char* c = color + 3 * (size_t)pix[k];
-                        r[k] = c[0];
-                        g[k] = c[1];
-                        b[k] = c[2];
+                        rgbp[k] = pix[k] < last_pix ? gs2m_load_u32_unaligned(c)
+                                                    : ((unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16));
                     }
                 }
             }
             // (e) update + stores
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 if (upd[k]) {
-                    const int vi = (zg + k) * 256 + tid;
-                    bt[vi] = (t[k] * w[k] + tnew[k]) / (w[k] + 1.0f);
+                    bt[vi[k]] = (t[k] * w[k] + tnew[k]) / (w[k] + 1.0f);
                     if (V.has_color) {
-                        bc[vi] = c0[k] + r[k];
-                        bc[GS2M_TSDF_VOX + vi] = c1[k] + g[k];
-                        bc[2 * GS2M_TSDF_VOX + vi] = c2[k] + b[k];
+                        bc[vi[k]] = c0[k] + (rgbp[k] & 0xffu);
+                        bc[GS2M_TSDF_VOX + vi[k]] = c1[k] + ((rgbp[k] >> 8) & 0xffu);
+                        bc[2 * GS2M_TSDF_VOX + vi[k]] = c2[k] + ((rgbp[k] >> 16) & 0xffu);
                     }
-                    bw[vi] = w[k] + 1.0f;
+                    bw[vi[k]] = w[k] + 1.0f;
                 }
             }
         }

@@ -5,11 +5,9 @@
 
 void gs2m_launch_tsdf_touch(hipStream_t st, const TsdfVolume& V, const TsdfFrame& f, const float* depth,
                             const unsigned char* mask) {
-    // blocks per axis the +-trunc box of a point can span
-    int span = (int)floor(2.0 * f.sdf_trunc / f.unit_length) + 2;
-    if (span < 2) span = 2;
-    const long long n = (long long)f.nx * f.ny * span * span * span;
-    GS2M_LAUNCH(k_tsdf_touch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, V, f, depth, mask, span);
+    const int n = f.nx * f.ny;
+    GS2M_LAUNCH(k_tsdf_touch, dim3((n + 255) / 256), dim3(256), 0, st, V, f, depth, mask);
+    GS2M_LAUNCH(k_tsdf_compact, dim3((V.hash_cap + 1023u) / 1024u), dim3(1024), 0, st, V, f.frame_id);
 }
 void gs2m_launch_tsdf_integrate(hipStream_t st, int n_wg, const TsdfVolume& V, const TsdfFrame& f,
                                 const float* depth, const unsigned char* color, const unsigned char* mask) {

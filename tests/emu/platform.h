@@ -81,6 +81,9 @@ static inline int gs2m_syncthreads_count(int pred) { return ::emu::sync_count(pr
 static inline unsigned long long gs2m_ballot(int pred) { return ::emu::ballot(pred); }
 static inline void gs2m_wave_sync() { (void)::emu::ballot(0); }
 static inline int gs2m_uniform(int v) { return v; }
+static inline unsigned gs2m_load_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+static inline unsigned long long gs2m_load_agent(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+static inline unsigned gs2m_load_u32_unaligned(const unsigned char* p) { unsigned v; memcpy(&v, p, 4); return v; }
 static inline int gs2m_lane() { return ::emu::lane(); }
 static inline int gs2m_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 template <typename T>
