@@ -442,8 +442,6 @@ k_blend_wave4q(const unsigned long long* __restrict__ keys, const unsigned* __re
         const bool live = pyf[0] < 1.0e17f || pyf[1] < 1.0e17f || pyf[2] < 1.0e17f || pyf[3] < 1.0e17f;
         if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
         gs2m_wave_sync();
-        s_a[wave][lane] = ra;
-        s_b[wave][lane] = rb;
         {
             // per-instance constants, computed once by the staging lane
             const float lim = -gs2m_fast_log(rb.y * 255.0f) - 1.0e-4f;   // alpha >= 1/255 <=> power >= lim
@@ -469,6 +467,13 @@ k_blend_wave4q(const unsigned long long* __restrict__ keys, const unsigned* __re
             cl.z = __uint_as_float(m);
             cl.w = 0.0f;
             s_c[wave][lane] = cl;
+            // conic pre-scaled by -0.5 (exact: power of two), so that
+            // power = -0.5*(a dx^2 + c dy^2) - b dx dy = (a' dx^2 + c' dy^2) - b dx dy bit for bit
+            float4 sa = ra, sb = rb;
+            sa.z = -0.5f * ra.z;
+            sb.x = -0.5f * rb.x;
+            s_a[wave][lane] = sa;
+            s_b[wave][lane] = sb;
         }
         gs2m_wave_sync();
         const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
@@ -493,7 +498,7 @@ k_blend_wave4q(const unsigned long long* __restrict__ keys, const unsigned* __re
             for (int k = 0; k < 4; ++k) {
                 if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
                     const float dy = A.y - pyf[k];
-                    const float power = -0.5f * (adx2[k & 1] + B.x * dy * dy) - bdx[k & 1] * dy;
+                    const float power = (adx2[k & 1] + B.x * dy * dy) - bdx[k & 1] * dy;
                     const bool cand = power >= CL.y && !(power > 0.0f);
                     if (gs2m_ballot(cand ? 1 : 0) != 0ull) {
                         const float alpha = fminf(0.99f, B.y * gs2m_fast_exp(power));

@@ -1,0 +1,125 @@
+"""BASELINE.json full-size configurations on the real GPU: direct oracle comparison where the CPU
+oracle finishes in seconds (one C2 eye, three C2 TSDF frames), size-independent properties elsewhere
+(determinism, image invariance under exact culling / kernel variant, view-order invariance)."""
+import numpy as np
+import pytest
+
+import oracle
+from gs2mesh_amd import _lib, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cfg_name, n_pairs=1):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+    cfg = synthetic.CONFIGS[cfg_name]
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    gd["raw"] = True
+    poses = synthetic.ring_poses(n_pairs, cfg.ring_radius, 0, cfg.n_pairs)
+    cams = [synthetic.stereo_cameras(p, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline) for p in poses]
+    return cfg, g, gd, poses, cams, Rasterizer, camera_from
+
+
+def test_c2_stereo_pair_vs_oracle_and_invariants():
+    cfg, g, gd, poses, cams, Rasterizer, camera_from = _setup("C2")
+    left, right = cams[0]
+    pair = [camera_from(left), camera_from(right)]
+    R = Rasterizer(0)
+    a = R.render_views(gd, pair, want_rgb8=True, want_radii=True)
+    n_ref_mode = list(a["num_rendered"])
+    img = a["color"].cpu().numpy()
+    # determinism (race-freedom): a second run is bitwise identical
+    b = R.render_views(gd, pair, want_rgb8=True)
+    assert np.array_equal(b["color"].cpu().numpy(), img) and np.array_equal(b["rgb8"].cpu().numpy(), a["rgb8"].cpu().numpy())
+    # exact culling: same image, fewer instances
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+    c = R.render_views(gd, pair)
+    assert np.array_equal(c["color"].cpu().numpy(), img)
+    assert max(c["num_rendered"]) < 0.8 * max(n_ref_mode)
+    # every compositing kernel variant agrees to rounding
+    for variant in (0, 1, 2):
+        R.set_option(_lib.OPT_BLEND_VARIANT, variant)
+        d = R.render_views(gd, pair)["color"].cpu().numpy()
+        diff = np.abs(d - img)
+        assert (diff > 1e-5).mean() < 1e-4 and diff.max() < 6e-3, variant
+    # u8 hand-off image = cv2's conversion of the float image
+    q8 = np.clip(np.rint(img.transpose(0, 2, 3, 1) * 255.0), 0, 255).astype(np.uint8)
+    assert np.array_equal(a["rgb8"].cpu().numpy(), q8)
+    # left eye against the CPU oracle at full size (~seconds)
+    s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
+    shs = np.concatenate([g["features_dc"], g["features_rest"]], axis=1)
+    ref, ref_radii, ref_n = oracle.rasterize_forward(g["xyz"], o, left.world_view_transform, left.full_proj_transform,
+                                                     left.camera_center, cfg.width, cfg.height, left.tanfovx,
+                                                     left.tanfovy, np.zeros(3, np.float32), shs=shs, scales=s, rotations=q)
+    radii = a["radii"].cpu().numpy()[0]
+    assert (radii != ref_radii).mean() < 2e-3
+    assert abs(n_ref_mode[0] - ref_n) < 2e-3 * ref_n
+    diff = np.abs(img[0] - ref)
+    assert (diff > 2e-5).mean() < 2e-3 and diff.max() < 2e-2
+    mse = float((diff.astype(np.float64) ** 2).mean())
+    psnr = 20 * np.log10(1.0 / np.sqrt(mse)) if mse > 0 else np.inf      # GS/utils/image_utils.py:17-19
+    assert psnr > 80.0, psnr
+
+
+def test_c3_two_million_gaussians_invariants():
+    cfg, g, gd, poses, cams, Rasterizer, camera_from = _setup("C3")
+    pair = [camera_from(cams[0][0]), camera_from(cams[0][1])]
+    R = Rasterizer(0)
+    a = R.render_views(gd, pair)
+    img = a["color"].cpu().numpy()
+    assert np.isfinite(img).all() and 4e6 < min(a["num_rendered"]) and img.mean() > 0.05
+    assert np.array_equal(R.render_views(gd, pair)["color"].cpu().numpy(), img)
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+    assert np.array_equal(R.render_views(gd, pair)["color"].cpu().numpy(), img)
+
+
+def test_c2_tsdf_frames_vs_oracle_and_order_invariance():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+    cfg = synthetic.CONFIGS["C2"]
+    W, H, f = cfg.width, cfg.height, cfg.focal
+    poses = synthetic.ring_poses(3, cfg.ring_radius, 0, cfg.n_pairs)
+    col = synthetic.color_pattern(W, H)
+    intr = PinholeCameraIntrinsic(W, H, f, f, W / 2.0, H / 2.0)
+    trunc, mind = cfg.baseline * 20, cfg.baseline * 4
+    frames = []
+    for p in poses:
+        E = np.eye(4)
+        E[:3] = p
+        frames.append((synthetic.sphere_depth(p, W, H, f, f, W / 2.0, H / 2.0, cfg.sphere_radius), E))
+
+    def fuse(order):
+        vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=8192)
+        for k in order:
+            d, E = frames[k]
+            vol.integrate(RGBDImage(col, d, depth_scale=1.0, depth_trunc=trunc), intr, E, min_depth=mind)
+        return vol.download(), vol.status()[1]
+
+    (keys, tsdf, weight, rgb), updates = fuse([0, 1, 2])
+    ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
+    ref.set_threads(16)
+    n_ref = 0
+    for d, E in frames:
+        dd = np.where(d < np.float32(mind), 0, d).astype(np.float32)
+        n_ref += ref.integrate(oracle.ScalableTSDFVolume.convert_depth(dd, 1.0, trunc), col, W, H, f, f, W / 2.0, H / 2.0, E)
+    assert updates == n_ref and n_ref > 4000
+    rk, rt, rw, rc = ref.export()
+    got = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    assert set(got) == set(map(tuple, rk.tolist()))
+    order = np.array([got[tuple(k)] for k in rk.tolist()])
+    assert np.array_equal(weight[order], rw)
+    assert np.array_equal(tsdf[order], rt)                                   # bit-exact running mean
+    mean = rgb[order].astype(np.float64) / np.maximum(weight[order], 1)[..., None]
+    assert np.abs(mean - rc).max() < 1e-9
+    # view order only reassociates the fp32 running mean
+    (k2, t2, w2, c2), _ = fuse([2, 0, 1])
+    i2 = {tuple(k): i for i, k in enumerate(k2.tolist())}
+    o2 = np.array([i2[tuple(k)] for k in keys.tolist()])
+    assert np.array_equal(w2[o2], weight) and np.array_equal(c2[o2], rgb)
+    assert np.abs(t2[o2] - tsdf).max() < 1e-6

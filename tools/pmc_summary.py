@@ -1,0 +1,43 @@
+"""Summarise a tools/profile_round.sh output directory into profiles/:
+   <tag>_kernel_stats.csv (rocprofv3 --stats), <tag>_pmc.json (per-kernel averages of every counter) and
+   profiles/pmc_traffic.json (HBM bytes per launch, read by bench.py for roofline.traffic).
+HBM bytes follow the guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+reports half of a wide coalesced read stream, so reads are doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+import collections, csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+cfg = sys.argv[2] if len(sys.argv) > 2 else "C2"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, f"{tag}_bench_{cfg}_kernel_stats.csv"))
+for name in ("bench.json", "stats_bench.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in glob.glob(os.path.join(src, "pmc_*")):
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if k.startswith("k_")}
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+stage_of = {"k_project_count<2>": "project_count", "k_hist_colscan": "hist_colscan", "k_tile_scan": "tile_scan",
+            "k_scatter<2>": "scatter", "k_sort_tiles_small": "sort_tiles", "k_tsdf_touch": "tsdf_touch",
+            "k_tsdf_integrate": "tsdf_integrate"}
+bench = json.load(open(os.path.join(src, "bench.json"))) if os.path.exists(os.path.join(src, "bench.json")) else {}
+traffic = {}
+for k, cs in summary.items():
+    stage = stage_of.get(k, "blend" if k.startswith("k_blend") else None)
+    if stage and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+                              fetch_kib=cs["FETCH_SIZE"], write_kib=cs["WRITE_SIZE"],
+                              cull=bench.get("config", {}).get("exact_tile_cull", 1), source=f"profiles/{tag}_pmc.json")
+tp = os.path.join(dst, "pmc_traffic.json")
+allt = json.load(open(tp)) if os.path.exists(tp) else {}
+allt[cfg] = traffic
+json.dump(allt, open(tp, "w"), indent=1, sort_keys=True)
+print(json.dumps(traffic, indent=1))
