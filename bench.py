@@ -90,6 +90,7 @@ def main():
     R = Rasterizer(local_rank)
     R.set_option(_lib.OPT_EXACT_TILE_CULL, args.cull)
     R.set_option(_lib.OPT_BLEND_VARIANT, args.blend)
+    R.pack_sh(gd)      # one-time SH re-layout (prepare_renderer stage, outside the timed region)
     vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=n_blocks_dense, device=local_rank)
     color = torch.empty((2, 3, Ht, Wd), dtype=torch.float32, device=dev)
     rgb8 = torch.empty((2, Ht, Wd, 3), dtype=torch.uint8, device=dev)

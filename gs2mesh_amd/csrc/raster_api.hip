@@ -2,6 +2,7 @@
 // stage sequencing.  Host code only; kernels live in raster_{project,bin,blend}.hip.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -47,6 +48,11 @@ struct gs2m_raster {
     GeomRec* d_recs = nullptr;
     size_t recs_cap = 0;  // records
     unsigned long long* d_tilemask = nullptr;
+    float* d_shpack = nullptr;   // wave-transposed SH copy of the Gaussians last passed to gs2m_raster_pack_sh
+    size_t shpack_cap = 0;
+    const float* pack_src = nullptr;
+    const float* pack_src_rest = nullptr;
+    int pack_P = 0;
     size_t mask_cap = 0;
     unsigned* d_hist = nullptr;
     size_t hist_cap = 0;  // words
@@ -103,6 +109,7 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     (void)hipFree(r->d_cams);
     (void)hipFree(r->d_recs);
     (void)hipFree(r->d_tilemask);
+    (void)hipFree(r->d_shpack);
     (void)hipFree(r->d_hist);
     (void)hipFree(r->d_tile_count);
     (void)hipFree(r->d_tile_start);
@@ -135,7 +142,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
 
 static void geometry(int P, int* chunk, int* n_wg) {
     // ~512 workgroups (2 per CU), chunks a multiple of 256 Gaussians
-    int c = (P + 511) / 512;
+    static int target = 0;
+    if (!target) {
+        const char* e = getenv("GS2M_NWG_TARGET");  // tuning knob
+        target = e ? atoi(e) : 512;
+        if (target < 1) target = 512;
+    }
+    int c = (P + target - 1) / target;
     c = (c + 255) / 256 * 256;
     if (c < 256) c = 256;
     *chunk = c;
@@ -331,6 +344,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     g.opac = opacities;
     g.shs = shs;
     g.shs_rest = nullptr;
+    g.shs_packed = nullptr;
     g.cov3D_precomp = cov3D_precomp;
     g.colors_precomp = colors_precomp;
     g.P = P;
@@ -404,6 +418,8 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     g.opac = gs->opacities;
     g.shs = gs->shs;
     g.shs_rest = gs->shs_rest;
+    g.shs_packed = (r->pack_src == gs->shs && r->pack_src_rest == gs->shs_rest && r->pack_P == gs->P && gs->M == 16)
+                       ? r->d_shpack : nullptr;
     g.cov3D_precomp = nullptr;
     g.colors_precomp = nullptr;
     g.P = gs->P;
@@ -443,6 +459,25 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
             return 1;
     }
     HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * n_views, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+extern "C" int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* gs, gs2m_stream stream) {
+    if (!r || !gs) {
+        gs2m_set_error("gs2m_raster_pack_sh: NULL argument");
+        return 1;
+    }
+    r->pack_src = nullptr;
+    r->pack_src_rest = nullptr;
+    r->pack_P = 0;
+    if (gs->P <= 0 || gs->M != 16 || !gs->shs) return 0;  // nothing to pack: the kernels read the caller's layout
+    HIPCHK(hipSetDevice(r->device));
+    const size_t groups = ((size_t)gs->P + 63) / 64;
+    if (ensure(&r->d_shpack, &r->shpack_cap, groups * 12 * 64 * 4)) return 1;
+    gs2m_launch_pack_sh((hipStream_t)stream, gs->P, gs->shs, gs->shs_rest, r->d_shpack);
+    r->pack_src = gs->shs;
+    r->pack_src_rest = gs->shs_rest;
+    r->pack_P = gs->P;
     return 0;
 }
 

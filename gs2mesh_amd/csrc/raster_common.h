@@ -38,6 +38,7 @@ struct GaussIn {
     const float* opac;            // [P]   (logit if raw)
     const float* shs;             // [P,M,3], or features_dc [P,1,3] when shs_rest != null
     const float* shs_rest;        // null or features_rest [P,M-1,3]
+    const float* shs_packed;      // null or wave-transposed SH [ceil(P/64)][12][64] float4 (M = 16 only)
     const float* cov3D_precomp;   // null or [P,6]
     const float* colors_precomp;  // null or [P,3]
     int P, D, M, raw;

@@ -14,6 +14,7 @@ size_t gs2m_project_lds_bytes(int nv, int tiles);
 int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull);
+void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed);
 void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,
                               unsigned char* present);
 void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,

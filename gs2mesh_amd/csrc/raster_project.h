@@ -152,7 +152,20 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
             float sh[48];
             const bool need_sh = any && (g.colors_precomp == nullptr);
             if (need_sh) {
-                if (g.shs_rest == nullptr && g.M == 16) {
+                if (g.shs_packed) {
+                    // wave-transposed copy (k_pack_sh): float4 k of 64 consecutive Gaussians is 1 KiB contiguous
+                    const float4* s4 = reinterpret_cast<const float4*>(g.shs_packed) + (size_t)(gi >> 6) * (12 * 64) + (gi & 63);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) {
+                        if (k * 4 < ncoef * 3) {
+                            const float4 t = s4[k * 64];
+                            sh[4 * k] = t.x;
+                            sh[4 * k + 1] = t.y;
+                            sh[4 * k + 2] = t.z;
+                            sh[4 * k + 3] = t.w;
+                        }
+                    }
+                } else if (g.shs_rest == nullptr && g.M == 16) {
                     // 192-B row, 16-B aligned: 12 x dwordx4
                     const float4* s4 = reinterpret_cast<const float4*>(g.shs + 48 * (size_t)gi);
 #pragma unroll
@@ -382,6 +395,24 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
             }
         }
     }
+}
+
+// One-time re-layout of the SH block for the pipeline-level path (Renderer.prepare_renderer): the
+// reference layout is one 192-B row per Gaussian ([P,16,3], or dc [P,1,3] + rest [P,15,3]), which a
+// thread-per-Gaussian kernel reads as 12 float4 loads strided by 192 B (64 cache lines per wave
+// instruction, L1 thrash).  Packed: [P/64][12][64] float4 -- every load instruction of a wave is one
+// contiguous KiB.
+GS2M_KERNEL void __launch_bounds__(256)
+k_pack_sh(int P, const float* __restrict__ shs, const float* __restrict__ shs_rest, float* __restrict__ packed) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float of the [P,48] matrix
+    if (i >= (size_t)P * 48) return;
+    const size_t gi = i / 48;
+    const int c = (int)(i - gi * 48);
+    float v;
+    if (shs_rest == nullptr) v = shs[i];
+    else v = c < 3 ? shs[gi * 3 + c] : shs_rest[gi * 45 + (c - 3)];
+    const int k = c >> 2, e = c & 3;
+    packed[(((gi >> 6) * 12 + k) * 64 + (gi & 63)) * 4 + e] = v;
 }
 
 // checkFrustum (rasterizer_impl.cu:54-66): present = z_view > 0.2

@@ -50,6 +50,11 @@ int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, cons
     return 0;
 }
 
+void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed) {
+    const size_t n = (size_t)P * 48;
+    GS2M_LAUNCH(k_pack_sh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, shs, shs_rest, packed);
+}
+
 void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,
                               unsigned char* present) {
     GS2M_LAUNCH(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, st, P, xyz, viewmatrix, present);

@@ -97,34 +97,67 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     }
 }
 
-// Bitonic network over s[0..npow2) in LDS, 256 threads.  Thread t owns compare-exchange pairs
+// Bitonic network over s[0..NP2) in LDS, 256 threads.  Thread t owns compare-exchange pairs
 // p = t, t+256, ...; pair p of a stride-j stage is (i, i|j) with i = p with a 0 inserted at bit log2(j),
 // so every thread is busy in every stage.  A wave's 64 consecutive pairs live in one aligned block
 // of 128 elements whenever j <= 64: those stages (the first 28 of any sort, and the last 7 of every
 // merge phase) only need wave-level ordering; workgroup barriers remain for the j >= 128 stages only
-// (10 instead of 66 for 2048 keys).
-GS2M_DEVICE void bitonic_lds(unsigned long long* s, int npow2, int tid, int nthreads) {
-    const int half = npow2 >> 1;
+// (10 instead of 66 for 2048 keys).  NP2 is a template parameter: the pair loop unrolls and the LDS
+// reads of a stage are issued back to back.
+template <int NP2>
+GS2M_DEVICE void bitonic_lds(unsigned long long* s, int tid) {
+    constexpr int PAIRS = (NP2 / 2 + 255) / 256;
     bool prev_block_level = true;  // the load that filled s[] was a workgroup-level step
-    for (int k = 2; k <= npow2; k <<= 1) {
+#pragma unroll 1
+    for (int k = 2; k <= NP2; k <<= 1) {
+#pragma unroll 1
         for (int j = k >> 1; j > 0; j >>= 1) {
             const bool block_level = j >= 128;
             if (block_level || prev_block_level) __syncthreads();
             else gs2m_wave_sync();
             prev_block_level = block_level;
-            for (int p = tid; p < half; p += nthreads) {
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                const int x = i | j;
-                const unsigned long long a = s[i], b = s[x];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    s[i] = b;
-                    s[x] = a;
+            unsigned long long a[PAIRS], b[PAIRS];
+            int ia[PAIRS], ib[PAIRS];
+#pragma unroll
+            for (int m = 0; m < PAIRS; ++m) {
+                const int p = tid + 256 * m;
+                ia[m] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                ib[m] = ia[m] | j;
+                if (p < NP2 / 2) {
+                    a[m] = s[ia[m]];
+                    b[m] = s[ib[m]];
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < PAIRS; ++m) {
+                const int p = tid + 256 * m;
+                if (p < NP2 / 2) {
+                    const bool up = (ia[m] & k) == 0;
+                    if ((a[m] > b[m]) == up) {
+                        s[ia[m]] = b[m];
+                        s[ib[m]] = a[m];
+                    }
                 }
             }
         }
     }
     __syncthreads();
+}
+GS2M_DEVICE void bitonic_lds_dispatch(unsigned long long* s, int np2, int tid) {
+    switch (np2) {
+        case 2: bitonic_lds<2>(s, tid); break;
+        case 4: bitonic_lds<4>(s, tid); break;
+        case 8: bitonic_lds<8>(s, tid); break;
+        case 16: bitonic_lds<16>(s, tid); break;
+        case 32: bitonic_lds<32>(s, tid); break;
+        case 64: bitonic_lds<64>(s, tid); break;
+        case 128: bitonic_lds<128>(s, tid); break;
+        case 256: bitonic_lds<256>(s, tid); break;
+        case 512: bitonic_lds<512>(s, tid); break;
+        case 1024: bitonic_lds<1024>(s, tid); break;
+        case 2048: bitonic_lds<2048>(s, tid); break;
+        default: bitonic_lds<4096>(s, tid); break;
+    }
 }
 
 // Small tiles (2 <= n <= GS2M_SORT_WAVE): ONE WAVE per (tile, view), 64-thread workgroups, 4 KiB of
@@ -222,7 +255,7 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
         int np2 = 2;
         while (np2 < rn) np2 <<= 1;
         for (int i = tid; i < np2; i += 256) s[i] = i < rn ? kv[r0 + i] : ~0ull;
-        bitonic_lds(s, np2, tid, 256);
+        bitonic_lds_dispatch(s, np2, tid);
         for (int i = tid; i < rn; i += 256) kv[r0 + i] = s[i];
         __syncthreads();
     }

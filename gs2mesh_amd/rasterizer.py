@@ -184,18 +184,10 @@ class Rasterizer:
         return present
 
     # -- pipeline level -------------------------------------------------------------------------
-    def render_views(self, gaussians: dict, cams, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, want_color=True,
-                     want_rgb8=False, want_radii=False, out_color=None, out_rgb8=None, stream=None, sync=True):
-        """``gs2m_render_views``.  ``gaussians``: dict with xyz[P,3], scaling[P,3], rotation[P,4],
-        opacity[P,1|P], and either features[P,M,3] or features_dc[P,1,3] + features_rest[P,M-1,3];
-        ``raw`` (default True) = pre-activation GaussianModel parameters; ``sh_degree`` (default 3).
-        ``cams``: list of ``_lib.Camera``.  Returns dict(color, rgb8, radii, num_rendered)."""
+    def _gaussians_struct(self, gaussians: dict):
         xyz = gaussians["xyz"]
-        P = int(xyz.shape[0])
-        n = len(cams)
-        W, H = cams[0].width, cams[0].height
         g = _lib.Gaussians()
-        g.P = P
+        g.P = int(xyz.shape[0])
         g.sh_degree = int(gaussians.get("sh_degree", 3))
         g.raw = int(bool(gaussians.get("raw", True)))
         f32 = torch.float32 if _is_torch(xyz) else None
@@ -211,6 +203,25 @@ class Rasterizer:
             g.shs = _ptr(gaussians["features_dc"], f32, "features_dc")
             g.shs_rest = _ptr(gaussians["features_rest"], f32, "features_rest")
             g.M = 1 + int(gaussians["features_rest"].shape[1])
+        return g
+
+    def pack_sh(self, gaussians: dict, stream=None):
+        """One-time preparation (``gs2m_raster_pack_sh``): cache a wave-transposed copy of the SH block of
+        these Gaussians in the handle; ``render_views`` with the same tensors then reads it."""
+        g = self._gaussians_struct(gaussians)
+        _lib.check(self._lib.gs2m_raster_pack_sh(self._h, C.byref(g), _stream_of(gaussians["xyz"], stream)), self._lib)
+
+    def render_views(self, gaussians: dict, cams, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, want_color=True,
+                     want_rgb8=False, want_radii=False, out_color=None, out_rgb8=None, stream=None, sync=True):
+        """``gs2m_render_views``.  ``gaussians``: dict with xyz[P,3], scaling[P,3], rotation[P,4],
+        opacity[P,1|P], and either features[P,M,3] or features_dc[P,1,3] + features_rest[P,M-1,3];
+        ``raw`` (default True) = pre-activation GaussianModel parameters; ``sh_degree`` (default 3).
+        ``cams``: list of ``_lib.Camera``.  Returns dict(color, rgb8, radii, num_rendered)."""
+        xyz = gaussians["xyz"]
+        P = int(xyz.shape[0])
+        n = len(cams)
+        W, H = cams[0].width, cams[0].height
+        g = self._gaussians_struct(gaussians)
         cam_arr = (_lib.Camera * n)(*cams)
         bg_arr = (C.c_float * 3)(*[float(b) for b in bg])
         if want_color and out_color is None:

@@ -167,6 +167,15 @@ int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* g, const gs2m_camera
                       int n_views, const float* bg /* host[3] */, float scale_modifier,
                       float* out_color, uint8_t* out_rgb8, int* out_radii, gs2m_stream stream);
 
+/*
+ * Optional one-time preparation for gs2m_render_views (Renderer.prepare_renderer stage): keeps a
+ * wave-transposed copy of the SH block ([P/64][12][64] float4, +192 B per Gaussian) inside the handle.
+ * Later gs2m_render_views calls whose gs->shs / shs_rest / P match read that copy with fully
+ * coalesced loads; the caller's arrays must not change in between (call again after an update;
+ * a call with P == 0 or M != 16 just drops the copy).  Same results either way.
+ */
+int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* g, gs2m_stream stream);
+
 /* Synchronises `stream` and reports, for the last forward/render_views call on the
  * handle: num_rendered[v] for v < n_views (host array, may be NULL) and whether the
  * instance arena overflowed (*overflow = 1: results invalid, *required = instances

@@ -334,3 +334,29 @@ def test_huge_and_tiny_gaussians_mixed(backend, cull):
         assert r.last_num_rendered == ref_n
     assert ref_n > 2000
     assert_image_close(be.host(img), ref_img)
+
+
+def test_packed_sh_layout_gives_identical_results(backend):
+    """gs2m_raster_pack_sh (one-time wave-transposed SH copy) must not change a bit of the output,
+    for both source layouts (concatenated features, dc + rest) and a P that is not a multiple of 64."""
+    W, H, f = 160, 120, 150.0
+    g, s, q, o, shs, left, right = scene(2500 + 37, 23, W, H, f)
+    be = backend
+    cams = [camera_from(left), camera_from(right)]
+    base = dict(xyz=be.dev(g["xyz"]), scaling=be.dev(g["scaling"]), rotation=be.dev(g["rotation"]),
+                opacity=be.dev(g["opacity"]), raw=True, sh_degree=3)
+    for layout in ("split", "cat"):
+        gd = dict(base)
+        if layout == "split":
+            gd["features_dc"], gd["features_rest"] = be.dev(g["features_dc"]), be.dev(g["features_rest"])
+        else:
+            gd["features"] = be.dev(shs)
+        r = Rasterizer(0, lib=be.lib)
+        a = be.host(r.render_views(gd, cams, want_radii=True)["color"]).copy()
+        r.pack_sh(gd)
+        res = r.render_views(gd, cams, want_radii=True)
+        np.testing.assert_array_equal(be.host(res["color"]), a)
+        geom = r.download_geometry(1, 2537)
+        r2 = Rasterizer(0, lib=be.lib)
+        r2.render_views(gd, cams)
+        np.testing.assert_array_equal(geom["rgb"], r2.download_geometry(1, 2537)["rgb"])

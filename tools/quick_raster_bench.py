@@ -14,10 +14,24 @@ ap.add_argument("--config", default="C2")
 ap.add_argument("--pairs", type=int, default=8)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--cull", type=int, default=0)
-ap.add_argument("--blend", type=int, default=0)
+ap.add_argument("--blend", type=int, default=3)
+ap.add_argument("--morton", type=int, default=0)
+ap.add_argument("--stages", type=int, default=1)
+ap.add_argument("--pack", type=int, default=1)
 a = ap.parse_args()
 cfg = synthetic.CONFIGS[a.config]
 g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+if a.morton:
+    q = np.clip(((g["xyz"] + 1.0) * 0.5 * 1023).astype(np.int64), 0, 1023)
+    def spread(x):
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        x = (x | (x << 2)) & 0x09249249
+        return x
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    perm = np.argsort(code, kind="stable")
+    g = {k: np.ascontiguousarray(v[perm]) for k, v in g.items()}
 gd = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
 gd["raw"] = True
 poses = synthetic.ring_poses(a.pairs, cfg.ring_radius, 0, cfg.n_pairs)
@@ -28,6 +42,8 @@ for p in poses:
 R = Rasterizer(0)
 R.set_option(_lib.OPT_EXACT_TILE_CULL, a.cull)
 R.set_option(_lib.OPT_BLEND_VARIANT, a.blend)
+if a.pack:
+    R.pack_sh(gd)
 out = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
 res = R.render_views(gd, cams[0], out_color=out)
 print("num_rendered", res["num_rendered"], "mean", float(out.mean()))
@@ -39,5 +55,11 @@ for it in range(a.iters):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nr, ov, req = R.status(2)
+    if a.stages and it == a.iters - 1:
+        R.set_option(_lib.OPT_STAGE_TIMING, 1)
+        for c in cams:
+            R.render_views(gd, c, out_color=out, sync=False)
+        print({k: round(1e3 * ms / max(n, 1), 1) for k, (ms, n) in R.stage_times().items()})
+        R.set_option(_lib.OPT_STAGE_TIMING, 0)
     print(json.dumps(dict(config=a.config, cull=a.cull, blend=a.blend, pairs_per_s=len(cams) / dt,
                           ms_per_pair=1e3 * dt / len(cams), overflow=ov, num_rendered=nr)))
