@@ -25,6 +25,7 @@ SOURCES = [
     ("raster_api.hip", []),
     ("tsdf_kernels.hip", ["-ffp-contract=off"]),
     ("tsdf_api.hip", []),
+    ("stereo_kernels.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.join(CSRC, "hip"), "-I", CSRC,
           "-Wall", "-Wno-unused-function"]

@@ -271,6 +271,22 @@ int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, fl
 int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
                      const float* weight, const uint32_t* rgb_sum, gs2m_stream stream);
 
+/* ------------------------------------------------------------------------------------ */
+/* stereo post-processing (between the stereo network and the TSDF)                     */
+/* ------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces Stereo.get_occlusion_mask(disparity_LR, disparity_RL, stereo_occlusion_threshold) and
+ * depth = fx * baseline / disparity_LR (gs2mesh_utils/stereo_utils.py:132-133,149-179), fused.
+ *   disp_lr, disp_rl  [H,W] f32 device (disp_rl may be NULL when mask_out is NULL)
+ *   depth_out         [H,W] f32 device or NULL
+ *   mask_out          [H,W] u8 device or NULL: 1 = visible (the reference returns ~occlusion_mask)
+ * The outputs are the `depth` / `mask` inputs of gs2m_tsdf_integrate.  Asynchronous.
+ */
+int gs2m_stereo_depth_occlusion(const float* disp_lr, const float* disp_rl, int width, int height,
+                                double fx_times_baseline, double occlusion_threshold, float* depth_out,
+                                uint8_t* mask_out, gs2m_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, "gs2mesh_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libgs2mesh_emu.so")
 SRCS = ["raster_project.hip", "raster_bin.hip", "raster_blend.hip", "raster_api.hip", "tsdf_kernels.hip",
-        "tsdf_api.hip"]
+        "tsdf_api.hip", "stereo_kernels.hip"]
 
 
 def build(force=False):

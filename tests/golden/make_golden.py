@@ -134,6 +134,24 @@ def main():
             acc[f"center_{eye}"].append(center.numpy())
         acc["proj"].append(proj.numpy())
     np.savez_compressed(os.path.join(OUT, "stereo_cameras.npz"), **rec, **{k: np.stack(v) for k, v in acc.items()})
+    # ---- 5. left-right consistency mask: execute the reference's OWN function body ----------------
+    # Stereo.get_occlusion_mask (gs2mesh_utils/stereo_utils.py:149-179) is pure numpy but lives in a module
+    # that imports DLNR / cv2; the function is lifted out of the file with ast and compiled on its own.
+    import ast
+    src = open(os.path.join(REF, "gs2mesh_utils", "stereo_utils.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "get_occlusion_mask")
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "stereo_utils.py", "exec"), ns)
+    H2, W2 = 96, 160
+    xs = np.arange(W2)[None, :].repeat(H2, 0)
+    true_disp = (18.0 + 10.0 * np.sin(xs / 23.0) + rng.normal(0, 0.05, (H2, W2))).astype(np.float32)
+    L2R = true_disp.copy()
+    R2L = (np.roll(true_disp, -18, axis=1) + rng.normal(0, 0.4, (H2, W2))).astype(np.float32)
+    L2R[10:30, 40:70] += 9.0            # inconsistent patch -> occluded
+    L2R[:, :12] = 30.0                  # projects left of the image -> occluded
+    L2R[50:60, 100:120] = -400.0        # projects right of the image
+    masks = {f"mask_thr{t}": ns["get_occlusion_mask"](None, L2R, R2L, t) for t in (1, 3)}
+    np.savez_compressed(os.path.join(OUT, "occlusion_mask.npz"), L2R=L2R, R2L=R2L, **masks)
     print("golden fixtures written to", OUT)
 
 
