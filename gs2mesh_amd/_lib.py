@@ -55,6 +55,8 @@ _PROTOS = {
     "gs2m_raster_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
     "gs2m_raster_download_geometry": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "gs2m_raster_download_binning": (i32, [vp, vp, i32, i64, vp, C.c_int32, vp]),
+    "gs2m_tsdf_extract_count": (i32, [vp, vp, C.POINTER(i64)]),
+    "gs2m_tsdf_extract": (i32, [vp, vp, i64, vp, vp, C.POINTER(i64)]),
     "gs2m_stereo_depth_occlusion": (i32, [vp, vp, i32, i32, f64, f64, vp, vp, vp]),
     "gs2m_tsdf_create": (i32, [C.POINTER(vp), f64, f64, i32, i32, i32, i64, i32]),
     "gs2m_tsdf_destroy": (i32, [vp]),

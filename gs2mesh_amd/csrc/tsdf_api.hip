@@ -28,6 +28,9 @@ struct gs2m_tsdf {
     unsigned* h_counters = nullptr;         // pinned [4]
     unsigned long long* h_totals = nullptr; // pinned [1]
     int n_cu = 256;
+    McDevTables* d_mc = nullptr;          // marching-cubes case table (generated at create)
+    unsigned* d_blk_tris = nullptr;       // [max_blocks] per-block triangle counts / offsets
+    unsigned long long* d_ntri = nullptr; // [1]
     int timing = 0;
     struct EvPair {
         int stage;
@@ -131,6 +134,9 @@ extern "C" int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf
               hipMalloc((void**)&V.touched, sizeof(unsigned) * (size_t)cap) == hipSuccess &&
               hipMalloc((void**)&V.counters, sizeof(unsigned) * 4) == hipSuccess &&
               hipMalloc((void**)&V.totals, sizeof(unsigned long long)) == hipSuccess &&
+              hipMalloc((void**)&t->d_mc, gs2m_mc_tables_bytes()) == hipSuccess &&
+              hipMalloc((void**)&t->d_blk_tris, sizeof(unsigned) * (size_t)max_blocks) == hipSuccess &&
+              hipMalloc((void**)&t->d_ntri, sizeof(unsigned long long)) == hipSuccess &&
               hipHostMalloc((void**)&t->h_counters, sizeof(unsigned) * 4) == hipSuccess &&
               hipHostMalloc((void**)&t->h_totals, sizeof(unsigned long long)) == hipSuccess;
     if (!ok) {
@@ -138,6 +144,15 @@ extern "C" int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf
                        (double)nvox * 20.0 / 1048576.0);
         gs2m_tsdf_destroy(t);
         return 1;
+    }
+    {
+        std::vector<unsigned char> tab(gs2m_mc_tables_bytes());
+        if (!gs2m_mc_tables_fill(tab.data()) ||
+            hipMemcpy(t->d_mc, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            gs2m_set_error("gs2m_tsdf_create: marching-cubes table generation failed");
+            gs2m_tsdf_destroy(t);
+            return 1;
+        }
     }
     if (zero_state(t, (hipStream_t)0)) {
         gs2m_tsdf_destroy(t);
@@ -161,6 +176,9 @@ extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
     (void)hipFree(V.touched);
     (void)hipFree(V.counters);
     (void)hipFree(V.totals);
+    (void)hipFree(t->d_mc);
+    (void)hipFree(t->d_blk_tris);
+    (void)hipFree(t->d_ntri);
     (void)hipHostFree(t->h_counters);
     (void)hipHostFree(t->h_totals);
     for (auto& p : t->ev_live) {
@@ -397,5 +415,45 @@ extern "C" int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, co
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(t->device));
     gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, wsum, weight, rgb_sum);
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_triangles) {
+    if (!t || !n_triangles) {
+        gs2m_set_error("gs2m_tsdf_extract_count: NULL argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    int64_t nb = 0;
+    if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
+    *n_triangles = 0;
+    if (nb == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    gs2m_launch_mc_count(st, t->V, t->d_mc, (unsigned)nb, t->d_blk_tris, t->d_ntri);
+    unsigned long long n = 0;
+    HIPCHK(hipMemcpyAsync(&n, t->d_ntri, sizeof(n), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (n >= (1ull << 32)) {
+        gs2m_set_error("mesh too large: %llu triangles (32-bit per-block offsets)", n);
+        return 1;
+    }
+    *n_triangles = (int64_t)n;
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
+                                 double* colors, int64_t* n_triangles) {
+    if (!t || !vertices || max_triangles < 0) {
+        gs2m_set_error("gs2m_tsdf_extract: bad argument");
+        return 1;
+    }
+    int64_t n = 0;
+    if (gs2m_tsdf_extract_count(t, stream, &n)) return 1;  // (re)computes the per-block offsets
+    if (n_triangles) *n_triangles = n;
+    if (n == 0 || max_triangles == 0) return 0;
+    int64_t nb = 0;
+    if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
+    gs2m_launch_mc_emit((hipStream_t)stream, t->V, t->d_mc, (unsigned)nb, t->d_blk_tris, (unsigned long long)max_triangles,
+                        t->voxel_length, t->unit_length, vertices, colors);
     return 0;
 }

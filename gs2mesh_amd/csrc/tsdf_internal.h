@@ -10,4 +10,13 @@ void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, cons
                            float* weight, unsigned* rgb);
 void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* wsum,
                              const float* weight, const unsigned* rgb);
+// marching cubes (tsdf_extract.h)
+struct McDevTables;
+size_t gs2m_mc_tables_bytes();
+bool gs2m_mc_tables_fill(void* host_buf);  // generates the case table (host); false on internal error
+void gs2m_launch_mc_count(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
+                          unsigned* blk_tris, unsigned long long* n_total);
+void gs2m_launch_mc_emit(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
+                         const unsigned* blk_off, unsigned long long max_tris, double voxel_length, double unit_length,
+                         double* vertices, double* colors);
 void gs2m_set_error(const char* fmt, ...);

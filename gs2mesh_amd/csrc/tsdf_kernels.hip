@@ -1,5 +1,6 @@
 // tsdf_kernels.hip -- TSDF integration stage (compiled with -ffp-contract=off).
 #include "tsdf_kernels.h"
+#include "tsdf_extract.h"
 #include "tsdf_internal.h"
 #include <math.h>
 
@@ -20,4 +21,30 @@ void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, cons
 void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* wsum,
                              const float* weight, const unsigned* rgb) {
     GS2M_LAUNCH(k_tsdf_unpack, dim3(n), dim3(256), 0, st, V, keys, wsum, weight, rgb);
+}
+
+size_t gs2m_mc_tables_bytes() { return sizeof(McDevTables); }
+bool gs2m_mc_tables_fill(void* host_buf) {
+    McTables T;
+    if (!mc_generate(&T)) return false;
+    McDevTables* D = (McDevTables*)host_buf;
+    memcpy(D->tri, T.tri, sizeof(T.tri));
+    memcpy(D->ntri, T.ntri, sizeof(T.ntri));
+    return true;
+}
+void gs2m_launch_mc_count(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
+                          unsigned* blk_tris, unsigned long long* n_total) {
+    GS2M_LAUNCH(k_mc_count, dim3(n_blocks), dim3(256), 0, st, V, T, n_blocks, blk_tris);
+    GS2M_LAUNCH(k_mc_scan, dim3(1), dim3(1024), 0, st, blk_tris, n_blocks, n_total);
+}
+void gs2m_launch_mc_emit(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
+                         const unsigned* blk_off, unsigned long long max_tris, double voxel_length, double unit_length,
+                         double* vertices, double* colors) {
+    McGeom G;
+    for (int i = 0; i < 8; ++i)
+        for (int a = 0; a < 3; ++a) G.corner[i][a] = mc_corner[i][a];
+    for (int e = 0; e < 12; ++e)
+        for (int a = 0; a < 3; ++a) G.edge[e][a] = mc_edge[e][a];
+    GS2M_LAUNCH(k_mc_emit, dim3(n_blocks), dim3(256), 0, st, V, T, G, n_blocks, blk_off, max_tris, voxel_length,
+                unit_length, vertices, colors);
 }

@@ -196,6 +196,32 @@ class ScalableTSDFVolume:
                    self._lib)
         return keys, tsdf, weight, rgb
 
+    def extract_triangle_mesh(self, stream=None):
+        """``volume.extract_triangle_mesh()`` (tsdf_utils.py:108): marching cubes on the GPU
+        (``gs2m_tsdf_extract``), vertices welded on the host -> ``gs2mesh_amd.mesh.TriangleMesh``."""
+        from .mesh import TriangleMesh
+        st = stream or C.c_void_p(0)
+        n = C.c_int64(0)
+        _lib.check(self._lib.gs2m_tsdf_extract_count(self._h, st, C.byref(n)), self._lib)
+        nt = int(n.value)
+        if nt == 0:
+            return TriangleMesh()
+        host = _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available())
+        if host:
+            verts = np.zeros((nt, 3, 3), np.float64)
+            cols = np.zeros((nt, 3, 3), np.float64)
+        else:
+            verts = torch.zeros((nt, 3, 3), dtype=torch.float64, device=f"cuda:{self.device}")
+            cols = torch.zeros((nt, 3, 3), dtype=torch.float64, device=f"cuda:{self.device}")
+        got = C.c_int64(0)
+        _lib.check(self._lib.gs2m_tsdf_extract(self._h, _stream_of(verts, stream), nt, _ptr(verts), _ptr(cols),
+                                               C.byref(got)), self._lib)
+        self.status(stream)
+        if not host:
+            verts, cols = verts.cpu().numpy(), cols.cpu().numpy()
+        has_color = self.color_type == TSDFVolumeColorType.RGB8
+        return TriangleMesh.from_triangle_soup(verts, cols if has_color else None)
+
     # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
     def block_keys(self, like=None, stream=None):
         n = self.status(stream)[0]

@@ -10,9 +10,9 @@ the host (scipy.ndimage; cv2 is not a dependency).  Frames can come from disk (`
 ``out_<model>/depth.npy``, ...: the reference layout, so ``--skip_rendering`` style resumes work) or
 from memory via ``frame_source`` (the in-memory hand-off).
 
-After ``run()``: ``self.volume`` (gs2mesh_amd.integration.ScalableTSDFVolume).  Mesh extraction
-(``extract_triangle_mesh``, ``save_mesh``, ``clean_mesh``: tsdf_utils.py:108-142) is the next row of
-the scope table and raises until it lands.
+After ``run()``: ``self.volume`` (gs2mesh_amd.integration.ScalableTSDFVolume) and ``self.mesh`` (marching
+cubes on the GPU, ``gs2m_tsdf_extract``); ``save_mesh`` / ``clean_mesh`` write the reference's
+``<out_name>_mesh.ply`` / ``<out_name>_cleaned_mesh.ply`` (tsdf_utils.py:112-142).
 """
 from __future__ import annotations
 
@@ -119,10 +119,27 @@ class TSDF:
                              min_depth=a.TSDF_min_depth_baselines * baseline)
         volume.status()
         self.volume = volume
+        self.mesh = volume.extract_triangle_mesh()                  # tsdf_utils.py:108
+        self.mesh.scale(a.TSDF_scale, (0, 0, 0))                    # :109
+        self.mesh.compute_vertex_normals()                          # :110
 
     def save_mesh(self):
-        raise NotImplementedError("mesh extraction (tsdf_utils.py:108-119) is the next scope row (SURVEY.md 8f-2); "
-                                  "use self.volume.download() for the fused TSDF")
+        """tsdf_utils.py:112-120."""
+        from .mesh import write_triangle_mesh
+        write_triangle_mesh(os.path.join(self.renderer.output_dir_root, f'{self.out_name}_mesh.ply'), self.mesh)
+        print("SAVED MESH")
 
     def clean_mesh(self):
-        raise NotImplementedError("mesh cleaning (tsdf_utils.py:122-142) is the next scope row (SURVEY.md 8f-2)")
+        """tsdf_utils.py:122-142: drop connected components with fewer than TSDF_cleaning_threshold / TSDF_scale
+        triangles.  As in the reference the method rebinds ``self.clean_mesh`` to the cleaned mesh (:138)."""
+        import copy
+        from .mesh import write_triangle_mesh
+        thres = self.args.TSDF_cleaning_threshold / self.args.TSDF_scale
+        triangle_clusters, cluster_n_triangles, cluster_area = self.mesh.cluster_connected_triangles()
+        triangles_to_remove = cluster_n_triangles[triangle_clusters] < thres
+        self.clean_mesh = copy.deepcopy(self.mesh)
+        self.clean_mesh.remove_triangles_by_mask(triangles_to_remove)
+        self.clean_mesh.remove_unreferenced_vertices()
+        write_triangle_mesh(os.path.join(self.renderer.output_dir_root, f'{self.out_name}_cleaned_mesh.ply'),
+                            self.clean_mesh)
+        print("SAVED CLEANED MESH")

@@ -271,6 +271,19 @@ int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, fl
 int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
                      const float* weight, const uint32_t* rgb_sum, gs2m_stream stream);
 
+/*
+ * Replaces volume.extract_triangle_mesh() (tsdf_utils.py:108; Open3D ScalableTSDFVolume::
+ * ExtractTriangleMesh): marching cubes over the allocated blocks; cubes with a zero-weight corner are
+ * skipped, inside = tsdf < 0, vertices interpolated on the cut edges, vertex colour = interpolated
+ * mean colour / 255.  gs2m_tsdf_extract_count synchronises and returns the triangle count;
+ * gs2m_tsdf_extract writes min(count, max_triangles) un-welded triangles to DEVICE buffers
+ * vertices[n,3,3] and colors[n,3,3] (float64, colors may be NULL), asynchronously after its
+ * own count pass.  Vertices shared by neighbouring triangles are bit-identical (weld on the host).
+ */
+int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_triangles);
+int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
+                      double* colors, int64_t* n_triangles);
+
 /* ------------------------------------------------------------------------------------ */
 /* stereo post-processing (between the stereo network and the TSDF)                     */
 /* ------------------------------------------------------------------------------------ */

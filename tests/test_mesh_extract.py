@@ -1,0 +1,131 @@
+"""Mesh extraction: GPU marching cubes + host welding / cleaning / PLY, on both back-ends.
+Open3D is absent (parity unpinned), so the checks are analytic: an injected plane field must come out
+as the exact plane, a fused sphere as a consistently oriented 2-manifold on the sphere, and the
+TSDF.run -> save_mesh -> clean_mesh sequence of run_single.py:161-174 must produce the reference's files."""
+import os
+from argparse import Namespace
+
+import numpy as np
+
+from gs2mesh_amd import synthetic
+from gs2mesh_amd.integration import (PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume,
+                                     TSDFVolumeColorType)
+from gs2mesh_amd.mesh import read_triangle_mesh
+
+
+def edge_counts(tri):
+    e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]], axis=0).astype(np.int64)
+    e.sort(axis=1)
+    key = e[:, 0] * (tri.max() + 2) + e[:, 1]
+    _, cnt = np.unique(key, return_counts=True)
+    return cnt
+
+
+def test_injected_plane_field_is_extracted_exactly(backend):
+    be = backend
+    vl, z0 = 1.0 / 32, 0.4321
+    vol = ScalableTSDFVolume(vl, 4 * vl, TSDFVolumeColorType.RGB8, max_blocks=64, lib=be.lib)
+    keys = np.array([[bx, by, bz] for bx in range(2) for by in range(2) for bz in range(2)], np.int32)
+    n = len(keys)
+    wsum = np.zeros((n, 4096), np.float32)
+    w = np.ones((n, 4096), np.float32)
+    rgb = np.zeros((n, 3, 4096), np.uint32)
+    x, y, z = np.meshgrid(np.arange(16), np.arange(16), np.arange(16), indexing="ij")
+    vidx = ((z >> 2) * 16 + (x >> 2) * 4 + (y >> 2)) * 64 + (z & 3) * 16 + (x & 3) * 4 + (y & 3)   # device layout
+    for b, k in enumerate(keys):
+        zc = (k[2] * 16 + z + 0.5) * vl
+        f = np.clip((zc - z0) / (4 * vl), -1, 1).astype(np.float32)        # positive above the plane
+        wsum[b, vidx.reshape(-1)] = f.reshape(-1)
+        rgb[b, 0, :] = 255
+        rgb[b, 1, vidx.reshape(-1)] = ((k[0] * 16 + x) * 4).reshape(-1)
+    vol.unpack(be.dev(keys), be.dev(wsum), be.dev(w), be.dev(rgb.view(np.int32) if be.name == "gpu" else rgb))
+    mesh = vol.extract_triangle_mesh()
+    assert mesh.triangles.shape[0] == 2 * 31 * 31          # 31 x 31 cubes across 2 x 2 blocks, one quad each
+    assert mesh.vertices.shape[0] == 32 * 32
+    np.testing.assert_allclose(mesh.vertices[:, 2], z0, atol=1e-6)
+    mesh.compute_vertex_normals()
+    np.testing.assert_allclose(mesh.triangle_normals, np.tile([0, 0, 1.0], (mesh.triangles.shape[0], 1)), atol=1e-9)
+    assert (edge_counts(mesh.triangles) <= 2).all()
+    np.testing.assert_allclose(mesh.vertex_colors[:, 0], 1.0, atol=1e-12)
+    gx = np.round(mesh.vertices[:, 0] / vl - 0.5)
+    np.testing.assert_allclose(mesh.vertex_colors[:, 1], gx * 4 / 255.0, atol=1e-12)
+
+
+def fused_sphere(be, n_views=10, W=200, H=150, f=210.0, r=0.6, voxel=2.0 / 96, trunc=0.09):
+    vol = ScalableTSDFVolume(voxel, trunc, max_blocks=4096, lib=be.lib)
+    col = synthetic.color_pattern(W, H)
+    intr = PinholeCameraIntrinsic(W, H, f, f, W / 2.0, H / 2.0)
+    for p in synthetic.ring_poses(n_views, 3.5):
+        E = np.eye(4)
+        E[:3] = p
+        d = synthetic.sphere_depth(p, W, H, f, f, W / 2.0, H / 2.0, r)
+        vol.integrate(RGBDImage(be.dev(col), be.dev(d)), intr, E)
+    return vol, r, voxel
+
+
+def test_fused_sphere_mesh_is_an_oriented_manifold_on_the_sphere(backend):
+    vol, r, voxel = fused_sphere(backend)
+    mesh = vol.extract_triangle_mesh()
+    nt = mesh.triangles.shape[0]
+    assert nt > 5000
+    rad = np.linalg.norm(mesh.vertices, axis=1)
+    assert np.abs(rad - r).max() < 1.5 * voxel and np.abs(rad - r).mean() < 0.35 * voxel
+    mesh.compute_vertex_normals()
+    cen = mesh.vertices[mesh.triangles].mean(axis=1)
+    outward = (mesh.triangle_normals * cen).sum(1) / np.linalg.norm(cen, axis=1)
+    assert (outward > 0.3).mean() > 0.999                   # normals point to the outside (positive tsdf)
+    cnt = edge_counts(mesh.triangles)
+    assert (cnt <= 2).all()                                 # 2-manifold: no edge shared by 3+ triangles
+    assert (cnt == 1).mean() < 0.05                         # open only where the ring of cameras did not see
+    assert abs(mesh.vertices.shape[0] - nt / 2) < 0.06 * nt # Euler: V ~ T/2 for a (nearly) closed surface
+    assert 0 <= mesh.vertex_colors.min() and mesh.vertex_colors.max() <= 1
+    # deterministic
+    m2 = vol.extract_triangle_mesh()
+    np.testing.assert_array_equal(m2.vertices, mesh.vertices)
+    np.testing.assert_array_equal(m2.triangles, mesh.triangles)
+
+
+class FakeRenderer:
+    def __init__(self, root, poses, W, H, f, baseline):
+        self.output_dir_root, self.baseline, self.left_cameras = root, baseline, []
+        for p in poses:
+            E = np.eye(4)
+            E[:3] = p
+            self.left_cameras.append(dict(width=W, height=H, fx=f, fy=f, cx=W / 2.0, cy=H / 2.0, extrinsic=np.linalg.inv(E)))
+
+    def __len__(self):
+        return len(self.left_cameras)
+
+    def render_folder_name(self, i):
+        return os.path.join(self.output_dir_root, f"{i:03}")
+
+
+def test_tsdf_run_save_and_clean_mesh_like_run_single(backend, tmp_path):
+    from gs2mesh_amd.tsdf_utils import TSDF
+    from test_pipeline_classes import make_args
+    W, H, f = 200, 150, 210.0
+    poses = synthetic.ring_poses(8, 3.5)
+    ren = FakeRenderer(str(tmp_path), poses, W, H, f, 0.245)
+    col = synthetic.color_pattern(W, H)
+
+    def frame(i):
+        d = synthetic.sphere_depth(poses[i], W, H, f, f, W / 2.0, H / 2.0, 0.6)
+        d[:12, :12] = 3.0                                       # a small floating blob: its own component
+        return dict(image=col, depth=d)
+
+    args = make_args(TSDF_use_occlusion_mask=False, TSDF_voxel=12, TSDF_sdf_trunc=0.09, TSDF_cleaning_threshold=2000,
+                     TSDF_min_depth_baselines=4, TSDF_max_depth_baselines=20)
+    t = TSDF(ren, Namespace(model_name="DLNR_Middlebury"), args, "out", frame_source=frame, max_blocks=4096, lib=backend.lib)
+    t.run()
+    assert t.mesh.triangles.shape[0] > 3000 and t.mesh.has_vertex_normals()
+    t.save_mesh()
+    t.clean_mesh()
+    raw = read_triangle_mesh(os.path.join(str(tmp_path), "out_mesh.ply"))
+    clean = read_triangle_mesh(os.path.join(str(tmp_path), "out_cleaned_mesh.ply"))
+    assert raw.triangles.shape[0] == t.mesh.triangles.shape[0]
+    np.testing.assert_allclose(raw.vertices, t.mesh.vertices, atol=0)
+    labels, counts, areas = t.mesh.cluster_connected_triangles()
+    assert len(counts) >= 2 and counts.max() > 2000 and counts.min() < 2000
+    assert clean.triangles.shape[0] == counts[counts >= 2000].sum()
+    assert clean.vertices.shape[0] < raw.vertices.shape[0]
+    assert t.clean_mesh is not None and not callable(t.clean_mesh)       # the method rebinds itself (tsdf_utils.py:138)

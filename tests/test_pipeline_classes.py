@@ -162,8 +162,6 @@ def test_tsdf_run_reads_the_reference_layout_and_matches_the_oracle(backend, tmp
     np.testing.assert_array_equal(weight[order], rw)
     np.testing.assert_array_equal(tsdf[order], rt)
     assert weight.max() == 3.0
-    with pytest.raises(NotImplementedError):
-        t.save_mesh()
 
 
 @pytest.mark.gpu
