@@ -6,11 +6,12 @@
 //        16^3 block overlapping the +-sdf_trunc box of the point (first touch in this frame);
 //   (ii) for each marked block sweep its 4096 voxels: project the voxel centre, fetch depth,
 //        sdf = (d - z) * ||ray||, and where sdf > -trunc update the running means.
-// Here: (i) = k_tsdf_touch, one thread per strided pixel, blocks found-or-inserted in a device
-// hash table and appended once per frame to a touched list (atomic frame stamp); (ii) =
-// k_tsdf_integrate, one 256-thread workgroup per touched block (persistent grid-stride loop over
-// the device-side list: no host sync between the phases), thread (x,y) walks z with the same
-// incremental fp32 camera-space step as upstream so every rounding matches.
+// Here: (i) = k_tsdf_touch (thread per strided pixel, wave-deduplicated block boxes, blocks
+// found-or-inserted in a device hash table and stamped with the frame id) + k_tsdf_compact (stamped
+// cells -> the frame's block list); (ii) = k_tsdf_integrate, one 256-thread workgroup per touched
+// block (grid-stride over the device-side list: no host sync between the phases), sweeping the
+// block's 4x4x4 micro-blocks with the same fp32 camera-space z chain as upstream (replayed from the
+// column start, so every rounding matches).
 // The RGBD conversion (depth/scale, >= trunc -> 0; RGBDImage.create_from_color_and_depth,
 // tsdf_utils.py:88-93) and TSDF.run's mask / min-depth preprocessing (tsdf_utils.py:68-83) are
 // fused into the depth fetch.
