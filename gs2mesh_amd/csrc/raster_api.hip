@@ -37,7 +37,7 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 3, opt_debug = 0, opt_timing = 0;
+    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0;
     struct EvPair {
         int stage;
         hipEvent_t a, b;

@@ -539,3 +539,167 @@ k_blend_wave4q(const unsigned long long* __restrict__ keys, const unsigned* __re
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Variant 4 (k_blend_wave4e): variant 3 with the exponent kept in the log2 domain.  The staging lane
+// folds log2(e) into the conic and log2(opacity) into the constant term,
+//   q = (a' dx^2 + log2 o) + c' dy^2 - b' dx dy,   alpha = min(0.99, exp2(q))        (1 v_exp_f32),
+// so the per-pixel path has no multiply by log2(e) and none by the opacity; the alpha >= 1/255
+// pre-filter becomes q >= -log2(255) (constant), power > 0 becomes q > log2 o.  The accumulate path is
+// written for the fewest VALU ops: test_T = fma(-T, alpha, T), one w*T product shared by the three
+// colour FMAs.  Batch bounds are wave-uniform scalars (scalar loop control).  Differences from
+// variant 3 are roundings of ~1 ulp in q (|q| <= 8) -> relative 1e-6 in alpha; same tolerance.
+// ---------------------------------------------------------------------------------------------
+GS2M_KERNEL void __launch_bounds__(256)
+k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
+               const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
+               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
+    __shared__ float4 s_a[4][64];  // mx, my, a' = -0.5 log2e ca, b' = log2e cb
+    __shared__ float4 s_b[4][64];  // c' = -0.5 log2e cc, log2 o, r, g
+    __shared__ float2 s_c[4][64];  // b, quadrant mask (bits)
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int v = (int)blockIdx.y;
+    const CamUniform& cam = cams[v];
+    const int W = cam.W, H = cam.H, gx = cam.gx;
+    const int tiles = gx * cam.gy;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
+    const unsigned grp = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
+    const int tile = gs2m_uniform((int)(grp * 4u) + wave);
+    if (tile >= tiles) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
+    float pxf0 = (float)px0, pxf1 = (float)(px0 + 8);
+    GS2M_KEEP_F32(pxf0);
+    GS2M_KEEP_F32(pxf1);
+    float pyf[4], T[4], C0[4], C1[4], C2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
+        pyf[k] = (x < W && y < H) ? (float)y : GS2M_PARKED;
+        T[k] = 1.0f;
+        C0[k] = C1[k] = C2[k] = 0.0f;
+    }
+    const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * GS2M_TILE);
+    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
+    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
+    if (r0 > cap) r0 = cap;
+    if (r1 > cap) r1 = cap;
+    r0 = (unsigned)gs2m_uniform((int)r0);
+    r1 = (unsigned)gs2m_uniform((int)r1);
+    const unsigned long long* kv = keys + (size_t)v * cap;
+    const GeomRec* rv = recs + (size_t)v * P;
+    const float LOG2E = 1.44269504088896340736f;
+    const float QMIN = -7.99435343685885793770f - 3.0e-4f;  // -log2(255) - margin: alpha >= 1/255 => q >= QMIN
+    float4 ra, rb;
+    float rc = 0.0f;
+    ra.x = ra.y = ra.z = ra.w = 0.0f;
+    rb = ra;
+    rb.y = 1.0f;
+    unsigned base = r0;
+    if (base + (unsigned)lane < r1) {
+        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+        ra = r4[0];
+        rb = r4[1];
+        rc = r4[2].x;
+    }
+    while (base < r1) {
+        const bool live = pyf[0] < 1.0e17f || pyf[1] < 1.0e17f || pyf[2] < 1.0e17f || pyf[3] < 1.0e17f;
+        if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
+        gs2m_wave_sync();
+        {
+            const float lo = gs2m_fast_log2(rb.y);                         // log2 o
+            const float t2 = fmaxf(2.0f * (gs2m_fast_log(rb.y * 255.0f) + 1.0e-4f), 0.0f);  // 2 ln(255 o) (+ margin)
+            const float det = ra.z * rb.x - ra.w * ra.w;                   // conic determinant (> 0)
+            const float inv = 1.0f / det;
+            const float hx = sqrtf(t2 * rb.x * inv) * 1.001f + 0.01f;      // cov_xx = cc/det
+            const float hy = sqrtf(t2 * ra.z * inv) * 1.001f + 0.01f;      // cov_yy = ca/det
+            const bool xl = ra.x - hx <= qx0 + 7.0f, xr = ra.x + hx >= qx0 + 8.0f;
+            const bool yt = ra.y - hy <= qy0 + 7.0f, yb = ra.y + hy >= qy0 + 8.0f;
+            unsigned m = 0u;
+            if (rb.y * 255.0f >= 0.9999f && det > 0.0f) {
+                if (xl && yt) m |= 1u;
+                if (xr && yt) m |= 2u;
+                if (xl && yb) m |= 4u;
+                if (xr && yb) m |= 8u;
+            } else if (!(det > 0.0f)) {
+                m = 15u;  // degenerate conic: no box, test every pixel
+            }
+            float2 cl;
+            cl.x = rc;
+            cl.y = __uint_as_float(m);
+            s_c[wave][lane] = cl;
+            float4 sa = ra, sb = rb;
+            sa.z = (-0.5f * LOG2E) * ra.z;
+            sa.w = LOG2E * ra.w;
+            sb.x = (-0.5f * LOG2E) * rb.x;
+            sb.y = lo;
+            s_a[wave][lane] = sa;
+            s_b[wave][lane] = sb;
+        }
+        gs2m_wave_sync();
+        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
+        base += 64u;
+        if (base + (unsigned)lane < r1) {
+            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+            ra = r4[0];
+            rb = r4[1];
+            rc = r4[2].x;
+        }
+        for (int j = 0; j < nb; ++j) {
+            const float2 CL = s_c[wave][j];
+            const int qm = gs2m_uniform((int)__float_as_uint(CL.y));
+            if (qm == 0) continue;
+            const float4 A = s_a[wave][j];
+            const float4 B = s_b[wave][j];
+            const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
+            const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
+            const float bdx[2] = {A.w * dx0, A.w * dx1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
+                    const float dy = A.y - pyf[k];
+                    const float qv = fmaf(-bdx[k & 1], dy, fmaf(B.x * dy, dy, e[k & 1]));
+                    const bool cand = qv >= QMIN && !(qv > B.y);
+                    if (gs2m_ballot(cand ? 1 : 0) != 0ull) {
+                        const float alpha = fminf(0.99f, gs2m_fast_exp2(qv));
+                        const bool hit = cand && !(alpha < 1.0f / 255.0f);
+                        const float test_T = fmaf(-T[k], alpha, T[k]);
+                        const bool sat = hit && test_T < 0.0001f;
+                        const bool acc = hit && !sat;
+                        const float wT = (acc ? alpha : 0.0f) * T[k];
+                        C0[k] = fmaf(B.z, wT, C0[k]);
+                        C1[k] = fmaf(B.w, wT, C1[k]);
+                        C2[k] = fmaf(CL.x, wT, C2[k]);
+                        T[k] = acc ? test_T : T[k];
+                        pyf[k] = sat ? GS2M_PARKED : pyf[k];
+                    }
+                }
+            }
+        }
+    }
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int pxi = px0 + 8 * (k & 1), pyi = py0 + 8 * (k >> 1);
+        if (pxi < W && pyi < H) {
+            const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];
+            const size_t pix = (size_t)pyi * W + pxi;
+            if (out_color) {
+                float* oc = out_color + (size_t)v * 3 * plane;
+                oc[pix] = o0;
+                oc[plane + pix] = o1;
+                oc[2 * plane + pix] = o2;
+            }
+            if (out_rgb8) {
+                unsigned char* o8 = out_rgb8 + ((size_t)v * plane + pix) * 3;
+                o8[0] = quantize_u8(o0);
+                o8[1] = quantize_u8(o1);
+                o8[2] = quantize_u8(o2);
+            }
+        }
+    }
+}

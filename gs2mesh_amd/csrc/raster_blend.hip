@@ -5,6 +5,12 @@
 void gs2m_launch_blend(hipStream_t st, int variant, int nv, int gx, int gy, const unsigned long long* keys,
                        const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
                        unsigned cap, float* out_color, unsigned char* out_rgb8) {
+    if (variant == 4) {
+        const int tiles = gx * gy;
+        GS2M_LAUNCH(k_blend_wave4e, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
+                    out_color, out_rgb8);
+        return;
+    }
     if (variant == 3) {
         const int tiles = gx * gy;
         GS2M_LAUNCH(k_blend_wave4q, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,

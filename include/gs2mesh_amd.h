@@ -57,8 +57,9 @@ enum {
                                      whole tile (image unchanged, num_rendered smaller)   */
     GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 0 = 16x16 tile per 256-thread workgroup
                                      (1 px/lane); 1 = one wave per tile, 4 px/lane; 2 = 1 with
-                                     the alpha pre-filter; 3 (default) = 2 with the quadrant
-                                     layout + per-instance quadrant mask.  Same image.       */
+                                     the alpha pre-filter; 3 = 2 with the quadrant layout +
+                                     per-instance quadrant mask; 4 (default) = 3 with the
+                                     exponent in the log2 domain.  Same image (to rounding). */
     GS2M_OPT_DEBUG_SYNC = 3,      /* 1 = synchronise + check after every launch (the
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4     /* 1 = bracket every stage launch with hipEvents on the

@@ -41,7 +41,7 @@ def test_c2_stereo_pair_vs_oracle_and_invariants():
     assert np.array_equal(c["color"].cpu().numpy(), img)
     assert max(c["num_rendered"]) < 0.8 * max(n_ref_mode)
     # every compositing kernel variant agrees to rounding
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         R.set_option(_lib.OPT_BLEND_VARIANT, variant)
         d = R.render_views(gd, pair)["color"].cpu().numpy()
         diff = np.abs(d - img)

@@ -259,7 +259,7 @@ def test_argument_validation_errors(backend):
         r.forward(*base, colors_precomp=d(np.ones((4, 3), np.float32)))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_blend_variants_match_the_oracle(backend, variant):
     """Every compositing kernel variant (GS2M_OPT_BLEND_VARIANT) on a ragged image, a crowded
     saturating tile stack and with exact culling on."""
@@ -321,7 +321,7 @@ def test_huge_and_tiny_gaussians_mixed(backend, cull):
     d = be.dev
     r = Rasterizer(0, lib=be.lib)
     r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
-    r.set_option(_lib.OPT_BLEND_VARIANT, 3)
+    r.set_option(_lib.OPT_BLEND_VARIANT, 4)
     img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform),
                            d(cam.camera_center), d(np.array([0.2, 0.1, 0.0], np.float32)), W, H, cam.tanfovx,
                            cam.tanfovy, colors_precomp=d(cols), scales=d(s), rotations=d(q))

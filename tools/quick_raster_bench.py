@@ -1,4 +1,6 @@
 """Quick rasteriser timing on synthetic configs (development aid; bench.py is the contract)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse
 import json
 import time

@@ -1,4 +1,6 @@
 """TSDF-only timing (development aid): distinct vs repeated depth frames, with/without colour."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse, json, time
 import numpy as np, torch
 from gs2mesh_amd import synthetic
