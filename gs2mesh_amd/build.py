@@ -21,7 +21,7 @@ ARCH = "gfx950"
 SOURCES = [
     ("raster_project.hip", ["-ffp-contract=off"]),
     ("raster_bin.hip", []),
-    ("raster_blend.hip", []),
+    ("raster_blend.hip", ["-fno-slp-vectorize"]),  # packed-f32 SLP costs register copies in the compositing loop
     ("raster_api.hip", []),
     ("tsdf_kernels.hip", ["-ffp-contract=off"]),
     ("tsdf_api.hip", []),
@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False, extra: list[str] | None = 
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= newest:
             continue
-        cmd = [hipcc, "-c", s, "-o", o] + COMMON + flags + (extra or [])
+        cmd = [hipcc, "-c", s, "-o", o] + COMMON + flags + (extra or []) + os.environ.get("GS2M_BUILD_EXTRA", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

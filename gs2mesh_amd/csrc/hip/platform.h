@@ -61,3 +61,5 @@ GS2M_DEVICE float gs2m_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); } 
 GS2M_DEVICE float gs2m_fast_log2(float x) { return __log2f(x); }
 // keep a loop-invariant float in its VGPR (stops the compiler re-materialising int->float converts in hot loops)
 #define GS2M_KEEP_F32(x) asm volatile("" : "+v"(x))
+// instruction-scheduling fence (nothing moves across it)
+#define GS2M_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)

@@ -12,6 +12,7 @@
 // opacity AND rgb -- the reference gathers rgb from global memory per contributing pixel,
 // forward.cu:355), the workgroup leaves as soon as all its pixels are saturated.
 #pragma once
+#include <type_traits>
 #include "raster_common.h"
 
 GS2M_DEVICE unsigned char quantize_u8(float c) {
@@ -550,13 +551,20 @@ k_blend_wave4q(const unsigned long long* __restrict__ keys, const unsigned* __re
 // colour FMAs.  Batch bounds are wave-uniform scalars (scalar loop control).  Differences from
 // variant 3 are roundings of ~1 ulp in q (|q| <= 8) -> relative 1e-6 in alpha; same tolerance.
 // ---------------------------------------------------------------------------------------------
-GS2M_KERNEL void __launch_bounds__(256)
+struct alignas(16) BlendInst {
+    float4 a, b;
+    float2 c, pad;
+};
+
+template <int ABL, int WPB>
+GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
-    __shared__ float4 s_a[4][64];  // mx, my, a' = -0.5 log2e ca, b' = log2e cb
-    __shared__ float4 s_b[4][64];  // c' = -0.5 log2e cc, log2 o, r, g
-    __shared__ float2 s_c[4][64];  // b, quadrant mask (bits)
+    // 48-B staged instance: a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc, log2 o, r, g},
+    // c = {b, quadrant mask (bits)}; one LDS address + immediate offsets per instance.  2 pad slots: the
+    // software-pipelined reads run up to 2 instances ahead.
+    __shared__ BlendInst s_i[WPB][64 + 2];
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int v = (int)blockIdx.y;
@@ -566,7 +574,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
     const unsigned grp = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
-    const int tile = gs2m_uniform((int)(grp * 4u) + wave);
+    const int tile = gs2m_uniform((int)(grp * (unsigned)WPB) + wave);
     if (tile >= tiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
@@ -591,7 +599,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const unsigned long long* kv = keys + (size_t)v * cap;
     const GeomRec* rv = recs + (size_t)v * P;
     const float LOG2E = 1.44269504088896340736f;
-    const float QMIN = -7.99435343685885793770f - 3.0e-4f;  // -log2(255) - margin: alpha >= 1/255 => q >= QMIN
+    const float QMIN = -7.99435343685885793770f;  // -log2(255): alpha >= 1/255 <=> q >= QMIN (decided in the log2 domain)
     float4 ra, rb;
     float rc = 0.0f;
     ra.x = ra.y = ra.z = ra.w = 0.0f;
@@ -627,17 +635,17 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             } else if (!(det > 0.0f)) {
                 m = 15u;  // degenerate conic: no box, test every pixel
             }
-            float2 cl;
-            cl.x = rc;
-            cl.y = __uint_as_float(m);
-            s_c[wave][lane] = cl;
-            float4 sa = ra, sb = rb;
-            sa.z = (-0.5f * LOG2E) * ra.z;
-            sa.w = LOG2E * ra.w;
-            sb.x = (-0.5f * LOG2E) * rb.x;
-            sb.y = lo;
-            s_a[wave][lane] = sa;
-            s_b[wave][lane] = sb;
+            BlendInst bi;
+            bi.a = ra;
+            bi.b = rb;
+            bi.a.z = (-0.5f * LOG2E) * ra.z;
+            bi.a.w = LOG2E * ra.w;
+            bi.b.x = (-0.5f * LOG2E) * rb.x;
+            bi.b.y = lo;
+            bi.c.x = rc;
+            bi.c.y = __uint_as_float(m);
+            bi.pad = bi.c;
+            s_i[wave][lane] = bi;
         }
         gs2m_wave_sync();
         const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
@@ -649,37 +657,58 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             rb = r4[1];
             rc = r4[2].x;
         }
-        for (int j = 0; j < nb; ++j) {
-            const float2 CL = s_c[wave][j];
-            const int qm = gs2m_uniform((int)__float_as_uint(CL.y));
-            if (qm == 0) continue;
-            const float4 A = s_a[wave][j];
-            const float4 B = s_b[wave][j];
-            const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
-            const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
-            const float bdx[2] = {A.w * dx0, A.w * dx1};
+        // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
+        // constants are in flight while instance j is composited (no LDS wait on the critical path).
+        auto step = [&](const int qm, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+            if (qm != 0) {
+                const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
+                const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
+                const float bdx[2] = {A.w * dx0, A.w * dx1};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
-                    const float dy = A.y - pyf[k];
-                    const float qv = fmaf(-bdx[k & 1], dy, fmaf(B.x * dy, dy, e[k & 1]));
-                    const bool cand = qv >= QMIN && !(qv > B.y);
-                    if (gs2m_ballot(cand ? 1 : 0) != 0ull) {
-                        const float alpha = fminf(0.99f, gs2m_fast_exp2(qv));
-                        const bool hit = cand && !(alpha < 1.0f / 255.0f);
-                        const float test_T = fmaf(-T[k], alpha, T[k]);
-                        const bool sat = hit && test_T < 0.0001f;
-                        const bool acc = hit && !sat;
-                        const float wT = (acc ? alpha : 0.0f) * T[k];
-                        C0[k] = fmaf(B.z, wT, C0[k]);
-                        C1[k] = fmaf(B.w, wT, C1[k]);
-                        C2[k] = fmaf(CL.x, wT, C2[k]);
-                        T[k] = acc ? test_T : T[k];
-                        pyf[k] = sat ? GS2M_PARKED : pyf[k];
+                for (int k = 0; k < 4; ++k) {
+                    if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
+                        const float dy = A.y - pyf[k];
+                        const float qv = fmaf(-bdx[k & 1], dy, fmaf(B.x * dy, dy, e[k & 1]));
+                        const bool cand = ABL == 2 ? qv > 1.0e30f : (qv >= QMIN && !(qv > B.y));
+                        if (gs2m_ballot(cand ? 1 : 0) != 0ull) {
+                            const float alpha = fminf(0.99f, gs2m_fast_exp2(qv));
+                            const float test_T = fmaf(-T[k], alpha, T[k]);
+                            const bool sat = cand && test_T < 0.0001f;
+                            const float Tn = (cand && !sat) ? test_T : T[k];
+                            const float wT = T[k] - Tn;  // = alpha * T for an accepted contribution, else 0
+                            C0[k] = fmaf(B.z, wT, C0[k]);
+                            C1[k] = fmaf(B.w, wT, C1[k]);
+                            C2[k] = fmaf(CL.x, wT, C2[k]);
+                            T[k] = Tn;
+                            pyf[k] = sat ? GS2M_PARKED : pyf[k];
+                        }
                     }
                 }
             }
+        };
+        // The quadrant mask is read (= the LDS wait) BEFORE the next instance's reads are issued, so the
+        // wait never covers a read that was just issued (the compiler's waitcnt is lgkmcnt(0) in this loop).
+        const BlendInst* sp = &s_i[wave][0];
+        float4 A0 = sp[0].a, B0 = sp[0].b, A1, B1;
+        float2 K0 = sp[0].c, K1;
+        int j = 0;
+        for (; j + 1 < nb; j += 2) {
+            const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
+            GS2M_SCHED_BARRIER();
+            A1 = sp[j + 1].a;
+            B1 = sp[j + 1].b;
+            K1 = sp[j + 1].c;
+            GS2M_SCHED_BARRIER();
+            step(qm0, K0, A0, B0);
+            const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
+            GS2M_SCHED_BARRIER();
+            A0 = sp[j + 2].a;
+            B0 = sp[j + 2].b;
+            K0 = sp[j + 2].c;
+            GS2M_SCHED_BARRIER();
+            step(qm1, K1, A1, B1);
         }
+        if (j < nb) step(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
     }
     const size_t plane = (size_t)H * W;
 #pragma unroll

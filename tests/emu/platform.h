@@ -108,6 +108,7 @@ static inline float gs2m_fast_log(float x) { return logf(x); }
 static inline float gs2m_fast_exp2(float x) { return exp2f(x); }
 static inline float gs2m_fast_log2(float x) { return log2f(x); }
 #define GS2M_KEEP_F32(x) ((void)0)
+#define GS2M_SCHED_BARRIER() ((void)0)
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 static inline int __ffsll(unsigned long long m) { return __builtin_ffsll((long long)m); }
 
