@@ -230,7 +230,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
     const int tiles = gx * gy;
-    const size_t lds = (size_t)nv * tiles * sizeof(unsigned);        // scatter: cursors only
+    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles);            // scatter: cursors + wave staging
     const size_t lds_p = gs2m_project_lds_bytes(nv, tiles);          // project: histogram + wave staging
     if (lds_p > 160 * 1024) {
         gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile histogram", W, H, nv, tiles);
@@ -246,10 +246,16 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     }
     if (gs2m_raster_reserve(r, g.P, nv, W, H, 0)) return 1;
     const unsigned cap = r->inst_cap;
+#ifdef GS2M_DEV_ABLATE
+    static const int dev_abl = getenv("GS2M_ABL") ? atoi(getenv("GS2M_ABL")) : 0;
+    const int cull_arg_p = r->opt_exact_cull | ((dev_abl & 0xff) << 8), cull_arg_s = r->opt_exact_cull | ((dev_abl >> 8) << 8);
+#else
+    const int cull_arg_p = r->opt_exact_cull, cull_arg_s = r->opt_exact_cull;
+#endif
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
         if (gs2m_launch_project_count(nv, n_wg, lds_p, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
-                                      r->d_tilemask, r->opt_exact_cull))
+                                      r->d_tilemask, cull_arg_p))
             return 1;
     }
     if (dbg_check(r, st, "project_count")) return 1;
@@ -266,7 +272,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
         if (gs2m_launch_scatter(nv, n_wg, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
-                                r->d_tilemask, r->d_keys, cap, r->opt_exact_cull))
+                                r->d_tilemask, r->d_keys, cap, cull_arg_s))
             return 1;
     }
     if (dbg_check(r, st, "scatter")) return 1;

@@ -7,6 +7,7 @@
 
 struct CamUniformArg;
 
+size_t gs2m_scatter_lds_bytes(int nv, int tiles);
 int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
                               const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
                               unsigned long long* tilemask, int exact_cull);

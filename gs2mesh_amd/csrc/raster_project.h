@@ -65,21 +65,43 @@ GS2M_DEVICE void project_view(const CamUniform& cam, float px, float py, float p
 }
 
 // ---- wave-balanced tile expansion ------------------------------------------------------------
-// Every Gaussian touches a different number of tiles (1 ... thousands).  Walking the rect per lane
-// (as duplicateWithKeys does, rasterizer_impl.cu:98-108) leaves most lanes idle.  Instead the 64
-// Gaussians of a wave publish their rects in LDS, an inclusive wave scan of the rect areas
-// flattens all (Gaussian, tile) pairs of the wave into one index space, and lane l takes pairs
-// l, l+64, ... (owner found by a 6-step binary search in the scan).  Each kept pair bumps the
-// workgroup's LDS tile histogram and, for rects of <= 64 tiles, sets a bit in the owner's tile
-// mask, which the scatter kernel walks instead of re-testing.
+// Every Gaussian touches a different number of tiles (1 ... hundreds).  Walking the rect per lane
+// (as duplicateWithKeys does, rasterizer_impl.cu:98-108) leaves most lanes idle while the wave waits for
+// its largest rect (C2: mean 8.6 tiles, mean of the per-wave maximum 38).  Instead:
+//   * the owners of small rects (<= 64 tiles) are compacted (rank k by ballot) and an exclusive wave scan
+//     of their areas flattens all their (Gaussian, tile) pairs into one item space of <= 4096 items;
+//   * a bit array marks the first item of every owner ("heads"); lane l of batch b0 takes item b0 + l and
+//     finds its owner as  k = (#heads before the batch) + popcount(heads_word & lanes <= l) - 1
+//     -- one broadcast LDS read and a popcount instead of a binary search;
+//   * rects of more than 64 tiles (rare) are walked by the whole wave, one owner at a time.
+// Each kept pair bumps the workgroup's LDS tile histogram; the kept tiles of a small rect are recorded as a
+// bit mask (assembled from ballots by the first lane of each owner's run) that the scatter kernel replays.
 struct WaveStage {
-    float mx[64], my[64], ca[64], cb[64], cc[64], thr[64];
+    float mx[64], my[64], ca[64], cb[64], cc[64], thr[64];  // indexed by owner rank k
+    unsigned swh[64];   // first item (16 bits) | w << 16 | h << 24
     unsigned xy0[64];   // x0 | y0 << 16
-    unsigned wh[64];    // w | h << 16
-    unsigned pref[64];  // inclusive scan of w*h
-    unsigned mlo[64], mhi[64];
+    unsigned mlo[64], mhi[64];  // kept-tile mask of the owner's rect
+    unsigned heads[130];        // bit i: item i is the first item of an owner (+ slack for the 64-bit window)
+    unsigned pad[2];
 };
 #define GS2M_STAGE_BYTES (4 * (int)sizeof(WaveStage))
+
+GS2M_DEVICE unsigned long long lanes_le(int lane) { return (2ull << lane) - 1ull; }
+GS2M_DEVICE unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// li -> (rx, ry) of a rect of width ow without an integer division (li < 2^16, exact after one fix-up)
+GS2M_DEVICE void rect_coords(unsigned li, unsigned ow, float inv_w, unsigned& rx, unsigned& ry) {
+    ry = (unsigned)((float)li * inv_w);
+    int r = (int)li - (int)(ry * ow);
+    if (r < 0) {
+        ry -= 1u;
+        r += (int)ow;
+    } else if (r >= (int)ow) {
+        ry += 1u;
+        r -= (int)ow;
+    }
+    rx = (unsigned)r;
+}
 
 GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
 #pragma unroll
@@ -96,6 +118,12 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 int* __restrict__ radii, unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask,
                 int exact_cull) {
     GS2M_DYN_LDS(unsigned, lds);
+#ifdef GS2M_DEV_ABLATE
+    const int abl = exact_cull >> 8;  // 1: no tile expansion, 2: no SH/colour, 4: no hist row write, 8: no rec write
+    exact_cull &= 1;
+#else
+    const int abl = 0;
+#endif
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int gx = cams[0].gx, gy = cams[0].gy;
@@ -150,7 +178,7 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 any = any || pv[v].ok;
             }
             float sh[48];
-            const bool need_sh = any && (g.colors_precomp == nullptr);
+            const bool need_sh = any && (g.colors_precomp == nullptr) && !(abl & 2);
             if (need_sh) {
                 if (g.shs_packed) {
                     // wave-transposed copy (k_pack_sh): float4 k of 64 consecutive Gaussians is 1 KiB contiguous
@@ -210,7 +238,9 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                     continue;
                 }
                 float cr, cg, cb;
-                if (g.colors_precomp) {
+                if (abl & 2) {
+                    cr = cg = cb = 0.5f;
+                } else if (g.colors_precomp) {
                     cr = g.colors_precomp[3 * (size_t)gi];
                     cg = g.colors_precomp[3 * (size_t)gi + 1];
                     cb = g.colors_precomp[3 * (size_t)gi + 2];
@@ -260,8 +290,10 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 w2.z = __uint_as_float((unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16));
                 w2.w = __uint_as_float((unsigned)pv[v].x1 | ((unsigned)pv[v].y1 << 16));
                 float4* r4 = reinterpret_cast<float4*>(rec);
-                r4[0] = w0;
-                r4[1] = w1;
+                if (!(abl & 8)) {
+                    r4[0] = w0;
+                    r4[1] = w1;
+                }
                 r4[2] = w2;
             }
         }
@@ -270,68 +302,113 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
         for (int v = 0; v < NV; ++v) {
             const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
             const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
-            const unsigned incl = wave_inclusive_scan(area);
-            const unsigned total = gs2m_shfl(incl, 63);
-            if (total == 0u) continue;  // wave-uniform
-            gs2m_wave_sync();
-            stage->mx[lane] = pv[v].mx;
-            stage->my[lane] = pv[v].my;
-            stage->ca[lane] = pv[v].ca;
-            stage->cb[lane] = pv[v].cb;
-            stage->cc[lane] = pv[v].cc;
-            stage->thr[lane] = thr;
-            stage->xy0[lane] = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
-            stage->wh[lane] = w | (h << 16);
-            stage->pref[lane] = incl;
-            stage->mlo[lane] = 0u;
-            stage->mhi[lane] = 0u;
-            gs2m_wave_sync();
+            if ((abl & 1) || gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
             unsigned* hh = lhist + v * tiles;
-            for (unsigned b0 = 0; b0 < total; b0 += 64u) {
-                const unsigned item = b0 + (unsigned)lane;
-                if (item < total) {
-                    int lo = 0, hi = 63;
-#pragma unroll
-                    for (int it = 0; it < 6; ++it) {
-                        const int mid = (lo + hi) >> 1;
-                        if (stage->pref[mid] > item) hi = mid;
-                        else lo = mid + 1;
+            const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
+            // ---- small rects: flattened item space ----
+            const bool small = area != 0u && area <= 64u;
+            const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
+            if (smalls != 0ull) {
+                const int k = gs2m_popc64(smalls & lanes_lt(lane));
+                const unsigned incl = wave_inclusive_scan(small ? area : 0u);
+                const unsigned total = gs2m_shfl(incl, 63);
+                const unsigned start = incl - (small ? area : 0u);
+                gs2m_wave_sync();
+                stage->heads[lane] = 0u;
+                stage->heads[lane + 64] = 0u;
+                if (lane < 2) stage->heads[128 + lane] = 0u;
+                gs2m_wave_sync();
+                if (small) {
+                    stage->mx[k] = pv[v].mx;
+                    stage->my[k] = pv[v].my;
+                    stage->ca[k] = pv[v].ca;
+                    stage->cb[k] = pv[v].cb;
+                    stage->cc[k] = pv[v].cc;
+                    stage->thr[k] = thr;
+                    stage->swh[k] = start | (w << 16) | (h << 24);
+                    stage->xy0[k] = xy0;
+                    stage->mlo[k] = 0u;
+                    stage->mhi[k] = 0u;
+                    atomicOr(&stage->heads[start >> 5], 1u << (start & 31u));
+                }
+                gs2m_wave_sync();
+                int kbase = 0;
+                for (unsigned b0 = 0; b0 < total; b0 += 64u) {
+                    const unsigned long long H =
+                        (unsigned long long)stage->heads[b0 >> 5] | ((unsigned long long)stage->heads[(b0 >> 5) + 1] << 32);
+                    const int kk = kbase + gs2m_popc64(H & lanes_le(lane)) - 1;
+                    kbase += gs2m_popc64(H);
+                    const unsigned item = b0 + (unsigned)lane;
+                    const bool act = item < total;
+                    bool keep = false;
+                    unsigned li = 0u;
+                    if (act) {
+                        const unsigned swh = stage->swh[kk];
+                        const unsigned ow = (swh >> 16) & 0xffu, oh = swh >> 24;
+                        li = item - (swh & 0xffffu);
+                        unsigned rx, ry;
+                        rect_coords(li, ow, gs2m_fast_rcp((float)ow), rx, ry);
+                        const unsigned oxy = stage->xy0[kk];
+                        const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
+                        keep = true;
+                        if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
+                            keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
+                                                       stage->cc[kk], stage->thr[kk], tx, ty);
+                        if (keep) atomicAdd(&hh[ty * gx + tx], 1u);
                     }
-                    const int o = lo;
-                    const unsigned wh = stage->wh[o];
-                    const unsigned ow = wh & 0xffffu, oh = wh >> 16;
-                    const unsigned li = item - (stage->pref[o] - ow * oh);
-                    const unsigned ry = li / ow, rx = li - ry * ow;
-                    const unsigned xy0 = stage->xy0[o];
-                    const int tx = (int)(xy0 & 0xffffu) + (int)rx, ty = (int)(xy0 >> 16) + (int)ry;
-                    bool keep = true;
-                    if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
-                        keep = tile_may_contribute(stage->mx[o], stage->my[o], stage->ca[o], stage->cb[o], stage->cc[o],
-                                                   stage->thr[o], tx, ty);
-                    if (keep) {
-                        atomicAdd(&hh[ty * gx + tx], 1u);
-                        if (li < 32u) atomicOr(&stage->mlo[o], 1u << li);
-                        else if (li < 64u) atomicOr(&stage->mhi[o], 1u << (li - 32u));
+                    // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
+                    const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
+                    if (act && (lane == 0 || ((H >> lane) & 1ull))) {
+                        const unsigned long long rest = lane == 63 ? 0ull : (H >> (lane + 1));
+                        const int len = rest ? __ffsll(rest) : 64 - lane;
+                        const unsigned long long run = (kept >> lane) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+                        const unsigned long long bits = run << li;
+                        stage->mlo[kk] |= (unsigned)bits;
+                        stage->mhi[kk] |= (unsigned)(bits >> 32);
                     }
                 }
+                gs2m_wave_sync();
+                if (small)
+                    tilemask[(size_t)v * g.P + gi] = (unsigned long long)stage->mlo[k] | ((unsigned long long)stage->mhi[k] << 32);
             }
-            gs2m_wave_sync();
-            if (area > 0u && area <= 64u)
-                tilemask[(size_t)v * g.P + gi] = (unsigned long long)stage->mlo[lane] | ((unsigned long long)stage->mhi[lane] << 32);
+            // ---- rects of more than 64 tiles: the whole wave walks one owner at a time ----
+            unsigned long long bigs = gs2m_ballot(area > 64u ? 1 : 0);
+            while (bigs != 0ull) {
+                const int o = __ffsll(bigs) - 1;
+                bigs &= bigs - 1ull;
+                const unsigned ow = gs2m_shfl(w, o), oa = gs2m_shfl(area, o), oxy = gs2m_shfl(xy0, o);
+                const float omx = gs2m_shfl(pv[v].mx, o), omy = gs2m_shfl(pv[v].my, o), oca = gs2m_shfl(pv[v].ca, o),
+                            ocb = gs2m_shfl(pv[v].cb, o), occ = gs2m_shfl(pv[v].cc, o), othr = gs2m_shfl(thr, o);
+                const float oinv = gs2m_fast_rcp((float)ow);
+                for (unsigned li = (unsigned)lane; li < oa; li += 64u) {
+                    unsigned rx, ry;
+                    rect_coords(li, ow, oinv, rx, ry);
+                    const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
+                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, othr, tx, ty)) atomicAdd(&hh[ty * gx + tx], 1u);
+                }
+            }
         }
     }
     __syncthreads();
+    if (abl & 4) return;
     for (int i = tid; i < NV * tiles; i += 256) {
         const int v = i / tiles, t = i - v * tiles;
         hist[((size_t)v * n_wg + blockIdx.x) * tiles + t] = lhist[i];
     }
 }
 
+struct ScatterStage {
+    unsigned swh[64], xy0[64], dbits[64], gid[64], mlo[64], mhi[64];  // indexed by owner rank k
+    unsigned heads[130];
+    unsigned pad[2];
+};
+#define GS2M_SCATTER_STAGE_BYTES (4 * (int)sizeof(ScatterStage))
+
 // Instance scatter: same Gaussian -> workgroup assignment as k_project_count; cursors start at
 // tile_start[v][t] + (exclusive prefix over workgroups, left in `hist` by k_hist_colscan).
 // Key = depth_bits << 32 | gaussian_id (unique => order after the per-tile sort is deterministic
-// although LDS-atomic arrival order is not).  Rects of <= 64 tiles replay the tile mask written by
-// k_project_count; larger ones repeat the same per-tile test.
+// although LDS-atomic arrival order is not).  Same balanced walk as k_project_count; rects of <= 64 tiles
+// replay the tile mask written there, larger ones repeat the same per-tile test.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(256)
 k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
@@ -339,58 +416,119 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
           const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
           int exact_cull) {
     GS2M_DYN_LDS(unsigned, cursor);
+#ifdef GS2M_DEV_ABLATE
+    const int abl = exact_cull >> 8;  // 1: no key store, 2: cursor init only, 4: no cursor init
+    exact_cull &= 1;
+#else
+    const int abl = 0;
+#endif
     const int tid = (int)threadIdx.x;
     const int gx = cams[0].gx, gy = cams[0].gy;
     const int tiles = gx * gy;
+    if (!(abl & 4))
     for (int i = tid; i < NV * tiles; i += 256) {
         const int v = i / tiles, t = i - v * tiles;
         cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + blockIdx.x) * tiles + t];
     }
     __syncthreads();
+    if (abl & 2) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    ScatterStage* stage = reinterpret_cast<ScatterStage*>(cursor + ((NV * tiles + 3) & ~3)) + wave;
     const int begin = (int)blockIdx.x * chunk;
     const int end = gs2m_imin(P, begin + chunk);
     for (int base = begin; base < end; base += 256) {
         const int gi = base + tid;
-        if (gi < end) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi);
-                const float4 w2 = r4[2];
-                const unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w);
-                const int x0 = (int)(rect0 & 0xffffu), y0 = (int)(rect0 >> 16);
-                const int x1 = (int)(rect1 & 0xffffu), y1 = (int)(rect1 >> 16);
-                if (x1 <= x0 || y1 <= y0) continue;
-                const unsigned long long hi = ((unsigned long long)__float_as_uint(w2.y)) << 32;
-                unsigned* cur = cursor + v * tiles;
-                unsigned long long* kv = keys + (size_t)v * cap;
-                const int w = x1 - x0, area = w * (y1 - y0);
-                if (area <= 64) {
-                    unsigned long long m = tilemask[(size_t)v * P + gi];
-                    while (m) {
-                        const int li = __ffsll((unsigned long long)m) - 1;
-                        m &= m - 1ull;
-                        const int ry = li / w, rx = li - ry * w;
-                        const unsigned pos = atomicAdd(&cur[(y0 + ry) * gx + x0 + rx], 1u);
-                        if (pos < cap) kv[pos] = hi | (unsigned)gi;
+        for (int v = 0; v < NV; ++v) {
+            unsigned rect0 = 0u, rect1 = 0u, dbits = 0u;
+            if (gi < end) {
+                const float4 w2 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi)[2];
+                rect0 = __float_as_uint(w2.z);
+                rect1 = __float_as_uint(w2.w);
+                dbits = __float_as_uint(w2.y);
+            }
+            const int x0 = (int)(rect0 & 0xffffu), y0 = (int)(rect0 >> 16);
+            const int x1 = (int)(rect1 & 0xffffu), y1 = (int)(rect1 >> 16);
+            const unsigned w = x1 > x0 ? (unsigned)(x1 - x0) : 0u, h = y1 > y0 ? (unsigned)(y1 - y0) : 0u;
+            const unsigned area = w * h;
+            if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
+            unsigned* cur = cursor + v * tiles;
+            unsigned long long* kv = keys + (size_t)v * cap;
+            const bool small = area != 0u && area <= 64u;
+            const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
+            if (smalls != 0ull) {
+                unsigned long long msk = 0ull;
+                if (small) msk = tilemask[(size_t)v * P + gi];
+                const int k = gs2m_popc64(smalls & lanes_lt(lane));
+                const unsigned incl = wave_inclusive_scan(small ? area : 0u);
+                const unsigned total = gs2m_shfl(incl, 63);
+                const unsigned start = incl - (small ? area : 0u);
+                gs2m_wave_sync();
+                stage->heads[lane] = 0u;
+                stage->heads[lane + 64] = 0u;
+                if (lane < 2) stage->heads[128 + lane] = 0u;
+                gs2m_wave_sync();
+                if (small) {
+                    stage->swh[k] = start | (w << 16) | (h << 24);
+                    stage->xy0[k] = rect0;
+                    stage->dbits[k] = dbits;
+                    stage->gid[k] = (unsigned)gi;
+                    stage->mlo[k] = (unsigned)msk;
+                    stage->mhi[k] = (unsigned)(msk >> 32);
+                    atomicOr(&stage->heads[start >> 5], 1u << (start & 31u));
+                }
+                gs2m_wave_sync();
+                int kbase = 0;
+                for (unsigned b0 = 0; b0 < total; b0 += 64u) {
+                    const unsigned long long H =
+                        (unsigned long long)stage->heads[b0 >> 5] | ((unsigned long long)stage->heads[(b0 >> 5) + 1] << 32);
+                    const int kk = kbase + gs2m_popc64(H & lanes_le(lane)) - 1;
+                    kbase += gs2m_popc64(H);
+                    const unsigned item = b0 + (unsigned)lane;
+                    if (item < total) {
+                        const unsigned swh = stage->swh[kk];
+                        const unsigned li = item - (swh & 0xffffu);
+                        const unsigned long long om = (unsigned long long)stage->mlo[kk] | ((unsigned long long)stage->mhi[kk] << 32);
+                        if ((om >> li) & 1ull) {
+                            const unsigned ow = (swh >> 16) & 0xffu;
+                            unsigned rx, ry;
+                            rect_coords(li, ow, gs2m_fast_rcp((float)ow), rx, ry);
+                            const unsigned oxy = stage->xy0[kk];
+                            const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
+                            const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
+                            if (pos < cap && !(abl & 1)) kv[pos] = ((unsigned long long)stage->dbits[kk] << 32) | stage->gid[kk];
+                        }
                     }
-                } else {
-                    float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
-                    if (exact_cull) {
-                        const float4 w0 = r4[0];
-                        const float4 w1 = r4[1];
-                        mx = w0.x;
-                        my = w0.y;
-                        ca = w0.z;
-                        cb = w0.w;
-                        cc = w1.x;
-                        thr = cull_threshold(w1.y);
+                }
+            }
+            // rects of more than 64 tiles (rare): the whole wave walks one owner at a time, repeating the test
+            unsigned long long bigs = gs2m_ballot(area > 64u ? 1 : 0);
+            while (bigs != 0ull) {
+                const int o = __ffsll(bigs) - 1;
+                bigs &= bigs - 1ull;
+                const unsigned ow = gs2m_shfl(w, o), oa = gs2m_shfl(area, o), oxy = gs2m_shfl(rect0, o);
+                const unsigned long long key = ((unsigned long long)gs2m_shfl(dbits, o) << 32) | (unsigned)gs2m_shfl(gi, o);
+                float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
+                if (exact_cull) {
+                    const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gs2m_shfl(gi, o));
+                    const float4 w0 = r4[0];
+                    const float4 w1 = r4[1];
+                    mx = w0.x;
+                    my = w0.y;
+                    ca = w0.z;
+                    cb = w0.w;
+                    cc = w1.x;
+                    thr = cull_threshold(w1.y);
+                }
+                const float oinv = gs2m_fast_rcp((float)ow);
+                for (unsigned li = (unsigned)lane; li < oa; li += 64u) {
+                    unsigned rx, ry;
+                    rect_coords(li, ow, oinv, rx, ry);
+                    const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
+                    if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
+                        const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
+                        if (pos < cap && !(abl & 1)) kv[pos] = key;
                     }
-                    for (int ty = y0; ty < y1; ++ty)
-                        for (int tx = x0; tx < x1; ++tx)
-                            if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
-                                const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
-                                if (pos < cap) kv[pos] = hi | (unsigned)gi;
-                            }
                 }
             }
         }

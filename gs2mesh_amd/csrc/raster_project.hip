@@ -6,6 +6,10 @@ size_t gs2m_project_lds_bytes(int nv, int tiles) {
     return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + GS2M_STAGE_BYTES;
 }
 
+size_t gs2m_scatter_lds_bytes(int nv, int tiles) {
+    return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + GS2M_SCATTER_STAGE_BYTES;
+}
+
 int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
                               const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
                               unsigned long long* tilemask, int exact_cull) {
