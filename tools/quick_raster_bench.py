@@ -16,7 +16,7 @@ ap.add_argument("--config", default="C2")
 ap.add_argument("--pairs", type=int, default=8)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--cull", type=int, default=0)
-ap.add_argument("--blend", type=int, default=3)
+ap.add_argument("--blend", type=int, default=4)
 ap.add_argument("--morton", type=int, default=0)
 ap.add_argument("--stages", type=int, default=1)
 ap.add_argument("--pack", type=int, default=1)
