@@ -663,14 +663,16 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             if (qm != 0) {
                 const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
                 const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
-                const float bdx[2] = {A.w * dx0, A.w * dx1};
+                const float nbdx[2] = {-(A.w * dx0), -(A.w * dx1)};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
                         const float dy = A.y - pyf[k];
-                        const float qv = fmaf(-bdx[k & 1], dy, fmaf(B.x * dy, dy, e[k & 1]));
-                        const bool cand = ABL == 2 ? qv > 1.0e30f : (qv >= QMIN && !(qv > B.y));
-                        if (gs2m_ballot(cand ? 1 : 0) != 0ull) {
+                        // q = e + dy (c' dy - b' dx): two FMAs
+                        const float qv = fmaf(fmaf(B.x, dy, nbdx[k & 1]), dy, e[k & 1]);
+                        const bool pre = ABL == 2 ? qv > 1.0e30f : qv >= QMIN;
+                        if (gs2m_ballot(pre ? 1 : 0) != 0ull) {
+                            const bool cand = pre && !(qv > B.y);  // power > 0 (numerically non-PSD conic): skipped
                             const float alpha = fminf(0.99f, gs2m_fast_exp2(qv));
                             const float test_T = fmaf(-T[k], alpha, T[k]);
                             const bool sat = cand && test_T < 0.0001f;
