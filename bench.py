@@ -44,7 +44,7 @@ def main():
                     help="exact tile culling (image-preserving); 0 = reference instance lists")
     ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "4")))
     ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "reduce_scatter"])
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "2")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "4")),
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
