@@ -42,13 +42,13 @@ def _lex_unique(keys: torch.Tensor) -> torch.Tensor:
     return out.to(torch.int32).contiguous()
 
 
-def canonical_keys(volume, group=None) -> torch.Tensor:
+def canonical_keys(volume, group=None, always_collective: bool = False) -> torch.Tensor:
     """Union of the block keys of all ranks, canonical order, on the local device."""
     keys = volume.block_keys()
     if not torch.is_tensor(keys):
         keys = torch.from_numpy(np.ascontiguousarray(keys))
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (always_collective and dist.is_initialized()):
         return _lex_unique(keys)
     n_local = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
@@ -62,19 +62,21 @@ def canonical_keys(volume, group=None) -> torch.Tensor:
     return _lex_unique(allk)
 
 
-def reduce_volume(volume, group=None, mode: str = "allreduce"):
+def reduce_volume(volume, group=None, mode: str = "allreduce", always_collective: bool = False):
     """Sum-reduce the TSDF accumulators of all ranks into `volume`.
 
     mode "allreduce": every rank ends with the complete fused volume.
     mode "reduce_scatter": rank r ends with blocks [lo_r, hi_r) of the canonical list only.
+    ``always_collective``: issue the collectives even at world size 1 (exercises the RCCL calls on one GPU).
     Returns dict(n_blocks_union, bytes_per_rank, keys) for reporting."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    keys = canonical_keys(volume, group)
+    keys = canonical_keys(volume, group, always_collective)
+    collective = world > 1 or (always_collective and dist.is_initialized())
     n = int(keys.shape[0])
     dev = keys.device
     has_color = int(volume.color_type) == 1
-    if mode == "reduce_scatter" and world > 1:
+    if mode == "reduce_scatter" and collective:
         n_pad = (n + world - 1) // world * world
     else:
         n_pad = n
@@ -89,7 +91,7 @@ def reduce_volume(volume, group=None, mode: str = "allreduce"):
     if n_pad:
         volume.pack(kpad, wsum, weight, rgb)
     nbytes = n_pad * 4096 * (8 + (12 if has_color else 0))
-    if world > 1 and n_pad:
+    if collective and n_pad:
         if mode == "allreduce":
             dist.all_reduce(wsum, op=dist.ReduceOp.SUM, group=group)
             dist.all_reduce(weight, op=dist.ReduceOp.SUM, group=group)

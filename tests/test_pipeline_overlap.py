@@ -86,3 +86,41 @@ def test_pipeline_steady_state_without_reading_back():
     order = np.lexsort(keys.T[::-1])
     for a, b in zip(ref[1:], (keys[order], tsdf[order], weight[order], rgb[order])):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
+def test_reduce_volume_over_rccl_single_rank(mode):
+    """The RCCL calls of parallel.reduce_volume (all_gather of keys, all_reduce / reduce_scatter of the f32 and
+    i32 accumulators) on device tensors, world size 1 (one GPU on the box): the volume must come back unchanged
+    up to the tsdf*w/w round trip."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent(f"""
+        import os, numpy as np, torch, torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        from gs2mesh_amd import synthetic
+        from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+        from gs2mesh_amd.parallel import reduce_volume
+        cfg = synthetic.CONFIGS["C1"]; W, H = cfg.width, cfg.height
+        dev = torch.device("cuda:0")
+        vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
+        intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
+        for p in synthetic.ring_poses(3, cfg.ring_radius, 0, 3):
+            d = synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2, H / 2, cfg.sphere_radius, dev)
+            E = np.eye(4); E[:3] = p
+            img = torch.from_numpy(synthetic.color_pattern(W, H)).to(dev)
+            vol.integrate(RGBDImage(img, d, depth_trunc=cfg.baseline * 20), intr, E)
+        k0, t0, w0, c0 = vol.download()
+        o0 = np.lexsort(k0.T[::-1])
+        info = reduce_volume(vol, mode="{mode}", always_collective=True)
+        k1, t1, w1, c1 = vol.download()
+        o1 = np.lexsort(k1.T[::-1])
+        assert np.array_equal(k0[o0], k1[o1]) and np.array_equal(w0[o0], w1[o1]) and np.array_equal(c0[o0], c1[o1])
+        assert np.abs(t0[o0] - t1[o1]).max() <= 2e-6
+        assert info["n_blocks_union"] == len(k0) > 10
+        dist.destroy_process_group()
+        print("RCCL_OK")
+    """)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -10,10 +10,11 @@ mkdir -p $OUT
 export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
+# kernel stats of the serial order (--inflight 1: kernels in isolation = what bench.py's `stages` time with hipEvents)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --no-cpu-baseline --inflight 1 > $OUT/stats_bench.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --no-cpu-baseline --steps 16 > /dev/null 2> $OUT/pmc_$c.err
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 16 > /dev/null 2> $OUT/pmc_$c.err
 done
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_SQ -- python $R/bench.py --no-cpu-baseline --steps 16 > /dev/null 2> $OUT/pmc_SQ.err
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_SQ -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 16 > /dev/null 2> $OUT/pmc_SQ.err
 find $OUT -name "*.csv" | head -20
 tail -c 400 $OUT/bench.json
