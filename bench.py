@@ -188,6 +188,7 @@ def main():
     dom = max(stages, key=lambda k: stages[k]["avg_us"] * stages[k]["launches"])
     achieved = alg[dom] / (stages[dom]["avg_us"] * 1e-6)
     traffic = None
+    valu = None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
@@ -195,11 +196,19 @@ def main():
             ent = tr.get(args.config, {}).get(dom)
             if ent and ent.get("cull") == args.cull:
                 traffic = ent["hbm_bytes_per_launch"]
+                if ent.get("valu_insts_per_launch"):
+                    # the dominant kernel is VALU-bound: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC
+                    # pass) / live launch time, against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+                    rate = ent["valu_insts_per_launch"] / (stages[dom]["avg_us"] * 1e-6)
+                    valu = dict(insts_per_launch=ent["valu_insts_per_launch"], achieved_Ginst_s=round(rate / 1e9, 1),
+                                peak_Ginst_s=1228.8, frac=round(rate / 1228.8e9, 4),
+                                measured_scalar_fma_ceiling_Ginst_s=805.0,
+                                note="MI355X_MICROARCH.md: scalar v_fma_f32 measured 103 TF = 805 G wave64 inst/s")
         except Exception:
             traffic = None
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
                     frac=round(achieved / HBM_PEAK, 4), traffic=traffic,
-                    algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_us=round(stages[dom]["avg_us"], 2),
+                    algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_us=round(stages[dom]["avg_us"], 2), valu=valu,
                     note="blend is VALU/LDS-bound (12 flop + exp per pixel x instance, data served from LDS); "
                          "HBM fraction reported as the contract asks, see DESIGN.md")
     per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launches=v["launches"],

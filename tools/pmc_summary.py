@@ -35,6 +35,7 @@ for k, cs in summary.items():
     if stage and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                               fetch_kib=cs["FETCH_SIZE"], write_kib=cs["WRITE_SIZE"],
+                              valu_insts_per_launch=int(cs["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in cs else None,
                               cull=bench.get("config", {}).get("exact_tile_cull", 1), source=f"profiles/{tag}_pmc.json")
 tp = os.path.join(dst, "pmc_traffic.json")
 allt = json.load(open(tp)) if os.path.exists(tp) else {}
