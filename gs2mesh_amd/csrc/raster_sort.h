@@ -97,114 +97,128 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     }
 }
 
-// Bitonic network over s[0..NP2) in LDS, 256 threads.  Thread t owns compare-exchange pairs
-// p = t, t+256, ...; pair p of a stride-j stage is (i, i|j) with i = p with a 0 inserted at bit log2(j),
-// so every thread is busy in every stage.  A wave's 64 consecutive pairs live in one aligned block
-// of 128 elements whenever j <= 64: those stages (the first 28 of any sort, and the last 7 of every
-// merge phase) only need wave-level ordering; workgroup barriers remain for the j >= 128 stages only
-// (10 instead of 66 for 2048 keys).  NP2 is a template parameter: the pair loop unrolls and the LDS
-// reads of a stage are issued back to back.
-template <int NP2>
-GS2M_DEVICE void bitonic_lds(unsigned long long* s, int tid) {
-    constexpr int PAIRS = (NP2 / 2 + 255) / 256;
-    bool prev_block_level = true;  // the load that filled s[] was a workgroup-level step
-#pragma unroll 1
-    for (int k = 2; k <= NP2; k <<= 1) {
-#pragma unroll 1
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool block_level = j >= 128;
-            if (block_level || prev_block_level) __syncthreads();
-            else gs2m_wave_sync();
-            prev_block_level = block_level;
-            unsigned long long a[PAIRS], b[PAIRS];
-            int ia[PAIRS], ib[PAIRS];
-#pragma unroll
-            for (int m = 0; m < PAIRS; ++m) {
-                const int p = tid + 256 * m;
-                ia[m] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                ib[m] = ia[m] | j;
-                if (p < NP2 / 2) {
-                    a[m] = s[ia[m]];
-                    b[m] = s[ib[m]];
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < PAIRS; ++m) {
-                const int p = tid + 256 * m;
-                if (p < NP2 / 2) {
-                    const bool up = (ia[m] & k) == 0;
-                    if ((a[m] > b[m]) == up) {
-                        s[ia[m]] = b[m];
-                        s[ib[m]] = a[m];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-GS2M_DEVICE void bitonic_lds_dispatch(unsigned long long* s, int np2, int tid) {
-    switch (np2) {
-        case 2: bitonic_lds<2>(s, tid); break;
-        case 4: bitonic_lds<4>(s, tid); break;
-        case 8: bitonic_lds<8>(s, tid); break;
-        case 16: bitonic_lds<16>(s, tid); break;
-        case 32: bitonic_lds<32>(s, tid); break;
-        case 64: bitonic_lds<64>(s, tid); break;
-        case 128: bitonic_lds<128>(s, tid); break;
-        case 256: bitonic_lds<256>(s, tid); break;
-        case 512: bitonic_lds<512>(s, tid); break;
-        case 1024: bitonic_lds<1024>(s, tid); break;
-        case 2048: bitonic_lds<2048>(s, tid); break;
-        default: bitonic_lds<4096>(s, tid); break;
-    }
+// ---- register-blocked bitonic sort -----------------------------------------------------------
+// Thread t holds E consecutive elements v[0..E) = elements t*E .. t*E+E-1 of the network.  A stage with
+// partner distance j is
+//   j <  E          : a compare-exchange between two registers of the same lane (no data movement);
+//   E <= j < 64 E   : the partner element sits in lane ^ (j/E) at the same register slot: one cross-lane
+//                     exchange per register (no LDS banks involved);
+//   j >= 64 E       : (workgroup sort only) the partner is in another wave: through LDS, transposed layout
+//                     s[r * THREADS + t] (conflict-free), 3 such stages for any size up to 4096.
+// For 256 keys on one wave (E = 4) 15 of the 36 stages are register-only and none touches LDS memory
+// (the all-LDS network it replaces: 36 stages x 4 ds_read_b64 + up to 4 ds_write_b64 per lane, 39 % of the
+// LDS cycles lost to bank conflicts -- PMC, profiles/).  Direction of element i in phase k: ascending iff
+// (i & k) == 0; the element keeps the minimum iff (it is the lower index of its pair) == ascending.
+GS2M_DEVICE void cmpx_keep(unsigned long long& a, unsigned long long p, bool keep_min) {
+    const bool p_less = p < a;
+    a = (p_less == keep_min) ? p : a;
 }
 
-// Small tiles (2 <= n <= GS2M_SORT_WAVE): ONE WAVE per (tile, view), 64-thread workgroups, 4 KiB of
-// LDS -> up to 32 resident waves per CU, and no workgroup barrier anywhere: the whole array belongs
-// to the wave.  NP2 is a template parameter so the pair loop unrolls and the LDS accesses of one
-// stage are issued back to back.
-#define GS2M_SORT_WAVE 512
-template <int NP2>
-GS2M_DEVICE void bitonic_wave(unsigned long long* s, int lane) {
-#pragma unroll 1
-    for (int k = 2; k <= NP2; k <<= 1) {
-#pragma unroll 1
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            gs2m_wave_sync();
-            constexpr int PAIRS = (NP2 / 2 + 63) / 64;
-            unsigned long long a[PAIRS], b[PAIRS];
-            int ia[PAIRS], ib[PAIRS];
+// stage (K, J) and, recursively, the smaller strides of phase K on the elements of one wave (compile-time
+// recursion: every register index is a constant); gtid = index of the thread in the sort
+template <int E, int K, int J>
+GS2M_DEVICE void bitonic_stages_wave(unsigned long long (&v)[E], int gtid, int lane) {
+    if constexpr (J >= 1) {
+        if constexpr (J >= E) {
+            constexpr int d = J / E;
+            const bool up = ((gtid * E) & K) == 0;
+            const bool keep_min = ((lane & d) == 0) == up;
 #pragma unroll
-            for (int m = 0; m < PAIRS; ++m) {
-                const int p = lane + 64 * m;
-                ia[m] = ((p & ~(j - 1)) << 1) | (p & (j - 1));
-                ib[m] = ia[m] | j;
-                if (p < NP2 / 2) {
-                    a[m] = s[ia[m]];
-                    b[m] = s[ib[m]];
-                }
-            }
+            for (int r = 0; r < E; ++r) cmpx_keep(v[r], gs2m_shfl_xor(v[r], d), keep_min);
+        } else {
 #pragma unroll
-            for (int m = 0; m < PAIRS; ++m) {
-                const int p = lane + 64 * m;
-                if (p < NP2 / 2) {
-                    const bool up = (ia[m] & k) == 0;
-                    if ((a[m] > b[m]) == up) {
-                        s[ia[m]] = b[m];
-                        s[ib[m]] = a[m];
-                    }
+            for (int r = 0; r < E; ++r) {
+                if ((r & J) == 0) {
+                    const bool up = K < E ? ((r & K) == 0) : (((gtid * E) & K) == 0);
+                    const unsigned long long a = v[r], b = v[r | J];
+                    const bool sw = (b < a) == up;
+                    v[r] = sw ? b : a;
+                    v[r | J] = sw ? a : b;
                 }
             }
         }
+        bitonic_stages_wave<E, K, J / 2>(v, gtid, lane);
     }
-    gs2m_wave_sync();
+}
+// phase K restricted to the strides that stay inside a wave (<= 32 E)
+template <int E, int K>
+GS2M_DEVICE void bitonic_phase_wave(unsigned long long (&v)[E], int gtid, int lane) {
+    bitonic_stages_wave<E, K, (K / 2 < 32 * E ? K / 2 : 32 * E)>(v, gtid, lane);
+}
+
+// whole sort of 64*E keys held by one wave
+template <int E>
+GS2M_DEVICE void bitonic_wave_regs(unsigned long long (&v)[E], int lane) {
+    bitonic_phase_wave<E, 2>(v, lane, lane);
+    if constexpr (E * 64 >= 4) bitonic_phase_wave<E, 4>(v, lane, lane);
+    if constexpr (E * 64 >= 8) bitonic_phase_wave<E, 8>(v, lane, lane);
+    if constexpr (E * 64 >= 16) bitonic_phase_wave<E, 16>(v, lane, lane);
+    if constexpr (E * 64 >= 32) bitonic_phase_wave<E, 32>(v, lane, lane);
+    if constexpr (E * 64 >= 64) bitonic_phase_wave<E, 64>(v, lane, lane);
+    if constexpr (E * 64 >= 128) bitonic_phase_wave<E, 128>(v, lane, lane);
+    if constexpr (E * 64 >= 256) bitonic_phase_wave<E, 256>(v, lane, lane);
+    if constexpr (E * 64 >= 512) bitonic_phase_wave<E, 512>(v, lane, lane);
+    if constexpr (E * 64 >= 1024) bitonic_phase_wave<E, 1024>(v, lane, lane);
+}
+
+// one cross-wave stage (stride j >= 64 E) of phase K through LDS; 256 threads, s holds 256 * E keys
+template <int E>
+GS2M_DEVICE void bitonic_stage_block(unsigned long long (&v)[E], unsigned long long* s, int tid, int K, int j) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) s[r * 256 + tid] = v[r];
+    __syncthreads();
+    const int dt = j / E;
+    const bool up = ((tid * E) & K) == 0;
+    const bool keep_min = ((tid & dt) == 0) == up;
+#pragma unroll
+    for (int r = 0; r < E; ++r) cmpx_keep(v[r], s[r * 256 + (tid ^ dt)], keep_min);
+}
+
+// whole sort of 256*E keys held by a 256-thread workgroup (E = 4, 8, 16 -> 1024, 2048, 4096 keys)
+template <int E>
+GS2M_DEVICE void bitonic_block_regs(unsigned long long (&v)[E], unsigned long long* s, int tid) {
+    const int lane = tid & 63;
+    bitonic_phase_wave<E, 2>(v, tid, lane);
+    bitonic_phase_wave<E, 4>(v, tid, lane);
+    bitonic_phase_wave<E, 8>(v, tid, lane);
+    bitonic_phase_wave<E, 16>(v, tid, lane);
+    bitonic_phase_wave<E, 32>(v, tid, lane);
+    bitonic_phase_wave<E, 64>(v, tid, lane);
+    bitonic_phase_wave<E, 128>(v, tid, lane);
+    bitonic_phase_wave<E, 256>(v, tid, lane);
+    if constexpr (64 * E >= 512) bitonic_phase_wave<E, 512>(v, tid, lane);
+    if constexpr (64 * E >= 1024) bitonic_phase_wave<E, 1024>(v, tid, lane);
+    // phases 128 E and 256 E: strides 64 E (and 128 E) cross waves
+    bitonic_stage_block<E>(v, s, tid, 128 * E, 64 * E);
+    bitonic_phase_wave<E, 128 * E>(v, tid, lane);
+    bitonic_stage_block<E>(v, s, tid, 256 * E, 128 * E);
+    bitonic_stage_block<E>(v, s, tid, 256 * E, 64 * E);
+    bitonic_phase_wave<E, 256 * E>(v, tid, lane);
+}
+
+// Small tiles (2 <= n <= GS2M_SORT_WAVE): ONE WAVE per (tile, view), 64-thread workgroups, no LDS and no
+// barrier: E = 1, 2, 4, 8 keys per lane for n <= 64, 128, 256, 512.
+#define GS2M_SORT_WAVE 512
+template <int E>
+GS2M_DEVICE void sort_wave_regs(unsigned long long* __restrict__ kv, int n, int lane) {
+    unsigned long long v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = lane * E + r;
+        v[r] = i < n ? kv[i] : ~0ull;
+    }
+    bitonic_wave_regs<E>(v, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = lane * E + r;
+        if (i < n) kv[i] = v[r];
+    }
 }
 
 GS2M_KERNEL void __launch_bounds__(64)
 k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
                    unsigned cap) {
-    __shared__ unsigned long long s[GS2M_SORT_WAVE];
     const int lane = (int)threadIdx.x;
     const int t = (int)blockIdx.x, v = (int)blockIdx.y;
     unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
@@ -214,24 +228,29 @@ k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __rest
     const int n = (int)(e - b);
     if (n <= 1 || n > GS2M_SORT_WAVE) return;  // larger tiles: k_sort_tiles
     unsigned long long* kv = keys + (size_t)v * cap + b;
-    int np2 = 2;
-    while (np2 < n) np2 <<= 1;
-    for (int i = lane; i < np2; i += 64) s[i] = i < n ? kv[i] : ~0ull;
-    switch (np2) {
-        case 2: bitonic_wave<2>(s, lane); break;
-        case 4: bitonic_wave<4>(s, lane); break;
-        case 8: bitonic_wave<8>(s, lane); break;
-        case 16: bitonic_wave<16>(s, lane); break;
-        case 32: bitonic_wave<32>(s, lane); break;
-        case 64: bitonic_wave<64>(s, lane); break;
-        case 128: bitonic_wave<128>(s, lane); break;
-        case 256: bitonic_wave<256>(s, lane); break;
-        default: bitonic_wave<512>(s, lane); break;
-    }
-    for (int i = lane; i < n; i += 64) kv[i] = s[i];
+    if (n <= 64) sort_wave_regs<1>(kv, n, lane);
+    else if (n <= 128) sort_wave_regs<2>(kv, n, lane);
+    else if (n <= 256) sort_wave_regs<4>(kv, n, lane);
+    else sort_wave_regs<8>(kv, n, lane);
 }
 
-// One workgroup per (tile, view).  n <= GS2M_SORT_LDS: bitonic in LDS.  Larger tiles: LDS-sorted
+template <int E>
+GS2M_DEVICE void sort_block_regs(unsigned long long* __restrict__ kv, int n, unsigned long long* s, int tid) {
+    unsigned long long v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = tid * E + r;
+        v[r] = i < n ? kv[i] : ~0ull;
+    }
+    bitonic_block_regs<E>(v, s, tid);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = tid * E + r;
+        if (i < n) kv[i] = v[r];
+    }
+}
+
+// One workgroup per (tile, view).  n <= GS2M_SORT_LDS: register-blocked bitonic (3 stages through LDS).  Larger tiles: LDS-sorted
 // runs of GS2M_SORT_LDS, then rank-based merge passes through HBM (keys <-> tmp) by the same
 // workgroup (keys are unique, so rank = index in own run + lower_bound in the sibling run).
 GS2M_KERNEL void __launch_bounds__(256)
@@ -252,11 +271,9 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
     for (int run = 0; run < nruns; ++run) {
         const int r0 = run * GS2M_SORT_LDS;
         const int rn = n - r0 < GS2M_SORT_LDS ? n - r0 : GS2M_SORT_LDS;
-        int np2 = 2;
-        while (np2 < rn) np2 <<= 1;
-        for (int i = tid; i < np2; i += 256) s[i] = i < rn ? kv[r0 + i] : ~0ull;
-        bitonic_lds_dispatch(s, np2, tid);
-        for (int i = tid; i < rn; i += 256) kv[r0 + i] = s[i];
+        if (rn <= 1024) sort_block_regs<4>(kv + r0, rn, s, tid);
+        else if (rn <= 2048) sort_block_regs<8>(kv + r0, rn, s, tid);
+        else sort_block_regs<16>(kv + r0, rn, s, tid);
         __syncthreads();
     }
     if (nruns == 1) return;
