@@ -174,7 +174,8 @@ def main():
     N_eye = [float(x) for x in num_rendered0]           # instances produced by this build (culling mode)
     img = 12.0 * Wd * Ht
     alg = {
-        "project_count": 44.0 * cfg.P + 192.0 * p_vis_union + 40.0 * sum(p_vis),
+        "project": 44.0 * cfg.P + 192.0 * p_vis_union + 40.0 * sum(p_vis),
+        "count_tiles": 16.0 * 2 * cfg.P + 32.0 * sum(p_vis),   # rect of every Gaussian + geometry half of the visible ones
         "scatter": 12.0 * sum(N_eye),
         "sort_tiles": 24.0 * sum(N_eye),
         "blend": 40.0 * sum(N_eye) + 2 * img,

@@ -35,7 +35,7 @@ OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_DEBUG_SYNC = 3
 OPT_STAGE_TIMING = 4
-RASTER_STAGES = ("project_count", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend")
+RASTER_STAGES = ("project", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend", "count_tiles")
 TSDF_STAGES = ("tsdf_touch", "tsdf_integrate")
 
 _PROTOS = {

@@ -151,6 +151,7 @@ static void geometry(int P, int* chunk, int* n_wg) {
     int c = (P + target - 1) / target;
     c = (c + 255) / 256 * 256;
     if (c < 256) c = 256;
+    if (c > 65280) c = 65280;  // k_count_tiles keeps 16-bit per-tile counters per workgroup
     *chunk = c;
     *n_wg = (P + c - 1) / c;
     if (*n_wg < 1) *n_wg = 1;
@@ -230,14 +231,14 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
     const int tiles = gx * gy;
-    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles);            // scatter: cursors + wave staging
-    const size_t lds_p = gs2m_project_lds_bytes(nv, tiles);          // project: histogram + wave staging
-    if (lds_p > 160 * 1024) {
-        gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile histogram", W, H, nv, tiles);
-        return 1;
-    }
     int chunk, n_wg;
     geometry(g.P, &chunk, &n_wg);
+    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles);            // scatter: u32 cursors + wave staging
+    const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, gs2m_count_threads(chunk));  // count: u16 histogram + staging
+    if (lds > 160 * 1024 || lds_p > 160 * 1024) {
+        gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile cursors", W, H, nv, tiles);
+        return 1;
+    }
     if (r->inst_cap == 0) {
         // first call: 4 instances per Gaussian, at least 64k
         int64_t guess = (int64_t)g.P * 4;
@@ -254,11 +255,16 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
 #endif
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
-        if (gs2m_launch_project_count(nv, n_wg, lds_p, st, g, r->d_cams, chunk, r->d_recs, out_radii, r->d_hist,
-                                      r->d_tilemask, cull_arg_p))
+        gs2m_launch_project(nv, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p);
+    }
+    if (dbg_check(r, st, "project")) return 1;
+    {
+        StageTimer tm(r, st, GS2M_STAGE_COUNT);
+        if (gs2m_launch_count_tiles(nv, n_wg, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
+                                    cull_arg_p))
             return 1;
     }
-    if (dbg_check(r, st, "project_count")) return 1;
+    if (dbg_check(r, st, "count_tiles")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_COLSCAN);
         gs2m_launch_hist_colscan(st, nv, r->d_hist, n_wg, tiles, r->d_tile_count);
@@ -434,9 +440,9 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     g.raw = gs->raw;
     g.scale_modifier = scale_modifier;
     const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
-    // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS histogram allows
+    // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS tile cursors of the scatter allow
     int per = GS2M_MAX_VIEWS;
-    while (per > 1 && gs2m_project_lds_bytes(per, tiles) > 160 * 1024) per--;
+    while (per > 1 && gs2m_scatter_lds_bytes(per, tiles) > 160 * 1024) per--;
     for (int v0 = 0; v0 < n_views; v0 += per) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
         for (int k = 0; k < nv; ++k) {

@@ -1,4 +1,5 @@
 // raster_blend.hip -- compositing stage (default FMA contraction; VALU-bound inner loop).
+#include <cstdlib>
 #include "raster_blend.h"
 #include "raster_internal.h"
 

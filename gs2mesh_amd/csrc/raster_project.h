@@ -84,7 +84,7 @@ struct WaveStage {
     unsigned heads[130];        // bit i: item i is the first item of an owner (+ slack for the 64-bit window)
     unsigned pad[2];
 };
-#define GS2M_STAGE_BYTES (4 * (int)sizeof(WaveStage))
+#define GS2M_STAGE_BYTES_PER_WAVE ((int)sizeof(WaveStage))
 
 GS2M_DEVICE unsigned long long lanes_le(int lane) { return (2ull << lane) - 1ull; }
 GS2M_DEVICE unsigned long long lanes_lt(int lane) { return (1ull << lane) - 1ull; }
@@ -112,32 +112,22 @@ GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
     return x;
 }
 
+// Projection + colour, one thread per Gaussian -- a streaming kernel (no LDS, no loop): activations, Sigma once
+// for all views of the batch, EWA projection, SH colour, the (cull-tightened) tile rect -> GeomRec.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(256)
-k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n_wg, GeomRec* __restrict__ recs,
-                int* __restrict__ radii, unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask,
-                int exact_cull) {
-    GS2M_DYN_LDS(unsigned, lds);
+k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
+          int exact_cull) {
 #ifdef GS2M_DEV_ABLATE
-    const int abl = exact_cull >> 8;  // 1: no tile expansion, 2: no SH/colour, 4: no hist row write, 8: no rec write
+    const int abl = exact_cull >> 8;  // 2: no SH/colour, 8: no rec write
     exact_cull &= 1;
 #else
     const int abl = 0;
 #endif
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int gx = cams[0].gx, gy = cams[0].gy;
-    const int tiles = gx * gy;
-    unsigned* lhist = lds;
-    WaveStage* stage = reinterpret_cast<WaveStage*>(lds + ((NV * tiles + 3) & ~3)) + wave;
-    for (int i = tid; i < NV * tiles; i += 256) lhist[i] = 0u;
-    __syncthreads();
-    const int begin = (int)blockIdx.x * chunk;
-    const int end = gs2m_imin(g.P, begin + chunk);
     const int ncoef = (g.D + 1) * (g.D + 1);
-    for (int base = begin; base < end; base += 256) {
-        const int gi = base + tid;
-        const bool valid = gi < end;
+    {
+        const int gi = (int)(blockIdx.x * 256u + threadIdx.x);
+        const bool valid = gi < g.P;
         ProjView pv[NV];
         float op = 0.0f, thr = 0.0f;
 #pragma unroll
@@ -297,13 +287,83 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                 r4[2] = w2;
             }
         }
+    }
+}
+
+// Tile counting: same Gaussian -> workgroup assignment as k_scatter.  Re-reads the geometry half of the
+// GeomRecs written by k_project, expands every rect into (Gaussian, tile) pairs with the balanced walk,
+// bumps the workgroup-private LDS tile histogram, records the kept tiles of small rects as bit masks and
+// writes the workgroup's histogram row.
+template <int NV>
+GS2M_KERNEL void __launch_bounds__(1024)
+k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
+              unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull) {
+    GS2M_DYN_LDS(unsigned, lds);
+#ifdef GS2M_DEV_ABLATE
+    const int abl = exact_cull >> 8;  // 1: no tile expansion, 4: no hist row write
+    exact_cull &= 1;
+#else
+    const int abl = 0;
+#endif
+    struct { int P; } g = {P};
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int gx = cams[0].gx, gy = cams[0].gy;
+    const int tiles = gx * gy;
+    // workgroup-private tile histogram, two 16-bit counters per word (a workgroup owns `chunk` <= 65535
+    // Gaussians and a Gaussian counts at most once per tile): half the LDS -> twice the resident waves
+    const int nthreads = (int)blockDim.x;
+    const int hw = (tiles + 1) >> 1;  // words per view
+    unsigned* lhist = lds;
+    WaveStage* stage = reinterpret_cast<WaveStage*>(lds + ((NV * hw + 3) & ~3)) + wave;
+    for (int i = tid; i < NV * hw; i += nthreads) lhist[i] = 0u;
+    __syncthreads();
+    const int begin = (int)blockIdx.x * chunk;
+    const int end = gs2m_imin(P, begin + chunk);
+    for (int base = begin; base < end; base += nthreads) {
+        const int gi = base + tid;
+        const bool valid = gi < end;
+        struct {
+            float mx, my, ca, cb, cc;
+            int x0, y0, x1, y1;
+            bool ok;
+        } pv[NV];
+        float thr = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            pv[v].ok = false;
+            pv[v].x0 = pv[v].y0 = pv[v].x1 = pv[v].y1 = 0;
+            pv[v].mx = pv[v].my = pv[v].ca = pv[v].cb = pv[v].cc = 0.0f;
+            if (valid) {
+                const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi);
+                const float4 w2 = r4[2];
+                const unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w);
+                pv[v].x0 = (int)(rect0 & 0xffffu);
+                pv[v].y0 = (int)(rect0 >> 16);
+                pv[v].x1 = (int)(rect1 & 0xffffu);
+                pv[v].y1 = (int)(rect1 >> 16);
+                pv[v].ok = pv[v].x1 > pv[v].x0 && pv[v].y1 > pv[v].y0;
+                if (pv[v].ok) {
+                    const float4 w0 = r4[0];
+                    const float4 w1 = r4[1];
+                    pv[v].mx = w0.x;
+                    pv[v].my = w0.y;
+                    pv[v].ca = w0.z;
+                    pv[v].cb = w0.w;
+                    pv[v].cc = w1.x;
+                    if (exact_cull) thr = cull_threshold(w1.y);
+                } else {
+                    pv[v].x0 = pv[v].y0 = pv[v].x1 = pv[v].y1 = 0;
+                }
+            }
+        }
         // ---- balanced (Gaussian, tile) expansion, one view at a time (wave collectives: every lane) ----
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
             const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
             if ((abl & 1) || gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
-            unsigned* hh = lhist + v * tiles;
+            unsigned* hh = lhist + v * hw;
             const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
             // ---- small rects: flattened item space ----
             const bool small = area != 0u && area <= 64u;
@@ -354,7 +414,7 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                         if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
                             keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
                                                        stage->cc[kk], stage->thr[kk], tx, ty);
-                        if (keep) atomicAdd(&hh[ty * gx + tx], 1u);
+                        if (keep) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
                     }
                     // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
                     const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
@@ -384,16 +444,16 @@ k_project_count(GaussIn g, const CamUniform* __restrict__ cams, int chunk, int n
                     unsigned rx, ry;
                     rect_coords(li, ow, oinv, rx, ry);
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, othr, tx, ty)) atomicAdd(&hh[ty * gx + tx], 1u);
+                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, othr, tx, ty)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
                 }
             }
         }
     }
     __syncthreads();
     if (abl & 4) return;
-    for (int i = tid; i < NV * tiles; i += 256) {
+    for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
-        hist[((size_t)v * n_wg + blockIdx.x) * tiles + t] = lhist[i];
+        hist[((size_t)v * n_wg + blockIdx.x) * tiles + t] = (lhist[v * hw + (t >> 1)] >> ((t & 1) << 4)) & 0xffffu;
     }
 }
 

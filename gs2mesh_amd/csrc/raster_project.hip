@@ -2,33 +2,43 @@
 #include "raster_project.h"
 #include "raster_internal.h"
 
-size_t gs2m_project_lds_bytes(int nv, int tiles) {
-    return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + GS2M_STAGE_BYTES;
+// k_count_tiles: threads per workgroup = the workgroup's chunk of Gaussians, at most 1024
+int gs2m_count_threads(int chunk) { return chunk < 1024 ? (chunk + 63) / 64 * 64 : 1024; }
+size_t gs2m_count_lds_bytes(int nv, int tiles, int threads) {
+    return (size_t)((nv * ((tiles + 1) / 2) + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_STAGE_BYTES_PER_WAVE;
 }
 
 size_t gs2m_scatter_lds_bytes(int nv, int tiles) {
     return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + GS2M_SCATTER_STAGE_BYTES;
 }
 
-int gs2m_launch_project_count(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GaussIn& g,
-                              const CamUniform* cams, int chunk, GeomRec* recs, int* radii, unsigned* hist,
-                              unsigned long long* tilemask, int exact_cull) {
+void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
+                         int exact_cull) {
+    const unsigned n = (unsigned)((g.P + 255) / 256);
+    if (n == 0) return;
+    if (nv == 2) GS2M_LAUNCH((k_project<2>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else GS2M_LAUNCH((k_project<1>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+}
+
+int gs2m_launch_count_tiles(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+                            const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
+                            int exact_cull) {
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_project_count<2>,
+        hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_count_tiles<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-                               : hipFuncSetAttribute((const void*)k_project_count<1>,
+                               : hipFuncSetAttribute((const void*)k_count_tiles<1>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
-            gs2m_set_error("hipFuncSetAttribute(k_project_count, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+            gs2m_set_error("hipFuncSetAttribute(k_count_tiles, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
             return 1;
         }
     }
     if (nv == 2)
-        GS2M_LAUNCH((k_project_count<2>), dim3(n_wg), dim3(256), lds_bytes, st, g, cams, chunk, n_wg, recs, radii,
-                    hist, tilemask, exact_cull);
+        GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
+                    exact_cull);
     else
-        GS2M_LAUNCH((k_project_count<1>), dim3(n_wg), dim3(256), lds_bytes, st, g, cams, chunk, n_wg, recs, radii,
-                    hist, tilemask, exact_cull);
+        GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
+                    exact_cull);
     return 0;
 }
 

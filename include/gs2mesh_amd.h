@@ -68,13 +68,14 @@ enum {
 
 /* Stage order of gs2m_raster_stage_times */
 enum {
-    GS2M_STAGE_PROJECT = 0, /* k_project_count */
+    GS2M_STAGE_PROJECT = 0, /* k_project       */
     GS2M_STAGE_COLSCAN = 1, /* k_hist_colscan  */
     GS2M_STAGE_TILESCAN = 2,/* k_tile_scan     */
     GS2M_STAGE_SCATTER = 3, /* k_scatter       */
     GS2M_STAGE_SORT = 4,    /* k_sort_tiles    */
     GS2M_STAGE_BLEND = 5,   /* k_blend_*       */
-    GS2M_N_STAGES = 6
+    GS2M_STAGE_COUNT = 6,   /* k_count_tiles (runs between PROJECT and COLSCAN) */
+    GS2M_N_STAGES = 7
 };
 
 int gs2m_raster_create(gs2m_raster** out, int device);

@@ -25,7 +25,7 @@ for d in glob.glob(os.path.join(src, "pmc_*")):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if k.startswith("k_")}
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-stage_of = {"k_project_count<2>": "project_count", "k_hist_colscan": "hist_colscan", "k_tile_scan": "tile_scan",
+stage_of = {"k_project<2>": "project", "k_count_tiles<2>": "count_tiles", "k_hist_colscan": "hist_colscan", "k_tile_scan": "tile_scan",
             "k_scatter<2>": "scatter", "k_sort_tiles_small": "sort_tiles", "k_tsdf_touch": "tsdf_touch",
             "k_tsdf_integrate": "tsdf_integrate"}
 bench = json.load(open(os.path.join(src, "bench.json"))) if os.path.exists(os.path.join(src, "bench.json")) else {}
