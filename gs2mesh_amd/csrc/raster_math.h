@@ -137,28 +137,33 @@ GS2M_DEVICE float sh_channel(int deg, const float* sh, int c, float x, float y, 
 GS2M_DEVICE float q_form(float a, float b, float c, float dx, float dy) {
     return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
 }
-GS2M_DEVICE float edge_min_x(float a, float b, float c, float dy, float x0, float x1) {
-    float dxs = a > 0.0f ? -(b * dy) / a : x0;
+// rx = -b / a, ry = -b / c: slopes of the minimiser lines, formed once per Gaussian (cull_slopes)
+GS2M_DEVICE float edge_min_x(float a, float b, float c, float rx, float dy, float x0, float x1) {
+    float dxs = a > 0.0f ? rx * dy : x0;
     dxs = fminf(x1, fmaxf(x0, dxs));
     return q_form(a, b, c, dxs, dy);
 }
-GS2M_DEVICE float edge_min_y(float a, float b, float c, float dx, float y0, float y1) {
-    float dys = c > 0.0f ? -(b * dx) / c : y0;
+GS2M_DEVICE float edge_min_y(float a, float b, float c, float ry, float dx, float y0, float y1) {
+    float dys = c > 0.0f ? ry * dx : y0;
     dys = fminf(y1, fmaxf(y0, dys));
     return q_form(a, b, c, dx, dys);
 }
+GS2M_DEVICE void cull_slopes(float ca, float cb, float cc, float& rx, float& ry) {
+    rx = -cb / ca;
+    ry = -cb / cc;
+}
 // thresh = ln(255*o)*1.0001 + 0.001 (precomputed per Gaussian), or < 0 if o*255 < 1.
-GS2M_DEVICE bool tile_may_contribute(float mx, float my, float ca, float cb, float cc, float thresh, int tx,
-                                     int ty) {
+GS2M_DEVICE bool tile_may_contribute(float mx, float my, float ca, float cb, float cc, float rx, float ry,
+                                     float thresh, int tx, int ty) {
     const float dx0 = mx - (float)(tx * GS2M_TILE + GS2M_TILE - 1);
     const float dx1 = mx - (float)(tx * GS2M_TILE);
     const float dy0 = my - (float)(ty * GS2M_TILE + GS2M_TILE - 1);
     const float dy1 = my - (float)(ty * GS2M_TILE);
     if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
-    float qmin = edge_min_x(ca, cb, cc, dy0, dx0, dx1);
-    qmin = fminf(qmin, edge_min_x(ca, cb, cc, dy1, dx0, dx1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, dx0, dy0, dy1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, dx1, dy0, dy1));
+    float qmin = edge_min_x(ca, cb, cc, rx, dy0, dx0, dx1);
+    qmin = fminf(qmin, edge_min_x(ca, cb, cc, rx, dy1, dx0, dx1));
+    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx0, dy0, dy1));
+    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx1, dy0, dy1));
     return qmin <= thresh;
 }
 GS2M_DEVICE float cull_threshold(float opacity) {

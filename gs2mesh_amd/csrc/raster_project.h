@@ -77,7 +77,7 @@ GS2M_DEVICE void project_view(const CamUniform& cam, float px, float py, float p
 // Each kept pair bumps the workgroup's LDS tile histogram; the kept tiles of a small rect are recorded as a
 // bit mask (assembled from ballots by the first lane of each owner's run) that the scatter kernel replays.
 struct WaveStage {
-    float mx[64], my[64], ca[64], cb[64], cc[64], thr[64];  // indexed by owner rank k
+    float mx[64], my[64], ca[64], cb[64], cc[64], thr[64], rx[64], ry[64];  // indexed by owner rank k
     unsigned swh[64];   // first item (16 bits) | w << 16 | h << 24
     unsigned xy0[64];   // x0 | y0 << 16
     unsigned mlo[64], mhi[64];  // kept-tile mask of the owner's rect
@@ -385,6 +385,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                     stage->cb[k] = pv[v].cb;
                     stage->cc[k] = pv[v].cc;
                     stage->thr[k] = thr;
+                    cull_slopes(pv[v].ca, pv[v].cb, pv[v].cc, stage->rx[k], stage->ry[k]);
                     stage->swh[k] = start | (w << 16) | (h << 24);
                     stage->xy0[k] = xy0;
                     stage->mlo[k] = 0u;
@@ -413,7 +414,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                         keep = true;
                         if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
                             keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
-                                                       stage->cc[kk], stage->thr[kk], tx, ty);
+                                                       stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty);
                         if (keep) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
                     }
                     // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
@@ -440,11 +441,13 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                 const float omx = gs2m_shfl(pv[v].mx, o), omy = gs2m_shfl(pv[v].my, o), oca = gs2m_shfl(pv[v].ca, o),
                             ocb = gs2m_shfl(pv[v].cb, o), occ = gs2m_shfl(pv[v].cc, o), othr = gs2m_shfl(thr, o);
                 const float oinv = gs2m_fast_rcp((float)ow);
+                float orx, ory;
+                cull_slopes(oca, ocb, occ, orx, ory);
                 for (unsigned li = (unsigned)lane; li < oa; li += 64u) {
                     unsigned rx, ry;
                     rect_coords(li, ow, oinv, rx, ry);
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, othr, tx, ty)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
+                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
                 }
             }
         }
@@ -580,12 +583,14 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                     cc = w1.x;
                     thr = cull_threshold(w1.y);
                 }
+                float srx, sry;
+                cull_slopes(ca, cb, cc, srx, sry);
                 const float oinv = gs2m_fast_rcp((float)ow);
                 for (unsigned li = (unsigned)lane; li < oa; li += 64u) {
                     unsigned rx, ry;
                     rect_coords(li, ow, oinv, rx, ry);
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, thr, tx, ty)) {
+                    if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, srx, sry, thr, tx, ty)) {
                         const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
                         if (pos < cap && !(abl & 1)) kv[pos] = key;
                     }

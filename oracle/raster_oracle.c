@@ -491,14 +491,15 @@ static float q_form(float a, float b, float c, float dx, float dy) {
     return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
 }
 /* min over t in [t0,t1] of q along an axis-aligned segment */
-static float edge_min_x(float a, float b, float c, float dy, float x0, float x1) {
-    /* q(dx) = 0.5 a dx^2 + b dy dx + 0.5 c dy^2, minimiser dx* = -b dy / a */
-    float dxs = a > 0.0f ? -(b * dy) / a : x0;
+static float edge_min_x(float a, float b, float c, float rx, float dy, float x0, float x1) {
+    /* q(dx) = 0.5 a dx^2 + b dy dx + 0.5 c dy^2, minimiser dx* = (-b / a) dy; rx = -b / a is formed once per
+       Gaussian (any point of the edge bounds the minimum from above, so its rounding only costs margin) */
+    float dxs = a > 0.0f ? rx * dy : x0;
     dxs = fminf(x1, fmaxf(x0, dxs));
     return q_form(a, b, c, dxs, dy);
 }
-static float edge_min_y(float a, float b, float c, float dx, float y0, float y1) {
-    float dys = c > 0.0f ? -(b * dx) / c : y0;
+static float edge_min_y(float a, float b, float c, float ry, float dx, float y0, float y1) {
+    float dys = c > 0.0f ? ry * dx : y0;
     dys = fminf(y1, fmaxf(y0, dys));
     return q_form(a, b, c, dx, dys);
 }
@@ -512,9 +513,10 @@ int oracle_tile_may_contribute(float mx, float my, float ca, float cb, float cc,
     if (!(opacity * 255.0f >= 1.0f)) return 0; /* alpha <= opacity < 1/255 everywhere */
     const float thresh = logf(opacity * 255.0f) * 1.0001f + 0.001f;
     if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 1; /* centre inside */
-    float qmin = edge_min_x(ca, cb, cc, dy0, dx0, dx1);
-    qmin = fminf(qmin, edge_min_x(ca, cb, cc, dy1, dx0, dx1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, dx0, dy0, dy1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, dx1, dy0, dy1));
+    const float rx = -cb / ca, ry = -cb / cc;
+    float qmin = edge_min_x(ca, cb, cc, rx, dy0, dx0, dx1);
+    qmin = fminf(qmin, edge_min_x(ca, cb, cc, rx, dy1, dx0, dx1));
+    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx0, dy0, dy1));
+    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx1, dy0, dy1));
     return qmin <= thresh ? 1 : 0;
 }
