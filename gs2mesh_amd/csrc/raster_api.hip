@@ -141,12 +141,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
 }
 
 static void geometry(int P, int* chunk, int* n_wg) {
-    // ~512 workgroups (2 per CU), chunks a multiple of 256 Gaussians
+    // ~256 workgroups (one per CU: the per-workgroup tile histogram rows / cursors scale with their number;
+    // measured optimum on C2/C3), chunks a multiple of 256 Gaussians
     static int target = 0;
     if (!target) {
         const char* e = getenv("GS2M_NWG_TARGET");  // tuning knob
-        target = e ? atoi(e) : 512;
-        if (target < 1) target = 512;
+        target = e ? atoi(e) : 256;
+        if (target < 1) target = 256;
     }
     int c = (P + target - 1) / target;
     c = (c + 255) / 256 * 256;
@@ -233,7 +234,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     const int tiles = gx * gy;
     int chunk, n_wg;
     geometry(g.P, &chunk, &n_wg);
-    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles);            // scatter: u32 cursors + wave staging
+    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, gs2m_count_threads(chunk));  // scatter: u32 cursors + wave staging
     const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, gs2m_count_threads(chunk));  // count: u16 histogram + staging
     if (lds > 160 * 1024 || lds_p > 160 * 1024) {
         gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile cursors", W, H, nv, tiles);
@@ -442,7 +443,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
     // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS tile cursors of the scatter allow
     int per = GS2M_MAX_VIEWS;
-    while (per > 1 && gs2m_scatter_lds_bytes(per, tiles) > 160 * 1024) per--;
+    while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 1024) > 160 * 1024) per--;
     for (int v0 = 0; v0 < n_views; v0 += per) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
         for (int k = 0; k < nv; ++k) {

@@ -7,7 +7,7 @@
 
 struct CamUniformArg;
 
-size_t gs2m_scatter_lds_bytes(int nv, int tiles);
+size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads);
 void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
                          int exact_cull);
 int gs2m_launch_count_tiles(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,

@@ -465,7 +465,7 @@ struct ScatterStage {
     unsigned heads[130];
     unsigned pad[2];
 };
-#define GS2M_SCATTER_STAGE_BYTES (4 * (int)sizeof(ScatterStage))
+#define GS2M_SCATTER_STAGE_BYTES_PER_WAVE ((int)sizeof(ScatterStage))
 
 // Instance scatter: same Gaussian -> workgroup assignment as k_project_count; cursors start at
 // tile_start[v][t] + (exclusive prefix over workgroups, left in `hist` by k_hist_colscan).
@@ -473,7 +473,7 @@ struct ScatterStage {
 // although LDS-atomic arrival order is not).  Same balanced walk as k_project_count; rects of <= 64 tiles
 // replay the tile mask written there, larger ones repeat the same per-tile test.
 template <int NV>
-GS2M_KERNEL void __launch_bounds__(256)
+GS2M_KERNEL void __launch_bounds__(1024)
 k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
           const unsigned* __restrict__ hist, const unsigned* __restrict__ tile_start,
           const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
@@ -486,10 +486,11 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
     const int abl = 0;
 #endif
     const int tid = (int)threadIdx.x;
+    const int nthreads = (int)blockDim.x;
     const int gx = cams[0].gx, gy = cams[0].gy;
     const int tiles = gx * gy;
     if (!(abl & 4))
-    for (int i = tid; i < NV * tiles; i += 256) {
+    for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
         cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + blockIdx.x) * tiles + t];
     }
@@ -499,7 +500,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
     ScatterStage* stage = reinterpret_cast<ScatterStage*>(cursor + ((NV * tiles + 3) & ~3)) + wave;
     const int begin = (int)blockIdx.x * chunk;
     const int end = gs2m_imin(P, begin + chunk);
-    for (int base = begin; base < end; base += 256) {
+    for (int base = begin; base < end; base += nthreads) {
         const int gi = base + tid;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {

@@ -8,8 +8,8 @@ size_t gs2m_count_lds_bytes(int nv, int tiles, int threads) {
     return (size_t)((nv * ((tiles + 1) / 2) + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_STAGE_BYTES_PER_WAVE;
 }
 
-size_t gs2m_scatter_lds_bytes(int nv, int tiles) {
-    return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + GS2M_SCATTER_STAGE_BYTES;
+size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads) {
+    return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_SCATTER_STAGE_BYTES_PER_WAVE;
 }
 
 void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
@@ -56,10 +56,10 @@ int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, cons
         }
     }
     if (nv == 2)
-        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(256), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
                     tile_start, tilemask, keys, cap, exact_cull);
     else
-        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(256), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
                     tile_start, tilemask, keys, cap, exact_cull);
     return 0;
 }
