@@ -1,15 +1,15 @@
 // raster_project.h -- kernels of the projection / tile-counting / instance-scatter stages.
 //
 // Stage map (reference -> here):
-//   preprocessCUDA            forward.cu:155-256          -> k_project_count (fused: activations,
-//   cub InclusiveSum + D2H    rasterizer_impl.cu:277-281     Sigma once per Gaussian for all views
-//   duplicateWithKeys         rasterizer_impl.cu:70-111      of the batch, per-workgroup LDS tile
-//                                                            histogram instead of a per-Gaussian scan)
+//   preprocessCUDA            forward.cu:155-256          -> k_project (fused activations, Sigma once per
+//                                                            Gaussian for all views of the batch)
+//   cub InclusiveSum + D2H    rasterizer_impl.cu:277-281  -> k_count_tiles (per-workgroup LDS tile histogram
+//   duplicateWithKeys         rasterizer_impl.cu:70-111      instead of a per-Gaussian scan)
 //                                                         -> k_scatter (LDS cursors, 8-B keys)
 // Instead of emitting (tile<<32|depth, id) pairs in Gaussian order and radix-sorting 64-bit keys
 // through HBM 5-6 times, instances are counting-sorted by tile with workgroup-private LDS
-// histograms (160 KiB LDS holds a 40k-tile histogram), then depth-sorted per tile in LDS
-// (raster_sort.h).  The final order is identical to the reference's: ascending depth bits, ties
+// histograms (160 KiB LDS holds a 40k-tile cursor array), then depth-sorted per tile in
+// registers (raster_sort.h).  The final order is identical to the reference's: ascending depth bits, ties
 // by ascending Gaussian id (= what the stable radix sort over emission order produces).
 #pragma once
 #include "raster_math.h"
@@ -467,10 +467,10 @@ struct ScatterStage {
 };
 #define GS2M_SCATTER_STAGE_BYTES_PER_WAVE ((int)sizeof(ScatterStage))
 
-// Instance scatter: same Gaussian -> workgroup assignment as k_project_count; cursors start at
+// Instance scatter: same Gaussian -> workgroup assignment as k_count_tiles; cursors start at
 // tile_start[v][t] + (exclusive prefix over workgroups, left in `hist` by k_hist_colscan).
 // Key = depth_bits << 32 | gaussian_id (unique => order after the per-tile sort is deterministic
-// although LDS-atomic arrival order is not).  Same balanced walk as k_project_count; rects of <= 64 tiles
+// although LDS-atomic arrival order is not).  Same balanced walk as k_count_tiles; rects of <= 64 tiles
 // replay the tile mask written there, larger ones repeat the same per-tile test.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(1024)

@@ -11,6 +11,7 @@ from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableT
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C2"); ap.add_argument("--pairs", type=int, default=16)
 ap.add_argument("--streams", type=int, default=2); ap.add_argument("--tsdf", type=int, default=1)
+ap.add_argument("--blend", type=int, default=4); ap.add_argument("--fuse-prio", type=int, default=0)
 a = ap.parse_args()
 cfg = synthetic.CONFIGS[a.config]
 dev = torch.device("cuda:0")
@@ -28,13 +29,13 @@ intr = PinholeCameraIntrinsic(Wd, Ht, cfg.focal, cfg.focal, Wd / 2, Ht / 2)
 S = a.streams
 Rs, cols, rgbs, streams = [], [], [], []
 for j in range(S):
-    R = Rasterizer(0); R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+    R = Rasterizer(0); R.set_option(_lib.OPT_EXACT_TILE_CULL, 1); R.set_option(_lib.OPT_BLEND_VARIANT, a.blend)
     if j == 0: R.pack_sh(gd)
     Rs.append(R)
     cols.append(torch.empty((2, 3, Ht, Wd), dtype=torch.float32, device=dev))
     rgbs.append(torch.empty((2, Ht, Wd, 3), dtype=torch.uint8, device=dev))
     streams.append(torch.cuda.Stream())
-fuse_stream = torch.cuda.Stream()
+fuse_stream = torch.cuda.Stream(priority=a.fuse_prio)
 vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=(cfg.tsdf_n // 16) ** 3, device=0)
 for j in range(S):
     res = Rs[j].render_views(gd, cams[0], out_color=cols[j], out_rgb8=rgbs[j])
