@@ -1,9 +1,14 @@
 // raster_project.hip -- projection / counting / scatter stage (compiled with -ffp-contract=off).
+#include <cstdlib>
 #include "raster_project.h"
 #include "raster_internal.h"
 
 // k_count_tiles: threads per workgroup = the workgroup's chunk of Gaussians, at most 1024
-int gs2m_count_threads(int chunk) { return chunk < 1024 ? (chunk + 63) / 64 * 64 : 1024; }
+int gs2m_count_threads(int chunk) {
+    static const int cap = getenv("GS2M_MAX_WG_THREADS") ? atoi(getenv("GS2M_MAX_WG_THREADS")) : 1024;  // tuning knob
+    const int t = chunk < cap ? (chunk + 63) / 64 * 64 : cap;
+    return t < 64 ? 64 : t;
+}
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads) {
     return (size_t)((nv * ((tiles + 1) / 2) + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_STAGE_BYTES_PER_WAVE;
 }
