@@ -446,9 +446,10 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 1024) > 160 * 1024) per--;
     for (int v0 = 0; v0 < n_views; v0 += per) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
+        CamUniform cu[GS2M_MAX_VIEWS];
         for (int k = 0; k < nv; ++k) {
             const gs2m_camera& c = cams[v0 + k];
-            CamUniform u;
+            CamUniform& u = cu[k];
             memcpy(u.view, c.viewmatrix, sizeof(u.view));
             memcpy(u.proj, c.projmatrix, sizeof(u.proj));
             memcpy(u.campos, c.campos, sizeof(u.campos));
@@ -464,8 +465,8 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
             u.bg[1] = bg[1];
             u.bg[2] = bg[2];
             u.pad = 0;
-            gs2m_launch_set_camera(st, r->d_cams, k, u);
         }
+        gs2m_launch_set_cameras(st, r->d_cams, nv, cu);  // one launch for the views of the pass
         if (run_views(r, g, nv, W, H, out_color ? out_color + 3 * img * v0 : nullptr,
                       out_rgb8 ? out_rgb8 + 3 * img * v0 : nullptr,
                       out_radii ? out_radii + (size_t)gs->P * v0 : nullptr, v0, st))

@@ -661,8 +661,8 @@ GS2M_KERNEL void k_pack_camera(CamUniform* cams, int slot, const float* viewmatr
 // Same from HOST values carried in the kernel arguments (pipeline-level API): the launch
 // packet is the transport, so no pinned staging buffer / lifetime hazard.
 struct CamUniformArg {
-    CamUniform c;
+    CamUniform c[GS2M_MAX_VIEWS];
 };
-GS2M_KERNEL void k_set_camera(CamUniform* cams, int slot, CamUniformArg a) {
-    if (threadIdx.x == 0) cams[slot] = a.c;
+GS2M_KERNEL void k_set_cameras(CamUniform* cams, int n, CamUniformArg a) {
+    if ((int)threadIdx.x < n) cams[threadIdx.x] = a.c[threadIdx.x];
 }

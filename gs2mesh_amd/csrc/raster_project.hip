@@ -86,8 +86,8 @@ void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const f
                 tanfovy, W, H);
 }
 
-void gs2m_launch_set_camera(hipStream_t st, CamUniform* cams, int slot, const CamUniform& c) {
+void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamUniform* c) {
     CamUniformArg a;
-    a.c = c;
-    GS2M_LAUNCH(k_set_camera, dim3(1), dim3(64), 0, st, cams, slot, a);
+    for (int k = 0; k < GS2M_MAX_VIEWS; ++k) a.c[k] = c[k < n ? k : 0];
+    GS2M_LAUNCH(k_set_cameras, dim3(1), dim3(64), 0, st, cams, n, a);
 }
