@@ -10,9 +10,12 @@ import this package, and only as the checker.  The product package ``gs2mesh_amd
 does (tests/test_no_oracle_in_product.py greps for it).
 
 Parity status: SH->RGB, Sigma=R S^2 R^T and the camera matrices are pinned by golden
-vectors generated from the reference's own Python (tests/golden/make_golden.py).  The EWA
-projection, binning, compositing and the whole TSDF are "parity unpinned" (no second
-implementation / Open3D absent); they are covered by analytic known-answer tests.
+vectors generated from the reference's own Python (tests/golden/make_golden.py).  The whole
+rasteriser forward (projection, tile rects, binning order, compositing) is pinned against the
+REFERENCE'S OWN KERNELS compiled for the CPU (``oracle/_ref``: oracle/build_ref.py +
+oracle/ref_driver.cpp + oracle/ref_shim/; ``ref_forward`` below) and against golden vectors
+produced by them (tests/golden/ref_forward.npz).  The TSDF is "parity unpinned" (Open3D absent);
+it is covered by analytic known-answer tests.
 """
 from __future__ import annotations
 
@@ -295,3 +298,88 @@ def dist_multiplier(width, height, fx, fy, cx, cy):
     out = np.zeros((height, width), np.float32)
     tsdf_lib().oracle_dist_multiplier(int(width), int(height), float(fx), float(fy), float(cx), float(cy), _ptr(out))
     return out
+
+
+# ---- the reference's own kernels on the CPU (oracle/_ref) --------------------------------------
+_ref = None
+
+
+def ref_available(build: bool = True) -> bool:
+    """True if oracle/_ref/libref_raster.so exists (or can be built here: needs /root/reference)."""
+    from . import build_ref
+    if build:
+        try:
+            return build_ref.build() is not None
+        except Exception:
+            return False
+    return os.path.exists(build_ref.LIB)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        from . import build_ref
+        path = build_ref.build()
+        if path is None:
+            raise RuntimeError("oracle/_ref is not built and /root/reference is absent")
+        lib = C.CDLL(path)
+        lib.ref_forward.restype = C.c_longlong
+        lib.ref_forward.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + \
+            [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int] + \
+            [C.c_void_p] * 9 + [C.c_longlong, C.c_void_p]
+        lib.ref_mark_visible.restype = None
+        lib.ref_mark_visible.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _ref = lib
+    return _ref
+
+
+def ref_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, bg,
+                shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                sh_degree=3, scale_modifier=1.0):
+    """CudaRasterizer::Rasterizer::forward run by the reference's own kernels (oracle/ref_driver.cpp).
+    -> dict(color[3,H,W], radii, means2D, depths, cov3D, rgb, conic_opacity, tiles_touched, point_list, ranges,
+    num_rendered)."""
+    lib = ref_lib()
+    means3D = np.ascontiguousarray(means3D, np.float32)
+    P = means3D.shape[0]
+    shs = _opt(shs, np.float32)
+    M = 0 if shs is None else shs.shape[1]
+    colors_precomp = _opt(colors_precomp, np.float32)
+    scales = _opt(scales, np.float32)
+    rotations = _opt(rotations, np.float32)
+    cov3D_precomp = _opt(cov3D_precomp, np.float32)
+    opacities = np.ascontiguousarray(opacities, np.float32).reshape(-1)
+    vm = np.ascontiguousarray(viewmatrix, np.float32).reshape(16)
+    pm = np.ascontiguousarray(projmatrix, np.float32).reshape(16)
+    cp = np.ascontiguousarray(campos, np.float32).reshape(3)
+    bgc = np.ascontiguousarray(bg, np.float32).reshape(3)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    o = dict(color=np.zeros((3, H, W), np.float32), radii=np.zeros(P, np.int32), means2D=np.zeros((P, 2), np.float32),
+             depths=np.zeros(P, np.float32), cov3D=np.zeros((P, 6), np.float32), rgb=np.zeros((P, 3), np.float32),
+             conic_opacity=np.zeros((P, 4), np.float32), tiles_touched=np.zeros(P, np.uint32),
+             ranges=np.zeros((gx * gy, 2), np.uint32))
+    cap = max(1, 64 * P)
+    while True:
+        pl = np.zeros(cap, np.uint32)
+        n = lib.ref_forward(P, sh_degree, M, _ptr(bgc), int(W), int(H), _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                            _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                            _ptr(vm), _ptr(pm), _ptr(cp), float(tanfovx), float(tanfovy), 0, _ptr(o["color"]),
+                            _ptr(o["radii"]), _ptr(o["means2D"]), _ptr(o["depths"]), _ptr(o["cov3D"]), _ptr(o["rgb"]),
+                            _ptr(o["conic_opacity"]), _ptr(o["tiles_touched"]), _ptr(pl), cap, _ptr(o["ranges"]))
+        if n >= 0:
+            break
+        cap *= 4
+    o["point_list"] = pl[:n].copy()
+    o["num_rendered"] = int(n)
+    return o
+
+
+def ref_mark_visible(means3D, viewmatrix, projmatrix):
+    lib = ref_lib()
+    means3D = np.ascontiguousarray(means3D, np.float32)
+    P = means3D.shape[0]
+    vm = np.ascontiguousarray(viewmatrix, np.float32).reshape(16)
+    pm = np.ascontiguousarray(projmatrix, np.float32).reshape(16)
+    present = np.zeros(P, np.uint8)
+    lib.ref_mark_visible(P, _ptr(means3D), _ptr(vm), _ptr(pm), _ptr(present))
+    return present.astype(bool)

@@ -1,0 +1,3 @@
+/* cuda.h shim (see cuda_runtime.h) */
+#pragma once
+#include "cuda_runtime.h"

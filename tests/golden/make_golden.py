@@ -12,6 +12,8 @@ are independent pure-Python implementations of sub-steps of the hot path that im
                                                                (forward.cu:118-152)
   * GS/utils/graphics_utils.py:38-71 getWorld2View2 / getProjectionMatrix, combined as in
     GS/scene/cameras.py:54-57                              -> pins the per-view uniforms
+  * the rasteriser forward itself (forward.cu, rasterizer_impl.cu kernels), compiled for the CPU by
+    oracle/build_ref.py                                    -> pins projection / binning / compositing
   * gs2mesh_utils/transformation_utils.py:23-63,83-141,207-224 (eul2rotm, rotm2eul,
     convert_R_T_to_GS, RT_from_rot_pos, calculate_right_camera_pose) chained exactly as
     Renderer.__init__ / render_image_pair do (renderer_utils.py:132-141,178-206,378-386)
@@ -152,6 +154,30 @@ def main():
     L2R[50:60, 100:120] = -400.0        # projects right of the image
     masks = {f"mask_thr{t}": ns["get_occlusion_mask"](None, L2R, R2L, t) for t in (1, 3)}
     np.savez_compressed(os.path.join(OUT, "occlusion_mask.npz"), L2R=L2R, R2L=R2L, **masks)
+
+    # ---- 6. the rasteriser forward, run by the REFERENCE'S OWN KERNELS compiled for the CPU -------------
+    # oracle/_ref (oracle/build_ref.py): cuda_rasterizer/forward.cu + three kernels of rasterizer_impl.cu built from
+    # the sources where they lie, -ffp-contract=off (the literal IEEE sequence of the source; nvcc contracts
+    # some a*b+c into FMAs, which moves results by ulps -- the HIP parity tolerances cover that).
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    import math
+    import oracle
+    from gs2mesh_amd import synthetic
+    W3, H3, f3 = 200, 136, 180.0                       # ragged: 12.5 x 8.5 tiles
+    g = synthetic.synth_v1(2000, 4242, math.log(0.03))
+    sc, qn, op = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
+    shs3 = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+    pose = synthetic.ring_pose(0.3, 3.5)
+    pose = np.concatenate([pose[0], pose[1][:, None]], axis=1)
+    cam, _ = synthetic.stereo_cameras(pose, W3, H3, f3, f3, 0.2)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    ref = oracle.ref_forward(g["xyz"], op, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W3, H3,
+                             cam.tanfovx, cam.tanfovy, bg, shs=shs3, scales=sc, rotations=qn)
+    np.savez_compressed(
+        os.path.join(OUT, "ref_forward.npz"), W=W3, H=H3, xyz=g["xyz"], scales=sc, rotations=qn, opacity=op, shs=shs3,
+        bg=bg, viewmatrix=np.asarray(cam.world_view_transform, np.float32), projmatrix=np.asarray(cam.full_proj_transform, np.float32),
+        campos=np.asarray(cam.camera_center, np.float32), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+        **{"out_" + k: v for k, v in ref.items() if k != "num_rendered"}, out_num_rendered=ref["num_rendered"])
     print("golden fixtures written to", OUT)
 
 
