@@ -269,6 +269,25 @@ def main():
                    label="restated Open3D 0.17 ScalableTSDFVolume::Integrate (oracle/tsdf_oracle.cpp, OpenMP over the "
                          "16 x-slices of a block like upstream; thread count = faster of {16, all host cores})",
                    sample=f"{n_cpu} of the {K} timed {args.config} frames ({Wd}x{Ht}), integrate() only, {t_cpu:.1f} s")
+        # render half: the REFERENCE'S OWN rasteriser kernels compiled for the CPU (oracle/_ref, built in the dev
+        # container from /root/reference; the prebuilt library travels to the GPU box), one eye of the first timed pair
+        try:
+            if oracle.ref_available(build=False):
+                s_a, q_a, o_a = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
+                shs_a = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+                lcam = synthetic.stereo_cameras(poses[Wm], Wd, Ht, cfg.focal, cfg.focal, cfg.baseline)[0]
+                tc = time.perf_counter()
+                rr = oracle.ref_forward(g["xyz"], o_a, lcam.world_view_transform, lcam.full_proj_transform,
+                                        lcam.camera_center, Wd, Ht, lcam.tanfovx, lcam.tanfovy, np.zeros(3, np.float32),
+                                        shs=shs_a, scales=s_a, rotations=q_a)
+                t_eye = time.perf_counter() - tc
+                cpu["raster_reference"] = dict(
+                    value=round(0.5 / t_eye, 4), unit="stereo-pairs/s (render only)", cores=cores, kind="reference",
+                    label="diff-gaussian-rasterization forward.cu + rasterizer_impl.cu kernels compiled for the CPU "
+                          "(oracle/build_ref.py: CUDA execution shim, blocks over OpenMP threads)",
+                    sample=f"left eye of the first timed {args.config} pair ({int(rr['num_rendered'])} instances), {t_eye:.1f} s")
+        except Exception as e:  # the reference build is optional test infrastructure
+            cpu["raster_reference"] = dict(error=str(e)[:200])
 
     if rank == 0:
         out = dict(

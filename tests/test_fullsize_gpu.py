@@ -63,6 +63,13 @@ def test_c2_stereo_pair_vs_oracle_and_invariants():
     mse = float((diff.astype(np.float64) ** 2).mean())
     psnr = 20 * np.log10(1.0 / np.sqrt(mse)) if mse > 0 else np.inf      # GS/utils/image_utils.py:17-19
     assert psnr > 80.0, psnr
+    # the oracle itself against the reference's own kernels (oracle/_ref, prebuilt) at full size: bit-exact
+    if oracle.ref_available(build=False):
+        rr = oracle.ref_forward(g["xyz"], o, left.world_view_transform, left.full_proj_transform, left.camera_center,
+                                cfg.width, cfg.height, left.tanfovx, left.tanfovy, np.zeros(3, np.float32), shs=shs,
+                                scales=s, rotations=q)
+        assert rr["num_rendered"] == ref_n and np.array_equal(rr["radii"], ref_radii)
+        assert np.array_equal(rr["color"], ref)
 
 
 def test_c3_two_million_gaussians_invariants():
