@@ -7,7 +7,7 @@ as called at gs2mesh_utils/tsdf_utils.py:53-56,88-93,106-107).
 
 Only ``tests/``, ``bench.py``'s ``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may
 import this package, and only as the checker.  The product package ``gs2mesh_amd`` never
-does (tests/test_no_oracle_in_product.py greps for it).
+does (tests/test_capi_symbols.py greps for it).
 
 Parity status: SH->RGB, Sigma=R S^2 R^T and the camera matrices are pinned by golden
 vectors generated from the reference's own Python (tests/golden/make_golden.py).  The whole

@@ -71,3 +71,4 @@ def test_host_pointers_are_rejected_by_the_product_wrappers():
             rasterizer._ptr(torch.zeros(4))
     finally:
         _lib.ALLOW_HOST_POINTERS = old
+
