@@ -388,3 +388,43 @@ def test_hip_path_against_reference_golden(backend):
     np.testing.assert_array_equal(pl, z["out_point_list"])
     np.testing.assert_array_equal(ranges, z["out_ranges"])
     assert_image_close(be.host(img), z["out_color"])
+
+
+@pytest.mark.parametrize("env", [{"GS2M_NWG_TARGET": "2", "GS2M_MAX_WG_THREADS": "128"},
+                                 {"GS2M_NWG_TARGET": "3", "GS2M_MAX_WG_THREADS": "1024"},
+                                 {"GS2M_NWG_TARGET": "64", "GS2M_MAX_WG_THREADS": "64"}])
+def test_workgroup_geometry_knobs_do_not_change_results(env):
+    """k_count_tiles / k_scatter with few large workgroup chunks (several loop iterations per workgroup, partial last
+    iteration) and with small workgroups: same records, instance lists and image as the reference golden.  The knobs are
+    read once per process, hence the subprocess (emulator build of the kernel sources)."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import os, sys, numpy as np
+        sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
+        from backends import make
+        from gs2mesh_amd.rasterizer import Rasterizer
+        be = make("emu")
+        z = np.load(os.path.join(%r, "tests", "golden", "ref_forward.npz"))
+        W, H, P = int(z["W"]), int(z["H"]), z["xyz"].shape[0]
+        for cull in (0, 1):
+            r = Rasterizer(0, lib=be.lib)
+            r.set_option(1, cull)
+            img, radii = r.forward(z["xyz"], z["opacity"], z["viewmatrix"], z["projmatrix"], z["campos"], z["bg"], W, H,
+                                   float(z["tanfovx"]), float(z["tanfovy"]), shs=z["shs"], scales=z["scales"],
+                                   rotations=z["rotations"])
+            assert np.array_equal(radii, z["out_radii"])
+            d = np.abs(np.asarray(img) - z["out_color"])
+            assert (d > 1e-5).mean() <= 1e-4 and d.max() <= 6e-3
+            if cull == 0:
+                n = int(z["out_num_rendered"])
+                assert r.last_num_rendered == n
+                pl, ranges = r.download_binning(0, n, ((W + 15) // 16) * ((H + 15) // 16))
+                assert np.array_equal(pl, z["out_point_list"]) and np.array_equal(ranges, z["out_ranges"])
+        print("KNOBS_OK")
+    """ % (root, root, root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "KNOBS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
