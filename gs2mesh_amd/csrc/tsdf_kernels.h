@@ -25,7 +25,7 @@ GS2M_DEVICE float tsdf_fetch_depth(const float* __restrict__ depth, const unsign
     float d = depth[p];
     if (f.use_mask && mask[p] == 0) d = d * 0.0f;           // depth = depth * mask
     if (f.use_min && d < f.min_depth_f) d = 0.0f;            // depth[depth < min] = 0
-    d /= f.depth_scale_f;                                    // *p /= (float)depth_scale
+    if (f.depth_scale_f != 1.0f) d /= f.depth_scale_f;       // *p /= (float)depth_scale (x / 1 == x: skipped, uniform)
     if ((double)d >= f.depth_trunc) d = 0.0f;                // if (*p >= depth_trunc) *p = 0
     return d;
 }
@@ -291,7 +291,7 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
                     float dd = depth[pix[k]];
                     if (f.use_mask && mask[pix[k]] == 0) dd = dd * 0.0f;
                     if (f.use_min && dd < f.min_depth_f) dd = 0.0f;
-                    dd /= f.depth_scale_f;
+                    if (f.depth_scale_f != 1.0f) dd /= f.depth_scale_f;  // x / 1 == x exactly: uniform skip
                     if ((double)dd >= f.depth_trunc) dd = 0.0f;
                     d[k] = dd;
                 }
