@@ -100,6 +100,13 @@ def get() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension has not been built "
                 "(run `python -m gs2mesh_amd.build`; there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever
+        # is loaded first serves both; torch must be that one, or the device torch allocated on is invisible to the
+        # runtime this library would otherwise bind to ("no ROCm-capable device is detected").
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is the memory/stream plumbing; the C ABI itself does not need it
+            pass
         _LIB = bind(C.CDLL(LIB_PATH))
     return _LIB
 
