@@ -120,10 +120,12 @@ def main():
     p_vis_union = ((radii0[0] > 0) | (radii0[1] > 0)).sum().item()
     for i in range(Wm):
         step(i)
+    torch.cuda.synchronize()                      # drain the pipeline's streams before touching the volume
     if world > 1:
         reduce_volume(vol, mode=args.reduce)      # warm the RCCL communicator
     vol.status()
     vol.reset()
+    torch.cuda.synchronize()
 
     # ---- timed region: EXACTLY K steps (+ the volume reduction when N > 1) --------------------
     barrier()
