@@ -248,12 +248,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     }
     if (gs2m_raster_reserve(r, g.P, nv, W, H, 0)) return 1;
     const unsigned cap = r->inst_cap;
-#ifdef GS2M_DEV_ABLATE
-    static const int dev_abl = getenv("GS2M_ABL") ? atoi(getenv("GS2M_ABL")) : 0;
-    const int cull_arg_p = r->opt_exact_cull | ((dev_abl & 0xff) << 8), cull_arg_s = r->opt_exact_cull | ((dev_abl >> 8) << 8);
-#else
-    const int cull_arg_p = r->opt_exact_cull, cull_arg_s = r->opt_exact_cull;
-#endif
+    const int cull_arg_p = r->opt_exact_cull, cull_arg_s = r->opt_exact_cull;  // same option for counting and scatter
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
         gs2m_launch_project(nv, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p);

@@ -556,7 +556,7 @@ struct alignas(16) BlendInst {
     float2 c, pad;
 };
 
-template <int ABL, int WPB>
+template <int WPB>
 GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
@@ -670,7 +670,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                         const float dy = A.y - pyf[k];
                         // q = e + dy (c' dy - b' dx): two FMAs
                         const float qv = fmaf(fmaf(B.x, dy, nbdx[k & 1]), dy, e[k & 1]);
-                        const bool pre = ABL == 2 ? qv > 1.0e30f : qv >= QMIN;
+                        const bool pre = qv >= QMIN;
                         if (gs2m_ballot(pre ? 1 : 0) != 0ull) {
                             const bool cand = pre && !(qv > B.y);  // power > 0 (numerically non-PSD conic): skipped
                             const float alpha = fminf(0.99f, gs2m_fast_exp2(qv));

@@ -118,12 +118,6 @@ template <int NV>
 GS2M_KERNEL void __launch_bounds__(256)
 k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
           int exact_cull) {
-#ifdef GS2M_DEV_ABLATE
-    const int abl = exact_cull >> 8;  // 2: no SH/colour, 8: no rec write
-    exact_cull &= 1;
-#else
-    const int abl = 0;
-#endif
     const int ncoef = (g.D + 1) * (g.D + 1);
     {
         const int gi = (int)(blockIdx.x * 256u + threadIdx.x);
@@ -168,7 +162,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                 any = any || pv[v].ok;
             }
             float sh[48];
-            const bool need_sh = any && (g.colors_precomp == nullptr) && !(abl & 2);
+            const bool need_sh = any && (g.colors_precomp == nullptr);
             if (need_sh) {
                 if (g.shs_packed) {
                     // wave-transposed copy (k_pack_sh): float4 k of 64 consecutive Gaussians is 1 KiB contiguous
@@ -228,9 +222,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                     continue;
                 }
                 float cr, cg, cb;
-                if (abl & 2) {
-                    cr = cg = cb = 0.5f;
-                } else if (g.colors_precomp) {
+                if (g.colors_precomp) {
                     cr = g.colors_precomp[3 * (size_t)gi];
                     cg = g.colors_precomp[3 * (size_t)gi + 1];
                     cb = g.colors_precomp[3 * (size_t)gi + 2];
@@ -280,10 +272,8 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                 w2.z = __uint_as_float((unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16));
                 w2.w = __uint_as_float((unsigned)pv[v].x1 | ((unsigned)pv[v].y1 << 16));
                 float4* r4 = reinterpret_cast<float4*>(rec);
-                if (!(abl & 8)) {
-                    r4[0] = w0;
-                    r4[1] = w1;
-                }
+                r4[0] = w0;
+                r4[1] = w1;
                 r4[2] = w2;
             }
         }
@@ -299,12 +289,6 @@ GS2M_KERNEL void __launch_bounds__(1024)
 k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
               unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull) {
     GS2M_DYN_LDS(unsigned, lds);
-#ifdef GS2M_DEV_ABLATE
-    const int abl = exact_cull >> 8;  // 1: no tile expansion, 4: no hist row write
-    exact_cull &= 1;
-#else
-    const int abl = 0;
-#endif
     struct { int P; } g = {P};
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -362,7 +346,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
         for (int v = 0; v < NV; ++v) {
             const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
             const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
-            if ((abl & 1) || gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
+            if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
             unsigned* hh = lhist + v * hw;
             const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
             // ---- small rects: flattened item space ----
@@ -453,7 +437,6 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
         }
     }
     __syncthreads();
-    if (abl & 4) return;
     for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
         hist[((size_t)v * n_wg + blockIdx.x) * tiles + t] = (lhist[v * hw + (t >> 1)] >> ((t & 1) << 4)) & 0xffffu;
@@ -479,23 +462,15 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
           const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
           int exact_cull) {
     GS2M_DYN_LDS(unsigned, cursor);
-#ifdef GS2M_DEV_ABLATE
-    const int abl = exact_cull >> 8;  // 1: no key store, 2: cursor init only, 4: no cursor init
-    exact_cull &= 1;
-#else
-    const int abl = 0;
-#endif
     const int tid = (int)threadIdx.x;
     const int nthreads = (int)blockDim.x;
     const int gx = cams[0].gx, gy = cams[0].gy;
     const int tiles = gx * gy;
-    if (!(abl & 4))
     for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
         cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + blockIdx.x) * tiles + t];
     }
     __syncthreads();
-    if (abl & 2) return;
     const int lane = tid & 63, wave = tid >> 6;
     ScatterStage* stage = reinterpret_cast<ScatterStage*>(cursor + ((NV * tiles + 3) & ~3)) + wave;
     const int begin = (int)blockIdx.x * chunk;
@@ -560,7 +535,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                             const unsigned oxy = stage->xy0[kk];
                             const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
                             const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
-                            if (pos < cap && !(abl & 1)) kv[pos] = ((unsigned long long)stage->dbits[kk] << 32) | stage->gid[kk];
+                            if (pos < cap) kv[pos] = ((unsigned long long)stage->dbits[kk] << 32) | stage->gid[kk];
                         }
                     }
                 }
@@ -593,7 +568,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
                     if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, srx, sry, thr, tx, ty)) {
                         const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
-                        if (pos < cap && !(abl & 1)) kv[pos] = key;
+                        if (pos < cap) kv[pos] = key;
                     }
                 }
             }
