@@ -44,6 +44,8 @@ def main():
                     help="exact tile culling (image-preserving); 0 = reference instance lists")
     ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "4")))
     ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "reduce_scatter"])
+    ap.add_argument("--tile-rows", type=int, default=int(os.environ.get("GS2M_BENCH_TILE_ROWS", "2")), choices=[1, 2],
+                    help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "4")),
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
@@ -94,7 +96,7 @@ def main():
     # `inflight` stereo pairs in flight on separate streams (own rasteriser handle + images each), integration
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
-                              exact_tile_cull=args.cull, blend_variant=args.blend)
+                              exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows)
     R = pipe.rasterizers[0]
     color, rgb8 = pipe.color[0], pipe.rgb8[0]
 
@@ -300,7 +302,7 @@ def main():
             config=dict(workload=f"{args.config}: {cfg.P} synth_v1 Gaussians (SH deg 3), {K} stereo pairs/GPU at "
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
-                        exact_tile_cull=args.cull, blend_variant=args.blend, pairs_in_flight=args.inflight,
+                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, pairs_in_flight=args.inflight,
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
             num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis,
             tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, cpu_baseline=cpu,

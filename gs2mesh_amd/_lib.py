@@ -33,6 +33,7 @@ class Gaussians(C.Structure):
 
 OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
+OPT_TILE_ROWS = 5
 OPT_DEBUG_SYNC = 3
 OPT_STAGE_TIMING = 4
 RASTER_STAGES = ("project", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend", "count_tiles")

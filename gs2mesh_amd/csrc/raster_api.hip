@@ -37,7 +37,7 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0;
+    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1;
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -134,10 +134,23 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
     switch (option) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
         case GS2M_OPT_BLEND_VARIANT: r->opt_blend = value; return 0;
+        case GS2M_OPT_TILE_ROWS:
+            if (value != 1 && value != 2) {
+                gs2m_set_error("GS2M_OPT_TILE_ROWS must be 1 or 2");
+                return 1;
+            }
+            r->opt_tile_rows = value;
+            return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
         case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
     }
+}
+
+// tiles of the binning grid: 16 x (16 * rows) pixels
+static int binning_tiles(const gs2m_raster* r, int W, int H) {
+    const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
+    return gx * ((gy + r->opt_tile_rows - 1) / r->opt_tile_rows);
 }
 
 static void geometry(int P, int* chunk, int* n_wg) {
@@ -231,7 +244,8 @@ struct StageTimer {  // RAII: records an event pair around one stage launch when
 static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, float* out_color,
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
-    const int tiles = gx * gy;
+    const int gys = (gy + r->opt_tile_rows - 1) / r->opt_tile_rows;  // binning rows (tiles of 16 x 16*rows pixels)
+    const int tiles = gx * gys;
     int chunk, n_wg;
     geometry(g.P, &chunk, &n_wg);
     const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, gs2m_count_threads(chunk));  // scatter: u32 cursors + wave staging
@@ -285,7 +299,8 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "sort_tiles")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
-        gs2m_launch_blend(st, r->opt_blend, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams, g.P, cap,
+        // 16 x 32 instance lists: variant 6 (two waves per list, 4 px/lane) unless 5 (one wave, 8 px/lane) is asked for
+        gs2m_launch_blend(st, r->opt_tile_rows == 2 ? (r->opt_blend == 5 ? 5 : 6) : r->opt_blend, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams, g.P, cap,
                           out_color, out_rgb8);
     }
     if (dbg_check(r, st, "blend")) return 1;
@@ -363,7 +378,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     const int saved_debug = r->opt_debug;
     if (debug) r->opt_debug = 1;
     gs2m_launch_pack_camera(st, r->d_cams, 0, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy,
-                            width, height);
+                            width, height, 16 * r->opt_tile_rows);
     int rc = run_views(r, g, 1, width, height, out_color, nullptr, radii, 0, st);
     r->opt_debug = saved_debug;
     if (rc) return rc;
@@ -435,7 +450,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     g.M = gs->M;
     g.raw = gs->raw;
     g.scale_modifier = scale_modifier;
-    const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
+    const int tiles = binning_tiles(r, W, H);
     // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS tile cursors of the scatter allow
     int per = GS2M_MAX_VIEWS;
     while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 1024) > 160 * 1024) per--;
@@ -459,7 +474,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
             u.bg[0] = bg[0];
             u.bg[1] = bg[1];
             u.bg[2] = bg[2];
-            u.pad = 0;
+            u.th = 16 * r->opt_tile_rows;
         }
         gs2m_launch_set_cameras(st, r->d_cams, nv, cu);  // one launch for the views of the pass
         if (run_views(r, g, nv, W, H, out_color ? out_color + 3 * img * v0 : nullptr,

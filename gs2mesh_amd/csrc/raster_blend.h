@@ -556,7 +556,7 @@ struct alignas(16) BlendInst {
     float2 c, pad;
 };
 
-template <int WPB>
+template <int WPB, int ROWS, int LROWS>
 GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
@@ -564,34 +564,43 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     // 48-B staged instance: a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc, log2 o, r, g},
     // c = {b, quadrant mask (bits)}; one LDS address + immediate offsets per instance.  2 pad slots: the
     // software-pipelined reads run up to 2 instances ahead.
+    // ROWS = reference tiles (16 x 16) composited by one wave, stacked vertically: 1 = 4 pixels per lane, 2 = 8.
+    // LROWS = reference tiles per instance list (GS2M_OPT_TILE_ROWS): with 2 the binning stages handle ~30 % fewer
+    // (Gaussian, tile) instances.  <ROWS 1, LROWS 2>: two waves walk the same 16 x 32 list, each compositing its own
+    // 16 x 16 half (instances that miss the half cost a skipped iteration); <2, 2>: one wave, 8 pixels per lane
+    // (fewer instructions, but 103 VGPRs -> 4 waves/SIMD: measured slower).  A quadrant outside the instance's
+    // 16 x 16 tile rect is masked, so the reference's rect still bounds every contribution.
+    constexpr int NQ = 4 * ROWS, TH = GS2M_TILE * ROWS;
     __shared__ BlendInst s_i[WPB][64 + 2];
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int v = (int)blockIdx.y;
     const CamUniform& cam = cams[v];
     const int W = cam.W, H = cam.H, gx = cam.gx;
-    const int tiles = gx * cam.gy;
+    const int tiles = gx * ((cam.gy + ROWS - 1) / ROWS);        // tiles composited by waves
+    const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);    // instance lists
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
     const unsigned grp = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
     const int tile = gs2m_uniform((int)(grp * (unsigned)WPB) + wave);
     if (tile >= tiles) return;
     const int tx = tile % gx, ty = tile / gx;
-    const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
+    const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * TH + (lane >> 3);
     float pxf0 = (float)px0, pxf1 = (float)(px0 + 8);
     GS2M_KEEP_F32(pxf0);
     GS2M_KEEP_F32(pxf1);
-    float pyf[4], T[4], C0[4], C1[4], C2[4];
+    float pyf[NQ], T[NQ], C0[NQ], C1[NQ], C2[NQ];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
         pyf[k] = (x < W && y < H) ? (float)y : GS2M_PARKED;
         T[k] = 1.0f;
         C0[k] = C1[k] = C2[k] = 0.0f;
     }
-    const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * GS2M_TILE);
-    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
-    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
+    const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * TH);
+    const int ltile = (ty * ROWS / LROWS) * gx + tx;
+    unsigned r0 = tile_start[(size_t)v * (ltiles + 1) + ltile];
+    unsigned r1 = tile_start[(size_t)v * (ltiles + 1) + ltile + 1];
     if (r0 > cap) r0 = cap;
     if (r1 > cap) r1 = cap;
     r0 = (unsigned)gs2m_uniform((int)r0);
@@ -600,10 +609,10 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const GeomRec* rv = recs + (size_t)v * P;
     const float LOG2E = 1.44269504088896340736f;
     const float QMIN = -7.99435343685885793770f;  // -log2(255): alpha >= 1/255 <=> q >= QMIN (decided in the log2 domain)
-    float4 ra, rb;
-    float rc = 0.0f;
+    float4 ra, rb, rc;  // the three 16-B vectors of a GeomRec
     ra.x = ra.y = ra.z = ra.w = 0.0f;
     rb = ra;
+    rc = ra;
     rb.y = 1.0f;
     unsigned base = r0;
     if (base + (unsigned)lane < r1) {
@@ -611,12 +620,15 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
         ra = r4[0];
         rb = r4[1];
-        rc = r4[2].x;
+        rc = r4[2];
     }
     while (base < r1) {
-        const bool live = pyf[0] < 1.0e17f || pyf[1] < 1.0e17f || pyf[2] < 1.0e17f || pyf[3] < 1.0e17f;
+        bool live = false;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) live = live || pyf[k] < 1.0e17f;
         if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
         gs2m_wave_sync();
+        int nb_staged = 0;
         {
             const float lo = gs2m_fast_log2(rb.y);                         // log2 o
             const float t2 = fmaxf(2.0f * (gs2m_fast_log(rb.y * 255.0f) + 1.0e-4f), 0.0f);  // 2 ln(255 o) (+ margin)
@@ -625,15 +637,20 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             const float hx = sqrtf(t2 * rb.x * inv) * 1.001f + 0.01f;      // cov_xx = cc/det
             const float hy = sqrtf(t2 * ra.z * inv) * 1.001f + 0.01f;      // cov_yy = ca/det
             const bool xl = ra.x - hx <= qx0 + 7.0f, xr = ra.x + hx >= qx0 + 8.0f;
-            const bool yt = ra.y - hy <= qy0 + 7.0f, yb = ra.y + hy >= qy0 + 8.0f;
+            const bool box = rb.y * 255.0f >= 0.9999f && det > 0.0f;
+            const bool degenerate = !(det > 0.0f);  // no box: test every pixel of the tile rect
+            const int ry0 = (int)(__float_as_uint(rc.z) >> 16), ry1 = (int)(__float_as_uint(rc.w) >> 16);  // rect rows, 16-px units
             unsigned m = 0u;
-            if (rb.y * 255.0f >= 0.9999f && det > 0.0f) {
-                if (xl && yt) m |= 1u;
-                if (xr && yt) m |= 2u;
-                if (xl && yb) m |= 4u;
-                if (xr && yb) m |= 8u;
-            } else if (!(det > 0.0f)) {
-                m = 15u;  // degenerate conic: no box, test every pixel
+#pragma unroll
+            for (int qr = 0; qr < 2 * ROWS; ++qr) {  // 8-pixel quadrant rows of the tile
+                const float top = qy0 + 8.0f * (float)qr;
+                bool row = degenerate || (box && ra.y - hy <= top + 7.0f && ra.y + hy >= top);
+                if (LROWS > 1) {  // the quadrant must lie in a 16 x 16 tile of the instance's rect
+                    const int y16 = ty * ROWS + (qr >> 1);
+                    row = row && y16 >= ry0 && y16 < ry1;
+                }
+                if (row && (degenerate || xl)) m |= 1u << (2 * qr);
+                if (row && (degenerate || xr)) m |= 2u << (2 * qr);
             }
             BlendInst bi;
             bi.a = ra;
@@ -642,20 +659,29 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             bi.a.w = LOG2E * ra.w;
             bi.b.x = (-0.5f * LOG2E) * rb.x;
             bi.b.y = lo;
-            bi.c.x = rc;
+            bi.c.x = rc.x;
             bi.c.y = __uint_as_float(m);
             bi.pad = bi.c;
-            s_i[wave][lane] = bi;
+            if (LROWS > ROWS) {
+                // the list also serves the other half of the 16 x 32 tile: stage only the instances that reach this
+                // half (ballot compaction), so the compositing loop never iterates over the others
+                const bool mine = m != 0u && base + (unsigned)lane < r1;
+                const unsigned long long keep = gs2m_ballot(mine ? 1 : 0);
+                if (mine) s_i[wave][gs2m_popc64(keep & ((1ull << lane) - 1ull))] = bi;
+                nb_staged = gs2m_popc64(keep);
+            } else {
+                s_i[wave][lane] = bi;
+            }
         }
         gs2m_wave_sync();
-        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
+        const int nb = LROWS > ROWS ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
         base += 64u;
         if (base + (unsigned)lane < r1) {
             const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
             const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
             ra = r4[0];
             rb = r4[1];
-            rc = r4[2].x;
+            rc = r4[2];
         }
         // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
         // constants are in flight while instance j is composited (no LDS wait on the critical path).
@@ -665,7 +691,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
                 const float nbdx[2] = {-(A.w * dx0), -(A.w * dx1)};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NQ; ++k) {
                     if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
                         const float dy = A.y - pyf[k];
                         // q = e + dy (c' dy - b' dx): two FMAs
@@ -714,7 +740,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     }
     const size_t plane = (size_t)H * W;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NQ; ++k) {
         const int pxi = px0 + 8 * (k & 1), pyi = py0 + 8 * (k >> 1);
         if (pxi < W && pyi < H) {
             const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];

@@ -14,10 +14,13 @@ struct CamUniform {
     float proj[16];  // "projmatrix"
     float campos[3];
     float tanfovx, tanfovy, focal_x, focal_y;
-    int W, H, gx, gy;
+    int W, H, gx, gy;  // gx x gy = the reference's 16 x 16 tile grid (rect units of the GeomRec)
     float bg[3];
-    int pad;
+    int th;            // binning tile height in pixels: 16 (reference tiles) or 32 (two reference tiles stacked)
 };
+// binning grid rows for a camera: tiles of 16 x th pixels
+#define GS2M_CAM_ROWS(cam) ((cam).th >> 4)
+#define GS2M_CAM_GYS(cam) (((cam).gy + ((cam).th >> 4) - 1) / ((cam).th >> 4))
 
 // Projected per-(view, Gaussian) record: 48 B, three 16-B vectors so that the blend stage
 // gathers one contiguous record per instance instead of three arrays

@@ -23,7 +23,7 @@ void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const flo
                               unsigned char* present);
 void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,
                              const float* projmatrix, const float* campos, const float* bg, float tanfovx,
-                             float tanfovy, int W, int H);
+                             float tanfovy, int W, int H, int th);
 void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamUniform* c);
 
 void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count);

@@ -153,12 +153,13 @@ GS2M_DEVICE void cull_slopes(float ca, float cb, float cc, float& rx, float& ry)
     ry = -cb / cc;
 }
 // thresh = ln(255*o)*1.0001 + 0.001 (precomputed per Gaussian), or < 0 if o*255 < 1.
+// th = tile height in pixels (16 = the reference tile; 32 = two stacked, GS2M_OPT_TILE_ROWS 2), ty in units of th
 GS2M_DEVICE bool tile_may_contribute(float mx, float my, float ca, float cb, float cc, float rx, float ry,
-                                     float thresh, int tx, int ty) {
+                                     float thresh, int tx, int ty, int th = GS2M_TILE) {
     const float dx0 = mx - (float)(tx * GS2M_TILE + GS2M_TILE - 1);
     const float dx1 = mx - (float)(tx * GS2M_TILE);
-    const float dy0 = my - (float)(ty * GS2M_TILE + GS2M_TILE - 1);
-    const float dy1 = my - (float)(ty * GS2M_TILE);
+    const float dy0 = my - (float)(ty * th + th - 1);
+    const float dy1 = my - (float)(ty * th);
     if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
     float qmin = edge_min_x(ca, cb, cc, rx, dy0, dx0, dx1);
     qmin = fminf(qmin, edge_min_x(ca, cb, cc, rx, dy1, dx0, dx1));

@@ -292,8 +292,8 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     struct { int P; } g = {P};
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int gx = cams[0].gx, gy = cams[0].gy;
-    const int tiles = gx * gy;
+    const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
+    const int tiles = gx * GS2M_CAM_GYS(cams[0]);
     // workgroup-private tile histogram, two 16-bit counters per word (a workgroup owns `chunk` <= 65535
     // Gaussians and a Gaussian counts at most once per tile): half the LDS -> twice the resident waves
     const int nthreads = (int)blockDim.x;
@@ -327,6 +327,9 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                 pv[v].x1 = (int)(rect1 & 0xffffu);
                 pv[v].y1 = (int)(rect1 >> 16);
                 pv[v].ok = pv[v].x1 > pv[v].x0 && pv[v].y1 > pv[v].y0;
+                // rows of the binning grid (tiles of 16 x th pixels) covered by the rect
+                pv[v].y0 = pv[v].y0 / rows;
+                pv[v].y1 = (pv[v].y1 + rows - 1) / rows;
                 if (pv[v].ok) {
                     const float4 w0 = r4[0];
                     const float4 w1 = r4[1];
@@ -398,7 +401,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                         keep = true;
                         if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
                             keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
-                                                       stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty);
+                                                       stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty, th);
                         if (keep) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
                     }
                     // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
@@ -431,7 +434,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                     unsigned rx, ry;
                     rect_coords(li, ow, oinv, rx, ry);
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
+                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
                 }
             }
         }
@@ -464,8 +467,8 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
     GS2M_DYN_LDS(unsigned, cursor);
     const int tid = (int)threadIdx.x;
     const int nthreads = (int)blockDim.x;
-    const int gx = cams[0].gx, gy = cams[0].gy;
-    const int tiles = gx * gy;
+    const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
+    const int tiles = gx * GS2M_CAM_GYS(cams[0]);
     for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
         cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + blockIdx.x) * tiles + t];
@@ -486,9 +489,13 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                 rect1 = __float_as_uint(w2.w);
                 dbits = __float_as_uint(w2.y);
             }
-            const int x0 = (int)(rect0 & 0xffffu), y0 = (int)(rect0 >> 16);
-            const int x1 = (int)(rect1 & 0xffffu), y1 = (int)(rect1 >> 16);
-            const unsigned w = x1 > x0 ? (unsigned)(x1 - x0) : 0u, h = y1 > y0 ? (unsigned)(y1 - y0) : 0u;
+            const int x0 = (int)(rect0 & 0xffffu), x1 = (int)(rect1 & 0xffffu);
+            int y0 = (int)(rect0 >> 16), y1 = (int)(rect1 >> 16);
+            const bool ok = x1 > x0 && y1 > y0;
+            y0 = y0 / rows;                  // rows of the binning grid (tiles of 16 x th pixels)
+            y1 = (y1 + rows - 1) / rows;
+            rect0 = (unsigned)x0 | ((unsigned)y0 << 16);
+            const unsigned w = ok ? (unsigned)(x1 - x0) : 0u, h = ok ? (unsigned)(y1 - y0) : 0u;
             const unsigned area = w * h;
             if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
             unsigned* cur = cursor + v * tiles;
@@ -566,7 +573,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                     unsigned rx, ry;
                     rect_coords(li, ow, oinv, rx, ry);
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, srx, sry, thr, tx, ty)) {
+                    if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, srx, sry, thr, tx, ty, th)) {
                         const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
                         if (pos < cap) kv[pos] = key;
                     }
@@ -609,7 +616,8 @@ k_mark_visible(int P, const float* __restrict__ xyz, const float* __restrict__ v
 // Fill the device CamUniform of view `slot` from DEVICE pointers (operator-level API, where
 // viewmatrix / projmatrix / campos / bg are device tensors as in the reference).
 GS2M_KERNEL void k_pack_camera(CamUniform* cams, int slot, const float* viewmatrix, const float* projmatrix,
-                               const float* campos, const float* bg, float tanfovx, float tanfovy, int W, int H) {
+                               const float* campos, const float* bg, float tanfovx, float tanfovy, int W, int H,
+                               int th) {
     const int t = (int)threadIdx.x;
     CamUniform* c = cams + slot;
     if (t < 16) {
@@ -629,7 +637,7 @@ GS2M_KERNEL void k_pack_camera(CamUniform* cams, int slot, const float* viewmatr
         c->H = H;
         c->gx = (W + GS2M_TILE - 1) / GS2M_TILE;
         c->gy = (H + GS2M_TILE - 1) / GS2M_TILE;
-        c->pad = 0;
+        c->th = th;
     }
 }
 

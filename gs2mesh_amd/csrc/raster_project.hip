@@ -81,9 +81,9 @@ void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const flo
 
 void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,
                              const float* projmatrix, const float* campos, const float* bg, float tanfovx,
-                             float tanfovy, int W, int H) {
+                             float tanfovy, int W, int H, int th) {
     GS2M_LAUNCH(k_pack_camera, dim3(1), dim3(64), 0, st, cams, slot, viewmatrix, projmatrix, campos, bg, tanfovx,
-                tanfovy, W, H);
+                tanfovy, W, H, th);
 }
 
 void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamUniform* c) {

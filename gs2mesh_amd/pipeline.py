@@ -27,7 +27,8 @@ from .rasterizer import Rasterizer
 class RenderFusePipeline:
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None,
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0,
-                 exact_tile_cull: int = 1, blend_variant: int | None = None, bg=(0.0, 0.0, 0.0), lib=None):
+                 exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
+                 lib=None):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
@@ -41,6 +42,7 @@ class RenderFusePipeline:
         for j in range(self.inflight):
             r = Rasterizer(device, lib=lib)
             r.set_option(_lib.OPT_EXACT_TILE_CULL, int(exact_tile_cull))
+            r.set_option(_lib.OPT_TILE_ROWS, int(tile_rows))   # 2 = 16 x 32 binning tiles (same image, fewer instances)
             if blend_variant is not None:
                 r.set_option(_lib.OPT_BLEND_VARIANT, int(blend_variant))
             self.rasterizers.append(r)

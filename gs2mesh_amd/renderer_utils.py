@@ -159,6 +159,7 @@ class Renderer:
         self._bg_host = tuple(float(b) for b in bg)
         self._raster = Rasterizer(torch.device(dev).index or 0)
         self._raster.set_option(_lib.OPT_EXACT_TILE_CULL, 1)      # image-preserving; fewer instances to sort/blend
+        self._raster.set_option(_lib.OPT_TILE_ROWS, 2)            # 16 x 32 binning tiles: same image, ~30 % fewer instances
         self._raster.pack_sh(self.gaussians.raw())                # one-time SH re-layout for coalesced loads
         self._views = {}
 

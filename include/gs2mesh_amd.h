@@ -62,8 +62,14 @@ enum {
                                      exponent in the log2 domain.  Same image (to rounding). */
     GS2M_OPT_DEBUG_SYNC = 3,      /* 1 = synchronise + check after every launch (the
                                      reference's `debug`: auxiliary.h:166-173)            */
-    GS2M_OPT_STAGE_TIMING = 4     /* 1 = bracket every stage launch with hipEvents on the
+    GS2M_OPT_STAGE_TIMING = 4,    /* 1 = bracket every stage launch with hipEvents on the
                                      work stream (read with gs2m_raster_stage_times)      */
+    GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
+                                     tiles: instance lists / num_rendered are the reference's.  2 = two reference
+                                     tiles stacked (one wave composites 16 x 32 pixels, 8 per lane): ~35 % fewer
+                                     (Gaussian, tile) instances to count, scatter and sort; same image -- the
+                                     reference's 16 x 16 tile rect still bounds every contribution.  The
+                                     binning taps then describe the 16 x 32 tiles.                          */
 };
 
 /* Stage order of gs2m_raster_stage_times */

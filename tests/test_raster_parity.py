@@ -428,3 +428,88 @@ def test_workgroup_geometry_knobs_do_not_change_results(env):
     """ % (root, root, root))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     assert r.returncode == 0 and "KNOBS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("cull", [0, 1])
+def test_tile_rows_2_same_image_fewer_instances(backend, cull):
+    """GS2M_OPT_TILE_ROWS 2 (16 x 32 binning tiles, one wave composites 8 pixels per lane): the image still matches
+    the oracle -- the reference's 16 x 16 tile rect bounds every contribution -- with fewer (Gaussian, tile)
+    instances.  Scenes: reference golden (odd number of tile rows: 8.5), huge/tiny mix, crowded saturating stack, fused
+    stereo pair from raw parameters."""
+    import os
+    be = backend
+    d = be.dev
+
+    def ras():
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+        r.set_option(_lib.OPT_TILE_ROWS, 2)
+        return r
+
+    # 1. reference golden
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_forward.npz"))
+    W, H = int(z["W"]), int(z["H"])
+    r = ras()
+    img, radii = r.forward(d(z["xyz"]), d(z["opacity"]), d(z["viewmatrix"]), d(z["projmatrix"]), d(z["campos"]), d(z["bg"]),
+                           W, H, float(z["tanfovx"]), float(z["tanfovy"]), shs=d(z["shs"]), scales=d(z["scales"]),
+                           rotations=d(z["rotations"]))
+    np.testing.assert_array_equal(be.host(radii), z["out_radii"])
+    assert r.last_num_rendered < 0.9 * int(z["out_num_rendered"])
+    assert_image_close(be.host(img), z["out_color"])
+    # the binning taps describe the 16 x 32 tiles: sizes are consistent
+    n_tiles2 = ((W + 15) // 16) * ((H + 31) // 32)
+    pl, ranges = r.download_binning(0, r.last_num_rendered, n_tiles2)
+    assert (ranges[:, 1] - ranges[:, 0]).sum() == r.last_num_rendered and pl.max() < z["xyz"].shape[0]
+    # 2. huge and tiny splats (rects from 1 to all tiles, opacity below 1/255, anisotropic)
+    W, H, f = 200, 136, 180.0
+    rng = np.random.default_rng(77)
+    P = 600
+    xyz = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    s = np.exp(rng.normal(math.log(0.02), 0.5, (P, 3))).astype(np.float32)
+    big = rng.choice(P, 12, replace=False)
+    s[big] = rng.uniform(0.3, 1.5, (12, 3)).astype(np.float32)
+    q = rng.normal(0, 1, (P, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    o = rng.uniform(0.01, 0.9, P).astype(np.float32)
+    o[big[:3]] = 0.003
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    pose = synthetic.ring_pose(0.7, 3.5)
+    pose = np.concatenate([pose[0], pose[1][:, None]], axis=1)
+    cam, _ = synthetic.stereo_cameras(pose, W, H, f, f, 0.2)
+    r = ras()
+    img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                           d(np.array([0.2, 0.1, 0.0], np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols),
+                           scales=d(s), rotations=d(q))
+    ref_img, ref_radii, _ = oracle_forward(cam, xyz, o, [0.2, 0.1, 0.0], colors_precomp=cols, scales=s, rotations=q)
+    np.testing.assert_array_equal(be.host(radii), ref_radii)
+    assert_image_close(be.host(img), ref_img)
+    # 3. crowded tiles (early saturation, several 64-instance batches, workgroup sort path), image 48 x 32 = 3 x 1 tiles
+    W, H, f = 48, 32, 60.0
+    P = 9000
+    rng = np.random.default_rng(3)
+    xyz = rng.normal(0, 0.02, (P, 3)).astype(np.float32)
+    xyz[:, 2] = rng.uniform(-1, 1, P)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    oo = rng.uniform(0.02, 0.4, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    ss = np.full((P, 3), 0.05, np.float32)
+    qq = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    r = ras()
+    img, _ = r.forward(d(xyz), d(oo), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                       d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols), scales=d(ss),
+                       rotations=d(qq))
+    ref_img, _, _ = oracle_forward(cam, xyz, oo, [0, 0, 0], colors_precomp=cols, scales=ss, rotations=qq)
+    assert_image_close(be.host(img), ref_img)
+    # 4. fused stereo pair from raw parameters == the same handle with 16 x 16 tiles
+    W, H, f = 160, 120, 150.0
+    g, s, q, o, shs, left, right = scene(2500, 21, W, H, f)
+    gd = dict(xyz=d(g["xyz"]), scaling=d(g["scaling"]), rotation=d(g["rotation"]), opacity=d(g["opacity"]),
+              features_dc=d(g["features_dc"]), features_rest=d(g["features_rest"]), raw=True, sh_degree=3)
+    r2 = ras()
+    a = r2.render_views(gd, [camera_from(left), camera_from(right)], want_rgb8=True)
+    r1 = Rasterizer(0, lib=be.lib)
+    r1.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+    b = r1.render_views(gd, [camera_from(left), camera_from(right)], want_rgb8=True)
+    assert max(a["num_rendered"]) < max(b["num_rendered"])
+    diff = np.abs(be.host(a["color"]) - be.host(b["color"]))
+    assert (diff > 1e-5).mean() < 1e-4 and diff.max() < 6e-3

@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C2"); ap.add_argument("--pairs", type=int, default=16)
 ap.add_argument("--streams", type=int, default=2); ap.add_argument("--tsdf", type=int, default=1)
 ap.add_argument("--blend", type=int, default=4); ap.add_argument("--fuse-prio", type=int, default=0)
+ap.add_argument("--rows", type=int, default=1)
 a = ap.parse_args()
 cfg = synthetic.CONFIGS[a.config]
 dev = torch.device("cuda:0")
@@ -29,7 +30,7 @@ intr = PinholeCameraIntrinsic(Wd, Ht, cfg.focal, cfg.focal, Wd / 2, Ht / 2)
 S = a.streams
 Rs, cols, rgbs, streams = [], [], [], []
 for j in range(S):
-    R = Rasterizer(0); R.set_option(_lib.OPT_EXACT_TILE_CULL, 1); R.set_option(_lib.OPT_BLEND_VARIANT, a.blend)
+    R = Rasterizer(0); R.set_option(_lib.OPT_EXACT_TILE_CULL, 1); R.set_option(_lib.OPT_BLEND_VARIANT, a.blend); R.set_option(_lib.OPT_TILE_ROWS, a.rows)
     if j == 0: R.pack_sh(gd)
     Rs.append(R)
     cols.append(torch.empty((2, 3, Ht, Wd), dtype=torch.float32, device=dev))

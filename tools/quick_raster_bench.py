@@ -17,6 +17,7 @@ ap.add_argument("--pairs", type=int, default=8)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--cull", type=int, default=0)
 ap.add_argument("--blend", type=int, default=4)
+ap.add_argument("--rows", type=int, default=1)
 ap.add_argument("--morton", type=int, default=0)
 ap.add_argument("--stages", type=int, default=1)
 ap.add_argument("--pack", type=int, default=1)
@@ -44,6 +45,7 @@ for p in poses:
 R = Rasterizer(0)
 R.set_option(_lib.OPT_EXACT_TILE_CULL, a.cull)
 R.set_option(_lib.OPT_BLEND_VARIANT, a.blend)
+R.set_option(_lib.OPT_TILE_ROWS, a.rows)
 if a.pack:
     R.pack_sh(gd)
 out = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
