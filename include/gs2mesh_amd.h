@@ -66,10 +66,11 @@ enum {
                                      work stream (read with gs2m_raster_stage_times)      */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
-                                     tiles stacked (one wave composites 16 x 32 pixels, 8 per lane): ~35 % fewer
-                                     (Gaussian, tile) instances to count, scatter and sort; same image -- the
-                                     reference's 16 x 16 tile rect still bounds every contribution.  The
-                                     binning taps then describe the 16 x 32 tiles.                          */
+                                     tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and
+                                     sort; two waves share a list, each compositing its 16 x 16 half (blend
+                                     variant 5 = one wave, 8 pixels per lane); same image -- the reference's
+                                     16 x 16 tile rect still bounds every contribution.  The binning taps then
+                                     describe the 16 x 32 tiles.                                            */
 };
 
 /* Stage order of gs2m_raster_stage_times */
