@@ -47,16 +47,19 @@ def single_process_reference():
 
 @pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "reduce_scatter"), (3, "allreduce")])
 def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
-    port = free_port()
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    for p in procs:
-        out, _ = p.communicate(timeout=600)
-        assert p.returncode == 0, out.decode(errors="replace")[-3000:]
+    for attempt in range(3):   # the rendezvous port is picked, released and re-bound by rank 0: retry if it was taken
+        port = free_port()
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+        if all(p.returncode == 0 for p in procs):
+            break
+        rendezvous = any("address already in use" in o.lower() or "connect" in o.lower() or "timed out" in o.lower() for o in outs)
+        assert rendezvous and attempt < 2, "\n".join(o[-3000:] for o in outs)
     kf, tf, wf, cf = single_process_reference()
     ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
     seen = set()
