@@ -115,7 +115,7 @@ def main():
             torch.cuda.synchronize()
 
     # ---- warm-up (also sizes the instance arena: grow + retry happens here, not in the timed loop)
-    res = pipe.prepare(cams[0], headroom=1.3)   # SH re-layout + arena sizing (prepare_renderer stage)
+    res = pipe.prepare(cams[0], headroom=2.0)   # SH re-layout + arena sizing (prepare_renderer stage)
     num_rendered0 = res["num_rendered"]
     radii0 = res["radii"]
     p_vis = [(radii0[v] > 0).sum().item() for v in range(2)]
