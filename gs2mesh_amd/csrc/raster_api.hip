@@ -248,8 +248,13 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     const int tiles = gx * gys;
     int chunk, n_wg;
     geometry(g.P, &chunk, &n_wg);
-    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, gs2m_count_threads(chunk));  // scatter: u32 cursors + wave staging
-    const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, gs2m_count_threads(chunk));  // count: u16 histogram + staging
+    // threads per counting / scatter workgroup: the chunk (<= 1024), halved until the wave staging fits next to the
+    // tile cursors in the 160 KiB LDS (large images)
+    int wg_threads = gs2m_count_threads(chunk);
+    while (wg_threads > 64 && gs2m_scatter_lds_bytes(nv, tiles, wg_threads) > 160 * 1024) wg_threads /= 2;
+    wg_threads = (wg_threads + 63) / 64 * 64;
+    const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, wg_threads);    // scatter: u32 cursors + wave staging
+    const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, wg_threads);    // count: u16 histogram + staging
     if (lds > 160 * 1024 || lds_p > 160 * 1024) {
         gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile cursors", W, H, nv, tiles);
         return 1;
@@ -270,7 +275,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "project")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_COUNT);
-        if (gs2m_launch_count_tiles(nv, n_wg, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
+        if (gs2m_launch_count_tiles(nv, n_wg, wg_threads, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
                                     cull_arg_p))
             return 1;
     }
@@ -287,7 +292,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "tile_scan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
-        if (gs2m_launch_scatter(nv, n_wg, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
+        if (gs2m_launch_scatter(nv, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
                                 r->d_tilemask, r->d_keys, cap, cull_arg_s))
             return 1;
     }
@@ -453,7 +458,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     const int tiles = binning_tiles(r, W, H);
     // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS tile cursors of the scatter allow
     int per = GS2M_MAX_VIEWS;
-    while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 1024) > 160 * 1024) per--;
+    while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 64) > 160 * 1024) per--;
     for (int v0 = 0; v0 < n_views; v0 += per) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
         CamUniform cu[GS2M_MAX_VIEWS];

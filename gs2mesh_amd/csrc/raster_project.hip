@@ -25,7 +25,7 @@ void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUnif
     else GS2M_LAUNCH((k_project<1>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
 }
 
-int gs2m_launch_count_tiles(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull) {
     if (lds_bytes > 64 * 1024) {
@@ -39,15 +39,15 @@ int gs2m_launch_count_tiles(int nv, int n_wg, size_t lds_bytes, hipStream_t st, 
         }
     }
     if (nv == 2)
-        GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
+        GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
                     exact_cull);
     else
-        GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
+        GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
                     exact_cull);
     return 0;
 }
 
-int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull) {
     if (lds_bytes > 64 * 1024) {
@@ -61,10 +61,10 @@ int gs2m_launch_scatter(int nv, int n_wg, size_t lds_bytes, hipStream_t st, cons
         }
     }
     if (nv == 2)
-        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
                     tile_start, tilemask, keys, cap, exact_cull);
     else
-        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(gs2m_count_threads(chunk)), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
                     tile_start, tilemask, keys, cap, exact_cull);
     return 0;
 }

@@ -513,3 +513,30 @@ def test_tile_rows_2_same_image_fewer_instances(backend, cull):
     assert max(a["num_rendered"]) < max(b["num_rendered"])
     diff = np.abs(be.host(a["color"]) - be.host(b["color"]))
     assert (diff > 1e-5).mean() < 1e-4 and diff.max() < 6e-3
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+def test_4k_image_tile_cursors_fit_the_lds(backend, rows):
+    """3840 x 2160 = 32 400 reference tiles: the per-workgroup tile cursors take 130 KB of the 160 KiB LDS, so the
+    counting / scatter workgroups run with fewer threads (less wave staging) instead of failing."""
+    W, H = 3840, 2160
+    rng = np.random.default_rng(1)
+    P = 300
+    xyz = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    s = np.full((P, 3), 0.01, np.float32)
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    o = rng.uniform(0.2, 0.9, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * 3000.0), 2 * math.atan2(H, 2 * 3000.0), W, H)
+    be = backend
+    d = be.dev
+    r = Rasterizer(0, lib=be.lib)
+    r.set_option(_lib.OPT_TILE_ROWS, rows)
+    img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                           d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols), scales=d(s),
+                           rotations=d(q))
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    np.testing.assert_array_equal(be.host(radii), ref_radii)
+    if rows == 1:
+        assert r.last_num_rendered == ref_n
+    assert_image_close(be.host(img), ref_img)
