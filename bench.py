@@ -10,18 +10,23 @@ device) into the block-sparse TSDF.  The workload at N=1 is BASELINE.json config
 1600x1200, TSDF 512^3, reference defaults voxel 2/512 / trunc 0.04); depth = analytic sphere (the
 reference's depth comes from the DLNR stereo network, which is outside the path).  All inputs are
 resident in HBM before the timed region.  N>1: weak scaling -- every rank renders+fuses its own K
-views with no data-path collective, then ONE RCCL sum-reduction of the TSDF accumulators inside the
+views with no data-path collective, then ONE RCCL reduce-scatter of the TSDF accumulators inside the
 timed region (gs2mesh_amd/parallel.py).
 
+Timing: the K-step job (+ the reduction when N > 1) is timed EXACTLY as the driver contract says (barrier +
+synchronize on both sides, MAX over ranks) and REPEATED (volume reset between repeats, outside the bracket) until at
+least 5 repeats and >= 1 s of timed region have accumulated; `ms_per_step` / `value` are the MEDIAN repeat.
+
 Prints ONE JSON line (rank 0): value = whole-job stereo pairs rendered+fused per second.
-Extra objects: "tsdf" (Mvoxel-updates/s), "stages" (hipEvent time per kernel launch),
-"roofline" (dominant kernel), "raster_roofline" (whole rasteriser vs SURVEY.md 8d's B_pair),
-"cpu_baseline" (oracle = restated Open3D 0.17 integrate on the host cores, bounded sample).
+Extra objects: "tsdf" (Mvoxel-updates/s), "stages" (hipEvent time per kernel launch), "roofline" (dominant kernel),
+"raster_roofline" (whole rasteriser vs SURVEY.md 8d's B_pair, with this build's instance count and with the
+reference's), "parity" (the first timed pair against the CPU oracle), "cpu_baseline" (oracle = restated Open3D 0.17
+integrate on the host cores, bounded sample), "c3" (render-only sub-measurement of the HBM-bound 2 M-Gaussian config).
 """
 import argparse
 import json
-import math
 import os
+import statistics
 import sys
 import time
 
@@ -34,6 +39,80 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md); measured float4-copy peak 6.29e12
 
 
+def alg_bytes(cfg, p_vis, p_vis_union, N_eye, U_frame=0.0):
+    """SURVEY.md 8(d) algorithmic bytes per kernel launch (= per stereo pair / per frame)."""
+    Wd, Ht = cfg.width, cfg.height
+    img = 12.0 * Wd * Ht
+    alg = {
+        "project": 44.0 * cfg.P + 192.0 * p_vis_union + 40.0 * sum(p_vis),
+        "count_tiles": 16.0 * 2 * cfg.P + 32.0 * sum(p_vis),   # rect of every Gaussian + geometry half of the visible ones
+        "scatter": 12.0 * sum(N_eye),
+        "sort_tiles": 24.0 * sum(N_eye),
+        "blend": 40.0 * sum(N_eye) + 2 * img,
+        "hist_colscan": 0.0, "tile_scan": 0.0,
+        "tsdf_touch": 4.0 * Wd * Ht / 16.0,
+        "tsdf_integrate": 40.0 * U_frame + 7.0 * Wd * Ht,
+    }
+    B_pair = 44.0 * cfg.P + 192.0 * p_vis_union + sum(40.0 * pv + 76.0 * n + img for pv, n in zip(p_vis, N_eye))
+    return alg, B_pair
+
+
+def raster_only(args, cfg_name, dev, local_rank, pairs=12):
+    """Render-only sub-measurement (no TSDF, serial on one stream, hipEvents per launch): used for the C3 sub-line."""
+    import torch
+    from gs2mesh_amd import _lib, synthetic
+    from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+    cfg = synthetic.CONFIGS[cfg_name]
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+    gd["raw"] = True
+    del g
+    poses = synthetic.ring_poses(pairs, cfg.ring_radius, 0, cfg.n_pairs)
+    cams = []
+    for p in poses:
+        l, r = synthetic.stereo_cameras(p, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline)
+        cams.append([camera_from(l), camera_from(r)])
+    R = Rasterizer(local_rank)
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, int(args.cull))
+    R.set_option(_lib.OPT_TILE_ROWS, int(args.tile_rows))
+    R.set_option(_lib.OPT_BLEND_VARIANT, int(args.blend))
+    R.pack_sh(gd)
+    color = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
+    rgb8 = torch.empty((2, cfg.height, cfg.width, 3), dtype=torch.uint8, device=dev)
+    res = R.render_views(gd, cams[0], out_color=color, out_rgb8=rgb8, want_radii=True)
+    R.reserve(cfg.P, 2, cfg.width, cfg.height, int(max(res["num_rendered"]) * 1.5))
+    radii0 = res["radii"]
+    p_vis = [(radii0[v] > 0).sum().item() for v in range(2)]
+    p_vis_union = ((radii0[0] > 0) | (radii0[1] > 0)).sum().item()
+    N_eye = [float(x) for x in res["num_rendered"]]
+    for c in cams[:2]:
+        R.render_views(gd, c, out_color=color, out_rgb8=rgb8, sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in cams:
+        R.render_views(gd, c, out_color=color, out_rgb8=rgb8, sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / len(cams)
+    R.set_option(_lib.OPT_STAGE_TIMING, 1)
+    for c in cams:
+        R.render_views(gd, c, out_color=color, out_rgb8=rgb8, sync=False)
+    st = R.stage_times()
+    R.set_option(_lib.OPT_STAGE_TIMING, 0)
+    _, ov, _ = R.status(2)
+    alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye)
+    stages = {k: dict(avg_us=round(1e3 * ms / max(c, 1), 2), frac_hbm=round(alg[k] / max(1e-9, 1e-3 * ms / max(c, 1)) / HBM_PEAK, 4))
+              for k, (ms, c) in st.items()}
+    t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
+    return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {len(cams)} pairs, "
+                         f"serial on one stream",
+                num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis, overflow=bool(ov),
+                ms_per_pair_wall=round(1e3 * dt, 4), stages=stages,
+                binning_us=round(sum(stages[k]["avg_us"] for k in ("count_tiles", "hist_colscan", "tile_scan", "scatter", "sort_tiles")), 1),
+                raster_roofline=dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
+                                     achieved_GBps=round(B_pair / t_raster / 1e9, 1),
+                                     frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,13 +122,18 @@ def main():
     ap.add_argument("--cull", type=int, default=int(os.environ.get("GS2M_BENCH_CULL", "1")),
                     help="exact tile culling (image-preserving); 0 = reference instance lists")
     ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "4")))
-    ap.add_argument("--reduce", default="allreduce", choices=["allreduce", "reduce_scatter"])
+    ap.add_argument("--reduce", default="reduce_scatter", choices=["allreduce", "reduce_scatter"])
     ap.add_argument("--tile-rows", type=int, default=int(os.environ.get("GS2M_BENCH_TILE_ROWS", "2")), choices=[1, 2],
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "4")),
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
+    ap.add_argument("--min-repeats", type=int, default=5)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
+    ap.add_argument("--max-repeats", type=int, default=400)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 render-only sub-measurement")
     args = ap.parse_args()
 
     import torch
@@ -57,7 +141,7 @@ def main():
     from gs2mesh_amd import _lib, synthetic
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
     from gs2mesh_amd.parallel import reduce_volume
-    from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+    from gs2mesh_amd.rasterizer import camera_from
     from gs2mesh_amd.pipeline import RenderFusePipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,10 +164,11 @@ def main():
     gd["raw"] = True
     n_local = K + Wm
     poses = synthetic.ring_poses(n_local, cfg.ring_radius, first=rank * n_local, total=world * n_local)
-    cams, depths, Es = [], [], []
+    cams, cams_np, depths, Es = [], [], [], []
     for p in poses:
         l, r = synthetic.stereo_cameras(p, Wd, Ht, cfg.focal, cfg.focal, cfg.baseline)
         cams.append([camera_from(l), camera_from(r)])
+        cams_np.append((l, r))
         depths.append(synthetic.sphere_depth_torch(p, Wd, Ht, cfg.focal, cfg.focal, cx, cy, cfg.sphere_radius, dev))
         E = np.eye(4)
         E[:3] = p
@@ -122,36 +207,42 @@ def main():
     p_vis_union = ((radii0[0] > 0) | (radii0[1] > 0)).sum().item()
     for i in range(Wm):
         step(i)
-    torch.cuda.synchronize()                      # drain the pipeline's streams before touching the volume
+    pipe.finish()                                 # drain the pipeline's streams before touching the volume
     if world > 1:
         reduce_volume(vol, mode=args.reduce)      # warm the RCCL communicator
     vol.status()
     vol.reset()
     torch.cuda.synchronize()
 
-    # ---- timed region: EXACTLY K steps (+ the volume reduction when N > 1) --------------------
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(Wm, Wm + K):
-        step(i)
+    # ---- timed region: EXACTLY K steps (+ the volume reduction when N > 1), repeated ------------
+    dts, reds = [], []
     red = None
-    if world > 1:
-        torch.cuda.synchronize()
-        t_red0 = time.perf_counter()
-        red = reduce_volume(vol, mode=args.reduce)
-        torch.cuda.synchronize()
-        t_red = time.perf_counter() - t_red0
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    pipe.finish()    # raises if an instance arena overflowed inside the timed region
+    while True:
+        vol.reset()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(Wm, Wm + K):
+            step(i)
+        if world > 1:
+            pipe.drain()                          # host waits for the fuse stream only (no device-wide sync)
+            t_red0 = time.perf_counter()
+            red = reduce_volume(vol, mode=args.reduce)
+            torch.cuda.synchronize()
+            reds.append(time.perf_counter() - t_red0)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())                 # identical on every rank -> identical stopping decision
+        pipe.finish()    # raises if an instance arena overflowed in ANY pair of the repeat (sticky device flag)
+        dts.append(dt)
+        if (len(dts) >= args.min_repeats and sum(dts) >= args.min_seconds) or len(dts) >= args.max_repeats:
+            break
+    dt = statistics.median(dts)
+    t_red = statistics.median(reds) if reds else None
 
     # ---- instrumented pass (hipEvents around every kernel launch, on the work stream) ---------
-    if world > 1:
-        local_updates = None
     vol.reset()
     vol.status()
     R.set_option(_lib.OPT_STAGE_TIMING, 1)
@@ -176,31 +267,22 @@ def main():
 
     # ---- algorithmic bytes, per kernel launch = per stereo pair ------------------
     N_eye = [float(x) for x in num_rendered0]           # instances produced by this build (culling mode)
-    img = 12.0 * Wd * Ht
-    alg = {
-        "project": 44.0 * cfg.P + 192.0 * p_vis_union + 40.0 * sum(p_vis),
-        "count_tiles": 16.0 * 2 * cfg.P + 32.0 * sum(p_vis),   # rect of every Gaussian + geometry half of the visible ones
-        "scatter": 12.0 * sum(N_eye),
-        "sort_tiles": 24.0 * sum(N_eye),
-        "blend": 40.0 * sum(N_eye) + 2 * img,
-        "hist_colscan": 0.0, "tile_scan": 0.0,
-        "tsdf_touch": 4.0 * Wd * Ht / 16.0,
-        "tsdf_integrate": 40.0 * U_frame + 7.0 * Wd * Ht,
-    }
-    B_pair = 44.0 * cfg.P + 192.0 * p_vis_union + sum(40.0 * pv + 76.0 * n + img for pv, n in zip(p_vis, N_eye))
+    alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye, U_frame)
     t_raster = sum(stages[k]["avg_us"] for k in _lib.RASTER_STAGES) * 1e-6
     t_tsdf = sum(stages[k]["avg_us"] for k in _lib.TSDF_STAGES) * 1e-6
     dom = max(stages, key=lambda k: stages[k]["avg_us"] * stages[k]["launches"])
     achieved = alg[dom] / (stages[dom]["avg_us"] * 1e-6)
-    traffic = None
-    valu = None
+    traffic, traffic_source, valu = None, None, None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
             tr = json.load(open(prof))
             ent = tr.get(args.config, {}).get(dom)
-            if ent and ent.get("cull") == args.cull:
+            if ent and ent.get("cull") == args.cull and ent.get("blend_variant", 4) == args.blend:
                 traffic = ent["hbm_bytes_per_launch"]
+                traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 1')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  f"passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')}; "
+                                  "committed profile, not measured in this run")
                 if ent.get("valu_insts_per_launch"):
                     # the dominant kernel is VALU-bound: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC
                     # pass) / live launch time, against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
@@ -212,10 +294,10 @@ def main():
         except Exception:
             traffic = None
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK, 4), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_source,
                     algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_us=round(stages[dom]["avg_us"], 2), valu=valu,
-                    note="blend is VALU/LDS-bound (12 flop + exp per pixel x instance, data served from LDS); "
-                         "HBM fraction reported as the contract asks, see DESIGN.md")
+                    note="blend is VALU-bound (exp + 10 VALU ops per contributing pixel x instance, data served from LDS / "
+                         "the matrix cores); HBM fraction reported as the contract asks, see DESIGN.md")
     per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launches=v["launches"],
                           alg_GBps=round(alg[k] / max(v["avg_us"], 1e-9) / 1e3, 1),
                           frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4))
@@ -230,13 +312,30 @@ def main():
                 allocated_blocks=int(n_blocks), voxel_length=cfg.voxel_length, sdf_trunc=cfg.sdf_trunc,
                 unit="Mvoxel-updates/s (4096 per touched 16^3 block per frame)")
     if red is not None:
-        tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 5), union_blocks=int(red["n_blocks_union"]),
-                              bytes_per_rank=int(red["bytes_per_rank"]))
+        tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
+                              union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),
+                              collectives=int(red.get("collectives", 0)))
 
-    # ---- CPU baseline: the oracle (restated Open3D integrate), rank 0, N = 1 only ----------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- oracle legs (rank 0, N = 1 only): parity of the first timed pair, CPU baseline --------------------------
+    cpu, par = None, None
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity):
         import oracle
+    if rank == 0 and world == 1 and not args.no_parity:
+        # the first timed pair as the timed configuration renders it (this handle: tile_rows, cull, packed SH, fused
+        # activations), against the CPU oracle (the reference's own kernels when oracle/_ref is prebuilt)
+        from oracle import parity
+        rr = R.render_views(gd, cams[Wm], out_color=color, out_rgb8=rgb8, want_radii=True)
+        par = parity.pair_parity(g, cams_np[Wm], Wd, Ht, color.cpu().numpy(), rgb8.cpu().numpy(), rr["radii"].cpu().numpy())
+        par["what"] = (f"first timed {args.config} pair (both eyes, worst case), fp32 image on [0,1] vs the CPU oracle; "
+                       "radii: fused exp/normalize/sigmoid vs numpy's")
+        N_ref = par.get("oracle_num_rendered")
+        if isinstance(N_ref, list):
+            _, B_pair_ref = alg_bytes(cfg, p_vis, p_vis_union, [float(x) for x in N_ref])
+            raster_roofline["with_reference_instance_count"] = dict(
+                num_rendered_per_eye=N_ref, B_pair_bytes=int(B_pair_ref),
+                frac_of_8TBps=round(B_pair_ref / t_raster / HBM_PEAK, 4),
+                note="same measured time, B_pair evaluated with the reference's num_rendered (16x16 tiles, no culling)")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         left_u8 = rgb8[0].cpu().numpy()
 
@@ -279,7 +378,7 @@ def main():
             if oracle.ref_available(build=False):
                 s_a, q_a, o_a = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
                 shs_a = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
-                lcam = synthetic.stereo_cameras(poses[Wm], Wd, Ht, cfg.focal, cfg.focal, cfg.baseline)[0]
+                lcam = cams_np[Wm][0]
                 tc = time.perf_counter()
                 rr = oracle.ref_forward(g["xyz"], o_a, lcam.world_view_transform, lcam.full_proj_transform,
                                         lcam.camera_center, Wd, Ht, lcam.tanfovx, lcam.tanfovy, np.zeros(3, np.float32),
@@ -293,6 +392,17 @@ def main():
         except Exception as e:  # the reference build is optional test infrastructure
             cpu["raster_reference"] = dict(error=str(e)[:200])
 
+    # ---- C3 sub-line: the HBM-bound 2 M-Gaussian configuration, render only ----------------------------------------
+    c3 = None
+    if rank == 0 and world == 1 and not args.no_c3 and args.config != "C3":
+        del pipe
+        vol.close()
+        torch.cuda.empty_cache()
+        try:
+            c3 = raster_only(args, "C3", dev, local_rank)
+        except Exception as e:   # never lose the main line to the sub-measurement
+            c3 = dict(error=str(e)[:300])
+
     if rank == 0:
         out = dict(
             metric="stereo-pair renders/sec + TSDF Mvoxel-updates/sec",
@@ -304,9 +414,11 @@ def main():
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
                         exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, pairs_in_flight=args.inflight,
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
+            timing=dict(repeats=len(dts), timed_region_s=round(sum(dts), 4), statistic="median over repeats of the K-step job",
+                        ms_per_step_min=round(1e3 * min(dts) / K, 4), ms_per_step_max=round(1e3 * max(dts) / K, 4)),
             num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis,
-            tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, cpu_baseline=cpu,
-            instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
+            tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, parity=par, cpu_baseline=cpu,
+            c3=c3, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
             note_stages="`stages` / `roofline` / `instrumented_ms_per_step`: second pass, serial on one stream with hipEvents "
                         "around every launch (kernels in isolation); `value`: timed pass with `pairs_in_flight` pairs "
                         "overlapped on separate streams")

@@ -63,8 +63,10 @@ struct gs2m_raster {
     unsigned long long* d_tmp = nullptr;
     size_t keys_cap_total = 0;  // entries in each of d_keys / d_tmp
     unsigned inst_cap = 0;      // per-view capacity requested
-    ViewStatus* d_status = nullptr;  // [GS2M_MAX_STATUS]
-    ViewStatus* h_status = nullptr;  // pinned
+    // [1 + GS2M_MAX_STATUS]: slot 0 is STICKY ({max instances any call needed, any call overflowed} since the last
+    // gs2m_raster_status), slots 1.. are the views of the last call
+    ViewStatus* d_status = nullptr;
+    ViewStatus* h_status = nullptr;  // pinned mirror
     // last call
     int last_P = 0, last_nv = 0, last_tiles = 0, last_views_total = 0;
     unsigned last_cap = 0;
@@ -93,13 +95,14 @@ extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
     gs2m_raster* r = new gs2m_raster();
     r->device = device;
     if (hipMalloc((void**)&r->d_cams, sizeof(CamUniform) * GS2M_MAX_VIEWS) != hipSuccess ||
-        hipMalloc((void**)&r->d_status, sizeof(ViewStatus) * GS2M_MAX_STATUS) != hipSuccess ||
-        hipHostMalloc((void**)&r->h_status, sizeof(ViewStatus) * GS2M_MAX_STATUS) != hipSuccess) {
+        hipMalloc((void**)&r->d_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
+        hipHostMalloc((void**)&r->h_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
+        hipMemset(r->d_status, 0, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess) {
         gs2m_set_error("gs2m_raster_create: allocation failed");
         delete r;
         return 1;
     }
-    memset(r->h_status, 0, sizeof(ViewStatus) * GS2M_MAX_STATUS);
+    memset(r->h_status, 0, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1));
     *out = r;
     return 0;
 }
@@ -250,9 +253,9 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     geometry(g.P, &chunk, &n_wg);
     // threads per counting / scatter workgroup: the chunk (<= 1024), halved until the wave staging fits next to the
     // tile cursors in the 160 KiB LDS (large images)
-    int wg_threads = gs2m_count_threads(chunk);
-    while (wg_threads > 64 && gs2m_scatter_lds_bytes(nv, tiles, wg_threads) > 160 * 1024) wg_threads /= 2;
-    wg_threads = (wg_threads + 63) / 64 * 64;
+    int wg_threads = (gs2m_count_threads(chunk) + 63) / 64 * 64;
+    while (wg_threads > 64 && gs2m_scatter_lds_bytes(nv, tiles, wg_threads) > 160 * 1024)
+        wg_threads = (wg_threads / 2 + 63) / 64 * 64;  // stays a whole number of waves: the size checked is the size launched
     const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, wg_threads);    // scatter: u32 cursors + wave staging
     const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, wg_threads);    // count: u16 histogram + staging
     if (lds > 160 * 1024 || lds_p > 160 * 1024) {
@@ -287,7 +290,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "hist_colscan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
-        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + status_slot, cap);
+        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + 1 + status_slot, r->d_status, cap);
     }
     if (dbg_check(r, st, "tile_scan")) return 1;
     {
@@ -342,8 +345,8 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     if (P == 0) {
         // rasterize_points.cu:68,81: the zero-filled image is returned untouched
         HIPCHK(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, st));
-        HIPCHK(hipMemsetAsync(r->d_status, 0, sizeof(ViewStatus), st));
-        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemsetAsync(r->d_status + 1, 0, sizeof(ViewStatus), st));
+        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * 2, hipMemcpyDeviceToHost, st));
         r->last_P = 0;
         r->last_nv = 1;
         return 0;
@@ -387,7 +390,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     int rc = run_views(r, g, 1, width, height, out_color, nullptr, radii, 0, st);
     r->opt_debug = saved_debug;
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * 2, hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -431,8 +434,8 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     if (gs->P == 0) {
         if (out_color) HIPCHK(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * img * n_views, st));
         if (out_rgb8) HIPCHK(hipMemsetAsync(out_rgb8, 0, 3 * img * n_views, st));
-        HIPCHK(hipMemsetAsync(r->d_status, 0, sizeof(ViewStatus) * n_views, st));
-        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * n_views, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemsetAsync(r->d_status + 1, 0, sizeof(ViewStatus) * n_views, st));
+        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * (n_views + 1), hipMemcpyDeviceToHost, st));
         return 0;
     }
     if (!gs->xyz || !gs->scales || !gs->rotations || !gs->opacities || !gs->shs) {
@@ -487,7 +490,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
                       out_radii ? out_radii + (size_t)gs->P * v0 : nullptr, v0, st))
             return 1;
     }
-    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * n_views, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * (n_views + 1), hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -518,16 +521,23 @@ extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_view
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipGetLastError());
-    int ov = 0;
-    int64_t req = 0;
+    // slot 0 is sticky: an overflow in ANY call since the last query is reported (a later call on the same handle that
+    // fits does not erase it), with the largest instance count any of those calls needed
+    int ov = r->h_status[0].overflow != 0;
+    int64_t req = r->h_status[0].num_rendered;
     const int n = n_views < r->last_views_total ? n_views : r->last_views_total;
     for (int v = 0; v < r->last_views_total && v < GS2M_MAX_STATUS; ++v) {
-        ov |= r->h_status[v].overflow != 0;
-        if ((int64_t)r->h_status[v].num_rendered > req) req = r->h_status[v].num_rendered;
+        ov |= r->h_status[1 + v].overflow != 0;
+        if ((int64_t)r->h_status[1 + v].num_rendered > req) req = r->h_status[1 + v].num_rendered;
     }
-    for (int v = 0; v < n && num_rendered; ++v) num_rendered[v] = r->h_status[v].num_rendered;
+    for (int v = 0; v < n && num_rendered; ++v) num_rendered[v] = r->h_status[1 + v].num_rendered;
     if (overflow) *overflow = ov;
     if (required) *required = req;
+    // the query consumes the sticky word (the stream is idle here)
+    HIPCHK(hipMemsetAsync(r->d_status, 0, sizeof(ViewStatus), (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    r->h_status[0].overflow = 0;
+    r->h_status[0].num_rendered = 0;
     return 0;
 }
 

@@ -6,8 +6,8 @@ void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, 
     GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(256), 0, st, hist, n_wg, tiles, tile_count);
 }
 void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles,
-                           ViewStatus* status, unsigned cap) {
-    GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, status, cap);
+                           ViewStatus* status, ViewStatus* sticky, unsigned cap) {
+    GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, status, sticky, cap);
 }
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap) {

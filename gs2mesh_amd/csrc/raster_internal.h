@@ -28,7 +28,7 @@ void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamU
 
 void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count);
 void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles,
-                           ViewStatus* status, unsigned cap);
+                           ViewStatus* status, ViewStatus* sticky, unsigned cap);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap);
 void gs2m_launch_blend(hipStream_t st, int variant, int nv, int gx, int gy, const unsigned long long* keys,

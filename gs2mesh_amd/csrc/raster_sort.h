@@ -61,10 +61,10 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
 }
 
 // Exclusive scan of tile_count over tiles: one 1024-thread workgroup per view.
-// tile_start[v][0..tiles]; status[v] = {N, N > cap}.
+// tile_start[v][0..tiles]; status[v] = {N, N > cap}; sticky = {max N, any N > cap} since the last status query.
 GS2M_KERNEL void __launch_bounds__(1024)
 k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles,
-            ViewStatus* __restrict__ status, unsigned cap) {
+            ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap) {
     __shared__ unsigned part[1024];
     const int tid = (int)threadIdx.x;
     const int v = (int)blockIdx.x;
@@ -94,6 +94,9 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
         start[tiles] = total;
         status[v].num_rendered = total;
         status[v].overflow = total > cap ? 1u : 0u;
+        // sticky word of the handle: survives later calls until gs2m_raster_status consumes it
+        if (total > cap) atomicOr(&sticky->overflow, 1u);
+        atomicMax(&sticky->num_rendered, total);
     }
 }
 

@@ -88,13 +88,22 @@ class RenderFusePipeline:
                 self.volume.integrate(RGBDImage(self.rgb8[0][0], depth, depth_scale=depth_scale, depth_trunc=depth_trunc),
                                       self.intrinsic, extrinsic, mask=mask, min_depth=min_depth)
             return 0
+        # Inputs (Gaussians, depth, mask) were produced on the caller's current stream (e.g. by the stereo network):
+        # both private streams wait for it, and the caching allocator is told the fuse stream still reads depth / mask
+        # after the caller drops them.
+        cur = torch.cuda.current_stream(self.device)
         rs = self.render_streams[j]
+        rs.wait_stream(cur)
         with torch.cuda.stream(rs):
             rs.wait_event(self._fused[j])          # the view that last used this slot's images is integrated
             r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j], sync=False)
             self._rendered[j].record(rs)
         if depth is not None:
             fs = self.fuse_stream
+            fs.wait_stream(cur)
+            for t in (depth, mask):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(fs)
             with torch.cuda.stream(fs):
                 fs.wait_event(self._rendered[j])
                 self.volume.integrate(RGBDImage(self.rgb8[j][0], depth, depth_scale=depth_scale, depth_trunc=depth_trunc),
@@ -108,18 +117,32 @@ class RenderFusePipeline:
         else:
             torch.cuda.current_stream(self.device).synchronize()
 
-    def finish(self):
-        """Drain every stream; raises if an instance arena overflowed during the pipelined loop."""
+    def drain(self):
+        """Host waits for everything submitted so far (render + fuse streams); no status query, no device-wide sync."""
         if self.inflight > 1:
             for s in self.render_streams:
                 s.synchronize()
             self.fuse_stream.synchronize()
         else:
             torch.cuda.current_stream(self.device).synchronize()
-        for r in self.rasterizers:
+
+    def finish(self):
+        """Drain every stream; raises if an instance arena overflowed in ANY pair submitted since the last
+        `finish` (the handle's overflow word is sticky on the device: a later pair that fits does not erase it).
+        The images of an overflowing pair were composited from a truncated instance list, so the views integrated
+        from them are invalid: grow the arenas (`prepare(..., headroom=)`) and redo the loop."""
+        if self.inflight > 1:
+            for s in self.render_streams:
+                s.synchronize()
+            self.fuse_stream.synchronize()
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+        for j, r in enumerate(self.rasterizers):
             nr, ov, req = r.status(2)
             if ov:
-                raise RuntimeError(f"instance arena overflow inside the pipelined loop (need {req})")
+                raise RuntimeError(f"instance arena overflow inside the pipelined loop (slot {j}: views "
+                                   f"{j}, {j + self.inflight}, ... of the {self._n} submitted; need {req} instances "
+                                   f"per view)")
 
     def set_stage_timing(self, enable: bool):
         for r in self.rasterizers:

@@ -185,10 +185,12 @@ int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* g, const gs2m_camera
  */
 int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* g, gs2m_stream stream);
 
-/* Synchronises `stream` and reports, for the last forward/render_views call on the
- * handle: num_rendered[v] for v < n_views (host array, may be NULL) and whether the
- * instance arena overflowed (*overflow = 1: results invalid, *required = instances
- * per view needed). */
+/* Synchronises `stream` (pass the stream the handle is used on) and reports num_rendered[v] for
+ * v < n_views of the LAST forward/render_views call on the handle (host array, may be NULL), and
+ * whether the instance arena overflowed in ANY call since the previous status query
+ * (*overflow = 1: the images of the overflowing calls are invalid; *required = the largest
+ * per-view instance count any of those calls needed).  The overflow word is sticky on the device:
+ * a later call that fits does not erase it; this query consumes it. */
 int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_views,
                        int64_t* num_rendered, int* overflow, int64_t* required);
 

@@ -1,0 +1,78 @@
+"""Parity measurements of a rendered image against the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Used by ``tests/`` and by the ``cpu_baseline`` leg of ``bench.py`` (the oracle as the checker, never as the
+thing measured).  The numbers reported here are the ones DESIGN.md section 2 quotes and the ones the
+full-size tests bound (tolerances = at most 2x the measured values).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import activate, rasterize_forward, ref_available, ref_forward
+
+
+def quantize_u8(img_chw: np.ndarray) -> np.ndarray:
+    """cv2.imwrite's float -> u8 conversion of ``render * 255`` (renderer_utils.py:389-390): HWC u8."""
+    return np.clip(np.rint(np.asarray(img_chw, np.float32).transpose(1, 2, 0) * np.float32(255.0)), 0, 255).astype(np.uint8)
+
+
+def image_parity(img: np.ndarray, ref: np.ndarray, rgb8: np.ndarray | None = None) -> dict:
+    """``img`` / ``ref``: [3,H,W] f32.  ``rgb8``: the device-quantised [H,W,3] u8 image, if produced."""
+    d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64))
+    mse = float((d * d).mean())
+    out = dict(max_abs=float(d.max()), mean_abs=float(d.mean()),
+               psnr_db=(float(20.0 * np.log10(1.0 / np.sqrt(mse))) if mse > 0 else float("inf")),   # GS/utils/image_utils.py:17-19
+               frac_gt_1e5=float((d > 1e-5).mean()), frac_gt_1e4=float((d > 1e-4).mean()),
+               n_values=int(d.size))
+    q_ref = quantize_u8(ref)
+    q_img = quantize_u8(img) if rgb8 is None else np.asarray(rgb8)
+    dq = np.abs(q_img.astype(np.int16) - q_ref.astype(np.int16))
+    out["u8_flipped_values"] = int((dq > 0).sum())          # values whose 8-bit code differs from the oracle's
+    out["u8_flipped_pixels"] = int((dq.max(axis=2) > 0).sum())
+    out["u8_max_lsb"] = int(dq.max())
+    return out
+
+
+def oracle_eye(g: dict, cam, W: int, H: int, bg=(0.0, 0.0, 0.0), prefer_reference: bool = True) -> dict:
+    """Render one eye of pre-activation Gaussians ``g`` (numpy, GaussianModel layout) on the CPU: with the
+    reference's own kernels (oracle/_ref, when prebuilt) or with the restated oracle (bit-identical, slower).
+    -> dict(color, radii, num_rendered, kind)."""
+    s, q, o = activate(g["scaling"], g["rotation"], g["opacity"])
+    shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+    bgv = np.asarray(bg, np.float32)
+    if prefer_reference and ref_available(build=False):
+        rr = ref_forward(g["xyz"], o, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                         cam.tanfovx, cam.tanfovy, bgv, shs=shs, scales=s, rotations=q)
+        return dict(color=rr["color"], radii=rr["radii"], num_rendered=int(rr["num_rendered"]), kind="reference")
+    ref, radii, n = rasterize_forward(g["xyz"], o, cam.world_view_transform, cam.full_proj_transform,
+                                      cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, bgv, shs=shs, scales=s,
+                                      rotations=q)
+    return dict(color=ref, radii=radii, num_rendered=int(n), kind="port")
+
+
+def pair_parity(g: dict, cams, W: int, H: int, color: np.ndarray, rgb8: np.ndarray | None = None,
+                radii: np.ndarray | None = None, bg=(0.0, 0.0, 0.0)) -> dict:
+    """Parity of one rendered stereo pair.  ``cams`` = (left, right) graphics.Camera, ``color`` [2,3,H,W],
+    ``rgb8`` [2,H,W,3] or None, ``radii`` [2,P] or None.  Worst case over the two eyes for every figure."""
+    eyes = []
+    for v, cam in enumerate(cams):
+        o = oracle_eye(g, cam, W, H, bg)
+        e = image_parity(color[v], o["color"], None if rgb8 is None else rgb8[v])
+        if radii is not None:
+            e["radii_mismatches"] = int((np.asarray(radii[v]) != o["radii"]).sum())
+        e["oracle"] = o["kind"]
+        e["oracle_num_rendered"] = o["num_rendered"]
+        eyes.append(e)
+    worst = dict(eyes[0])
+    for e in eyes[1:]:
+        for k, val in e.items():
+            if k == "psnr_db":
+                worst[k] = min(worst[k], val)
+            elif k in ("oracle", "n_values"):
+                continue
+            elif k == "oracle_num_rendered":
+                worst[k] = [eyes[0][k], val]
+            else:
+                worst[k] = max(worst[k], val)
+    worst["eyes"] = len(eyes)
+    return worst

@@ -130,3 +130,91 @@ def test_c2_tsdf_frames_vs_oracle_and_order_invariance():
     o2 = np.array([i2[tuple(k)] for k in keys.tolist()])
     assert np.array_equal(w2[o2], weight) and np.array_equal(c2[o2], rgb)
     assert np.abs(t2[o2] - tsdf).max() < 1e-6
+
+
+# ---- the exact configuration bench.py times, at full size, against the oracle --------------
+# Measured on MI355X (gpurun_out/parity_<cfg>.json, copied to profiles/r2a_parity_<cfg>.json); every bound below is
+# <= 2x the measured worst case over the checked eyes.
+BENCH_PARITY_BOUNDS = {
+    #        max_abs  mean_abs  psnr_db  frac>1e-5  u8 flipped px  radii mismatches (fused exp/sigmoid vs numpy)
+    # measured r2a: C2 max 2.0e-3 (2.6e-3 on the bench's pair), mean 4.7e-8, PSNR 115.8 / 114.2 dB, 8.0e-6 of the values off by
+    # > 1e-5, 70 u8 pixels off by 1 LSB, 1 radius;  C3 max 3.8e-4, mean 3.0e-8, PSNR 130.8 dB, 1.6e-6, 26 pixels, 1 radius
+    "C2": dict(max_abs=5e-3, mean_abs=1e-7, psnr_db=111.0, frac_gt_1e5=1.6e-5, u8_flipped_pixels=140, radii_mismatches=2),
+    "C3": dict(max_abs=8e-4, mean_abs=6e-8, psnr_db=127.0, frac_gt_1e5=3.2e-6, u8_flipped_pixels=52, radii_mismatches=2),
+}
+
+
+@pytest.mark.parametrize("cfg_name", ["C2", "C3"])
+def test_bench_configuration_full_size_vs_oracle(cfg_name):
+    """RenderFusePipeline(inflight=4) + 16x32 binning tiles + exact tile cull + packed SH + fused raw activations
+    + TSDF integration on the fuse stream: the loop of bench.py, both eyes of two of the pipelined views compared
+    with the CPU oracle (the reference's own kernels when oracle/_ref is prebuilt) at BASELINE.json's full size."""
+    import json
+    import os
+    import torch
+    from oracle import parity
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    cfg, g, gd, poses, cams, Rasterizer, camera_from = _setup(cfg_name, n_pairs=5)
+    W, H = cfg.width, cfg.height
+    dev = torch.device("cuda:0")
+    intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2.0, H / 2.0)
+    vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=16384, device=0)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=4, device=0, exact_tile_cull=1, tile_rows=2)
+    ccams = [[camera_from(l), camera_from(r)] for l, r in cams]
+    first = pipe.prepare(ccams[0], headroom=2.0)
+    radii0 = first["radii"].cpu().numpy()
+    kept = {}
+    for i, p in enumerate(poses):
+        d = synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2.0, H / 2.0, cfg.sphere_radius, dev)
+        E = np.eye(4)
+        E[:3] = p
+        slot = pipe.submit(ccams[i], d, E, depth_trunc=cfg.baseline * 20, min_depth=cfg.baseline * 4)
+        kept[slot] = i                      # no wait between submits: views 1..4 are in flight together
+    pipe.finish()
+    assert vol.status()[0] > 100
+    worst = None
+    for slot, i in sorted(kept.items())[:2]:                      # two of the four views still held by the slots
+        color = pipe.color[slot].cpu().numpy()
+        rgb8 = pipe.rgb8[slot].cpu().numpy()
+        m = parity.pair_parity(g, cams[i], W, H, color, rgb8, radii0 if i == 0 else None)
+        m["view"] = i
+        if worst is None:
+            worst = m
+        else:
+            for k in ("max_abs", "mean_abs", "frac_gt_1e5", "frac_gt_1e4", "u8_flipped_pixels", "u8_flipped_values", "u8_max_lsb"):
+                worst[k] = max(worst[k], m[k])
+            worst["psnr_db"] = min(worst["psnr_db"], m["psnr_db"])
+    # radii of the prepare() render of view 0 (fused exp / normalize / sigmoid vs numpy's)
+    o0 = [parity.oracle_eye(g, c, W, H) for c in cams[0]]
+    worst["radii_mismatches"] = int(max((radii0[v] != o0[v]["radii"]).sum() for v in range(2)))
+    worst["num_rendered_reference_lists"] = [o["num_rendered"] for o in o0]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"parity_{cfg_name}.json"), "w") as fh:
+        json.dump(worst, fh, indent=1)
+    print("PARITY", cfg_name, json.dumps(worst))
+    b = BENCH_PARITY_BOUNDS[cfg_name]
+    assert worst["max_abs"] <= b["max_abs"], worst
+    assert worst["mean_abs"] <= b["mean_abs"], worst
+    assert worst["psnr_db"] >= b["psnr_db"], worst
+    assert worst["frac_gt_1e5"] <= b["frac_gt_1e5"], worst
+    assert worst["u8_flipped_pixels"] <= b["u8_flipped_pixels"] and worst["u8_max_lsb"] <= 1, worst
+    assert worst["radii_mismatches"] <= b["radii_mismatches"], worst
+
+
+def test_c2_tile_rows_2_is_bit_identical_to_tile_rows_1():
+    """16 x 32 binning tiles only change which list an instance is found in: every pixel composites the same
+    instances in the same order with the same arithmetic, so the image is the 16 x 16 image bit for bit."""
+    cfg, g, gd, poses, cams, Rasterizer, camera_from = _setup("C2")
+    pair = [camera_from(cams[0][0]), camera_from(cams[0][1])]
+    R = Rasterizer(0)
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+    a = R.render_views(gd, pair, want_rgb8=True)
+    R2 = Rasterizer(0)
+    R2.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+    R2.set_option(_lib.OPT_TILE_ROWS, 2)
+    R2.pack_sh(gd)
+    b = R2.render_views(gd, pair, want_rgb8=True)
+    assert max(b["num_rendered"]) < 0.8 * max(a["num_rendered"])
+    assert np.array_equal(a["color"].cpu().numpy(), b["color"].cpu().numpy())
+    assert np.array_equal(a["rgb8"].cpu().numpy(), b["rgb8"].cpu().numpy())

@@ -237,6 +237,33 @@ def test_arena_overflow_is_detected_and_retried(backend):
     assert_image_close(be.host(img), ref_img)
 
 
+def test_overflow_in_an_earlier_call_is_not_erased_by_a_later_one(backend):
+    """the overflow word is sticky on the device.  Call 1 overflows, call 2 on the same handle (a view that
+    sees nothing of the scene) fits; the status query after both must still report the overflow and what call 1 needed."""
+    W, H, f = 96, 80, 90.0
+    g, s, q, o, shs, left, _ = scene(2000, 8, W, H, f, log_s=math.log(0.08))
+    be = backend
+    d = be.dev
+    r = Rasterizer(0, lib=be.lib)
+    r.reserve(2000, 1, W, H, 1024)
+    kw = dict(shs=d(shs), scales=d(s), rotations=d(q))
+
+    def args(cam):
+        return (d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy)
+
+    away = Camera(0, left.R, np.asarray(left.T) + np.array([0.0, 0.0, -40.0]), left.FoVx, left.FoVy, W, H)  # scene behind
+    r.forward(*args(left), sync=False, **kw)
+    r.forward(*args(away), sync=False, **kw)
+    nr, ov, req = r.status(1)
+    assert nr[0] == 0                     # the last call rendered nothing ...
+    assert ov and req > 1024              # ... and the earlier overflow is still reported
+    nr, ov, req = r.status(1)
+    assert not ov                         # consumed by the query
+    r.forward(*args(away), sync=False, **kw)
+    assert not r.status(1)[1]
+
+
 def test_mark_visible(backend):
     cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 1.0, 0.8, 64, 48)
     xyz = np.random.default_rng(2).uniform(-6, 6, (1000, 3)).astype(np.float32)
