@@ -136,7 +136,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
     }
     switch (option) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
-        case GS2M_OPT_BLEND_VARIANT: r->opt_blend = value; return 0;
+        case GS2M_OPT_BLEND_VARIANT:
+            if (value != 0 && (value < 4 || value > 9)) {
+                gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0, 4 or 7");
+                return 1;
+            }
+            r->opt_blend = value;
+            return 0;
         case GS2M_OPT_TILE_ROWS:
             if (value != 1 && value != 2) {
                 gs2m_set_error("GS2M_OPT_TILE_ROWS must be 1 or 2");
@@ -307,9 +313,9 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "sort_tiles")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
-        // 16 x 32 instance lists: variant 6 (two waves per list, 4 px/lane) unless 5 (one wave, 8 px/lane) is asked for
-        gs2m_launch_blend(st, r->opt_tile_rows == 2 ? (r->opt_blend == 5 ? 5 : 6) : r->opt_blend, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams, g.P, cap,
-                          out_color, out_rgb8);
+        if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
+                              g.P, cap, out_color, out_rgb8))
+            return 1;
     }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;

@@ -99,485 +99,58 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant 1 (k_blend_wave4): ONE WAVE PER 16x16 TILE, 4 pixels per lane (column lane&15, rows
-// (lane>>4) + 4k).  A 256-thread workgroup is four independent waves = four consecutive tiles:
-// no __syncthreads at all, a wave leaves as soon as ITS 256 pixels are saturated.
-//   * per instance the wave pays ONE pair of LDS broadcast reads (2 x ds_read_b128) for 256 pixel
-//     evaluations instead of four (variant 0: one pair per 64 pixels) -> VALU-bound, not LDS-bound;
-//   * dx, a*dx*dx and b*dx are shared by the lane's 4 pixels;
-//   * the accumulate path is entered only if some lane of the wave has a contributing pixel;
-//   * the next 64 records are gathered into registers while the current 64 are composited;
-//   * workgroup -> tile-group mapping is XCD-aware (block b runs on XCD b%8: give each XCD a
-//     contiguous run of tiles so neighbouring tiles, which share Gaussians, hit the same L2).
+// Variant 4 (k_blend_wave4e): ONE WAVE PER 16x16 TILE, 4 pixels per lane laid out as the tile's four 8x8 QUADRANTS
+// (lane l: x = l&7, y = l>>3, plus (0|8, 0|8)).  A 256-thread workgroup is four independent waves = four consecutive
+// tiles: no __syncthreads at all, a wave leaves as soon as ITS 256 pixels are saturated.
+//   * per instance the wave pays one set of LDS broadcast reads for 256 pixel evaluations; dx terms are shared by the
+//     lane's pixels;
+//   * the 48-B records of the NEXT 64 instances are gathered from HBM straight into LDS by the DMA path
+//     (global_load_lds_dwordx4: no VGPR holds them while the current 64 are composited), their ids one batch earlier;
+//   * a per-instance 4-bit quadrant mask, computed while staging from the bounding box of the alpha >= 1/255 ellipse
+//     (|dx| <= sqrt(2 t cov_xx), |dy| <= sqrt(2 t cov_yy), t = ln(255 o); cov = conic^-1), skips quadrants with a scalar
+//     branch;
+//   * the exponent is kept in the log2 domain: the staging lane folds log2(e) into the conic and log2(opacity) into the
+//     constant term,  q = (a' dx^2 + log2 o) + c' dy^2 - b' dx dy,  alpha = exp2(q)  (1 v_exp_f32), so the
+//     alpha >= 1/255 pre-filter is q >= -log2(255);
+//   * every per-pixel decision is a LANE MASK in scalar registers (v_cmp + s_and*): the finished pixels of each quadrant
+//     (parking a pixel costs no vector op; a finished quadrant is removed from every instance's quadrant mask), the
+//     candidates, the saturating ones; v_cndmask takes the mask directly (gs2m_lanes);
+//   * the reference's power > 0 test and alpha cap (forward.cu:336-343) only run for the instances where they can matter
+//     (opacity > 0.98, or a conic within 1e-3 of singular), flagged while staging: 9 vector ops per contributing
+//     (instance, quadrant) -- exp, T' = fma(-T, alpha, T), compare, select, w = T - T', 3 colour FMAs, move;
+//   * workgroup -> tile-group mapping is XCD-aware (block b runs on XCD b%8: each XCD gets a contiguous run of tiles, so
+//     neighbouring tiles, which share Gaussians, hit the same L2).
+// Decisions are the reference's (same thresholds, same order); roundings of ~1 ulp in q (|q| <= 8) -> relative 1e-6 in alpha.
+// LROWS = reference tiles per instance list (GS2M_OPT_TILE_ROWS): with 2 the binning stages handle ~30 % fewer
+// (Gaussian, tile) instances; two waves walk the same 16 x 32 list, each compositing its own 16 x 16 half (instances that
+// miss the half are dropped while staging, by ballot compaction).  A quadrant outside the instance's 16 x 16 tile rect is
+// masked, so the reference's rect still bounds every contribution: the image is the 16 x 16 image bit for bit.
+// Measured ladder (C2, us per pair): r1 all-VALU kernel 250 -> lane masks + flagged general path 245 -> 7 waves/SIMD 235
+// -> DMA prefetch (this file).  The kernel is bound by VALU issue (one wave64 op per 4 cycles per SIMD in practice:
+// 136 M ops -> 221 us); PMC in profiles/r2*.
 // ---------------------------------------------------------------------------------------------
-GS2M_KERNEL void __launch_bounds__(256)
-k_blend_wave4(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
-              const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-              float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
-    __shared__ float4 s_a[4][64];
-    __shared__ float4 s_b[4][64];
-    __shared__ float s_c[4][64];
-    const int tid = (int)threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int v = (int)blockIdx.y;
-    const CamUniform& cam = cams[v];
-    const int W = cam.W, H = cam.H, gx = cam.gx;
-    const int tiles = gx * cam.gy;
-    // bijective XCD swizzle (guide T1)
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
-    const unsigned grp = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
-    const int tile = (int)(grp * 4u) + wave;
-    if (tile >= tiles) return;  // whole wave; no workgroup barriers in this kernel
-    const int tx = tile % gx, ty = tile / gx;
-    const int pxi = tx * GS2M_TILE + (lane & 15);
-    const int py0 = ty * GS2M_TILE + (lane >> 4);
-    const float pxf = (float)pxi;
-    float pyf[4];
-    bool done[4];
-    float T[4], C0[4], C1[4], C2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        pyf[k] = (float)(py0 + 4 * k);
-        done[k] = !(pxi < W && py0 + 4 * k < H);
-        T[k] = 1.0f;
-        C0[k] = C1[k] = C2[k] = 0.0f;
-    }
-    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
-    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
-    if (r0 > cap) r0 = cap;
-    if (r1 > cap) r1 = cap;
-    const unsigned long long* kv = keys + (size_t)v * cap;
-    const GeomRec* rv = recs + (size_t)v * P;
-    float4 ra, rb;
-    float rc = 0.0f;
-    ra.x = ra.y = ra.z = ra.w = 0.0f;
-    rb = ra;
-    unsigned base = r0;
-    if (base + (unsigned)lane < r1) {
-        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-        ra = r4[0];
-        rb = r4[1];
-        rc = r4[2].x;
-    }
-    while (base < r1) {
-        const bool all_done = done[0] && done[1] && done[2] && done[3];
-        if (gs2m_ballot(all_done ? 0 : 1) == 0ull) break;
-        gs2m_wave_sync();  // the previous batch has been read by every lane
-        s_a[wave][lane] = ra;
-        s_b[wave][lane] = rb;
-        s_c[wave][lane] = rc;
-        gs2m_wave_sync();
-        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
-        base += 64u;
-        if (base + (unsigned)lane < r1) {  // gather the next batch while this one is composited
-            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-            ra = r4[0];
-            rb = r4[1];
-            rc = r4[2].x;
-        }
-        for (int j = 0; j < nb; ++j) {
-            const float4 A = s_a[wave][j];
-            const float4 B = s_b[wave][j];
-            const float dx = A.x - pxf;
-            const float adx2 = A.z * dx * dx;
-            const float bdx = A.w * dx;
-            float alpha[4];
-            bool hit[4];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dy = A.y - pyf[k];
-                const float power = -0.5f * (adx2 + B.x * dy * dy) - bdx * dy;
-                alpha[k] = fminf(0.99f, B.y * gs2m_fast_exp(power));
-                hit[k] = !done[k] && !(power > 0.0f) && !(alpha[k] < 1.0f / 255.0f);
-                any = any || hit[k];
-            }
-            if (gs2m_ballot(any ? 1 : 0) != 0ull) {
-                const float cb = s_c[wave][j];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (hit[k]) {
-                        const float test_T = T[k] * (1.0f - alpha[k]);
-                        if (test_T < 0.0001f) {
-                            done[k] = true;
-                        } else {
-                            C0[k] += B.z * alpha[k] * T[k];
-                            C1[k] += B.w * alpha[k] * T[k];
-                            C2[k] += cb * alpha[k] * T[k];
-                            T[k] = test_T;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    const size_t plane = (size_t)H * W;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int pyi = py0 + 4 * k;
-        if (pxi < W && pyi < H) {
-            const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];
-            const size_t pix = (size_t)pyi * W + pxi;
-            if (out_color) {
-                float* oc = out_color + (size_t)v * 3 * plane;
-                oc[pix] = o0;
-                oc[plane + pix] = o1;
-                oc[2 * plane + pix] = o2;
-            }
-            if (out_rgb8) {
-                unsigned char* o8 = out_rgb8 + ((size_t)v * plane + pix) * 3;
-                o8[0] = quantize_u8(o0);
-                o8[1] = quantize_u8(o1);
-                o8[2] = quantize_u8(o2);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Variant 2 (k_blend_wave4p): variant 1's layout with a cheaper inner loop.  The kernel is
-// VALU-bound (measured: ~300 issue cycles per instance x 256 pixels in variant 1), so the loop is
-// rebuilt around instruction count:
-//   * alpha >= 1/255  <=>  power >= -ln(255*opacity).  A per-instance limit lim = -ln(255 o) - 1e-4
-//     (computed once per instance while staging, kept in LDS) gives a conservative one-compare
-//     pre-filter per pixel; exp() and the exact alpha test of the reference run only inside the
-//     accumulate path, and only for the 16x4 strips (the lane's pixel index k) in which some lane
-//     passed the pre-filter;
-//   * a finished pixel is parked at y = 1e18 (its power becomes hugely negative), which removes
-//     every per-pixel "done" flag from the hot path;
-//   * the accumulate path is straight-line predicated arithmetic (weights selected to 0), no
-//     per-pixel exec-mask regions.
-// Decisions are the reference's (same alpha, same thresholds, same order): the pre-filter only
-// skips pixels whose exact test would fail.
-// ---------------------------------------------------------------------------------------------
-#define GS2M_PARKED 1.0e18f
-
-GS2M_KERNEL void __launch_bounds__(256)
-k_blend_wave4p(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
-               const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
-    __shared__ float4 s_a[4][64];  // mx, my, ca, cb
-    __shared__ float4 s_b[4][64];  // cc, op, r, g
-    __shared__ float2 s_c[4][64];  // b, lim
-    const int tid = (int)threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int v = (int)blockIdx.y;
-    const CamUniform& cam = cams[v];
-    const int W = cam.W, H = cam.H, gx = cam.gx;
-    const int tiles = gx * cam.gy;
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
-    const unsigned grp = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
-    const int tile = (int)(grp * 4u) + wave;
-    if (tile >= tiles) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int pxi = tx * GS2M_TILE + (lane & 15);
-    const int py0 = ty * GS2M_TILE + (lane >> 4);
-    const float pxf = (float)pxi;
-    float pyf[4], T[4], C0[4], C1[4], C2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        pyf[k] = (pxi < W && py0 + 4 * k < H) ? (float)(py0 + 4 * k) : GS2M_PARKED;
-        T[k] = 1.0f;
-        C0[k] = C1[k] = C2[k] = 0.0f;
-    }
-    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
-    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
-    if (r0 > cap) r0 = cap;
-    if (r1 > cap) r1 = cap;
-    const unsigned long long* kv = keys + (size_t)v * cap;
-    const GeomRec* rv = recs + (size_t)v * P;
-    float4 ra, rb;
-    float rc = 0.0f;
-    ra.x = ra.y = ra.z = ra.w = 0.0f;
-    rb = ra;
-    unsigned base = r0;
-    if (base + (unsigned)lane < r1) {
-        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-        ra = r4[0];
-        rb = r4[1];
-        rc = r4[2].x;
-    }
-    while (base < r1) {
-        const bool live = pyf[0] < 1.0e17f || pyf[1] < 1.0e17f || pyf[2] < 1.0e17f || pyf[3] < 1.0e17f;
-        if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
-        gs2m_wave_sync();
-        s_a[wave][lane] = ra;
-        s_b[wave][lane] = rb;
-        float2 cl;
-        cl.x = rc;
-        // alpha >= 1/255 <=> power >= -ln(255*o); opacity*255 < 1 never contributes (lim > 0 >= power)
-        cl.y = -gs2m_fast_log(rb.y * 255.0f) - 1.0e-4f;
-        s_c[wave][lane] = cl;
-        gs2m_wave_sync();
-        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
-        base += 64u;
-        if (base + (unsigned)lane < r1) {
-            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-            ra = r4[0];
-            rb = r4[1];
-            rc = r4[2].x;
-        }
-        for (int j = 0; j < nb; ++j) {
-            const float4 A = s_a[wave][j];
-            const float4 B = s_b[wave][j];
-            const float2 CL = s_c[wave][j];
-            const float dx = A.x - pxf;
-            const float adx2 = A.z * dx * dx;
-            const float bdx = A.w * dx;
-            float power[4];
-            bool cand[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dy = A.y - pyf[k];
-                power[k] = -0.5f * (adx2 + B.x * dy * dy) - bdx * dy;
-                cand[k] = power[k] >= CL.y && !(power[k] > 0.0f);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (gs2m_ballot(cand[k] ? 1 : 0) != 0ull) {  // wave-uniform: strip k has a candidate
-                    const float alpha = fminf(0.99f, B.y * gs2m_fast_exp(power[k]));
-                    const bool hit = cand[k] && !(alpha < 1.0f / 255.0f);
-                    const float test_T = T[k] * (1.0f - alpha);
-                    const bool sat = hit && test_T < 0.0001f;
-                    const bool acc = hit && !sat;
-                    const float w = acc ? alpha : 0.0f;
-                    C0[k] += B.z * w * T[k];
-                    C1[k] += B.w * w * T[k];
-                    C2[k] += CL.x * w * T[k];
-                    T[k] = acc ? test_T : T[k];
-                    pyf[k] = sat ? GS2M_PARKED : pyf[k];
-                }
-            }
-        }
-    }
-    const size_t plane = (size_t)H * W;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int pyi = py0 + 4 * k;
-        if (pxi < W && pyi < H) {
-            const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];
-            const size_t pix = (size_t)pyi * W + pxi;
-            if (out_color) {
-                float* oc = out_color + (size_t)v * 3 * plane;
-                oc[pix] = o0;
-                oc[plane + pix] = o1;
-                oc[2 * plane + pix] = o2;
-            }
-            if (out_rgb8) {
-                unsigned char* o8 = out_rgb8 + ((size_t)v * plane + pix) * 3;
-                o8[0] = quantize_u8(o0);
-                o8[1] = quantize_u8(o1);
-                o8[2] = quantize_u8(o2);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Variant 3 (k_blend_wave4q): variant 2 with the lane's four pixels laid out as the four 8x8
-// QUADRANTS of the tile (lane l: x = l&7, y = l>>3, plus (0|8, 0|8)), and a per-instance 4-bit
-// quadrant mask computed while staging from the bounding box of the alpha >= 1/255 ellipse
-// (|dx| <= sqrt(2 t cov_xx), |dy| <= sqrt(2 t cov_yy), t = ln(255 o); cov = conic^-1).  A quadrant
-// whose 8x8 pixels lie outside that box is skipped with a scalar branch: for a splat of radius r the
-// evaluated pixel groups drop from 4 per touched tile to ~(1 + 2r/8)^2 / (1 + 2r/16)^2 (44 % at
-// r = 15 px, 40 % at r = 5 px).  Same decisions as the reference: the mask, like the pre-filter, only
-// removes pixels whose exact alpha test would fail.
-// ---------------------------------------------------------------------------------------------
-GS2M_KERNEL void __launch_bounds__(256)
-k_blend_wave4q(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
-               const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
-    __shared__ float4 s_a[4][64];  // mx, my, ca, cb
-    __shared__ float4 s_b[4][64];  // cc, op, r, g
-    __shared__ float4 s_c[4][64];  // b, lim, quadrant mask (bits), -
-    const int tid = (int)threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int v = (int)blockIdx.y;
-    const CamUniform& cam = cams[v];
-    const int W = cam.W, H = cam.H, gx = cam.gx;
-    const int tiles = gx * cam.gy;
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    const unsigned q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
-    const unsigned grp = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
-    const int tile = (int)(grp * 4u) + wave;
-    if (tile >= tiles) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
-    // pixel k: x = px0 + 8*(k&1), y = py0 + 8*(k>>1)
-    const float pxf0 = (float)px0, pxf1 = (float)(px0 + 8);
-    float pyf[4], T[4], C0[4], C1[4], C2[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
-        pyf[k] = (x < W && y < H) ? (float)y : GS2M_PARKED;
-        T[k] = 1.0f;
-        C0[k] = C1[k] = C2[k] = 0.0f;
-    }
-    // quadrant pixel ranges (tile-uniform)
-    const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * GS2M_TILE);
-    unsigned r0 = tile_start[(size_t)v * (tiles + 1) + tile];
-    unsigned r1 = tile_start[(size_t)v * (tiles + 1) + tile + 1];
-    if (r0 > cap) r0 = cap;
-    if (r1 > cap) r1 = cap;
-    const unsigned long long* kv = keys + (size_t)v * cap;
-    const GeomRec* rv = recs + (size_t)v * P;
-    float4 ra, rb;
-    float rc = 0.0f;
-    ra.x = ra.y = ra.z = ra.w = 0.0f;
-    rb = ra;
-    unsigned base = r0;
-    if (base + (unsigned)lane < r1) {
-        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-        ra = r4[0];
-        rb = r4[1];
-        rc = r4[2].x;
-    }
-    while (base < r1) {
-        const bool live = pyf[0] < 1.0e17f || pyf[1] < 1.0e17f || pyf[2] < 1.0e17f || pyf[3] < 1.0e17f;
-        if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
-        gs2m_wave_sync();
-        {
-            // per-instance constants, computed once by the staging lane
-            const float lim = -gs2m_fast_log(rb.y * 255.0f) - 1.0e-4f;   // alpha >= 1/255 <=> power >= lim
-            const float t2 = fmaxf(-2.0f * lim, 0.0f);                    // 2 ln(255 o) (+ margin)
-            const float det = ra.z * rb.x - ra.w * ra.w;                  // conic determinant (> 0)
-            const float inv = 1.0f / det;
-            const float hx = sqrtf(t2 * rb.x * inv) * 1.001f + 0.01f;     // cov_xx = cc/det
-            const float hy = sqrtf(t2 * ra.z * inv) * 1.001f + 0.01f;     // cov_yy = ca/det
-            const bool xl = ra.x - hx <= qx0 + 7.0f, xr = ra.x + hx >= qx0 + 8.0f;
-            const bool yt = ra.y - hy <= qy0 + 7.0f, yb = ra.y + hy >= qy0 + 8.0f;
-            unsigned m = 0u;
-            if (!(lim > 0.0f) && det > 0.0f) {
-                if (xl && yt) m |= 1u;
-                if (xr && yt) m |= 2u;
-                if (xl && yb) m |= 4u;
-                if (xr && yb) m |= 8u;
-            } else if (!(det > 0.0f)) {
-                m = 15u;  // degenerate conic: no box, test every pixel
-            }
-            float4 cl;
-            cl.x = rc;
-            cl.y = lim;
-            cl.z = __uint_as_float(m);
-            cl.w = 0.0f;
-            s_c[wave][lane] = cl;
-            // conic pre-scaled by -0.5 (exact: power of two), so that
-            // power = -0.5*(a dx^2 + c dy^2) - b dx dy = (a' dx^2 + c' dy^2) - b dx dy bit for bit
-            float4 sa = ra, sb = rb;
-            sa.z = -0.5f * ra.z;
-            sb.x = -0.5f * rb.x;
-            s_a[wave][lane] = sa;
-            s_b[wave][lane] = sb;
-        }
-        gs2m_wave_sync();
-        const int nb = (int)(r1 - base) < 64 ? (int)(r1 - base) : 64;
-        base += 64u;
-        if (base + (unsigned)lane < r1) {
-            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-            ra = r4[0];
-            rb = r4[1];
-            rc = r4[2].x;
-        }
-        for (int j = 0; j < nb; ++j) {
-            const float4 CL = s_c[wave][j];
-            const int qm = gs2m_uniform((int)__float_as_uint(CL.z));
-            if (qm == 0) continue;
-            const float4 A = s_a[wave][j];
-            const float4 B = s_b[wave][j];
-            const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
-            const float adx2[2] = {A.z * dx0 * dx0, A.z * dx1 * dx1};
-            const float bdx[2] = {A.w * dx0, A.w * dx1};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
-                    const float dy = A.y - pyf[k];
-                    const float power = (adx2[k & 1] + B.x * dy * dy) - bdx[k & 1] * dy;
-                    const bool cand = power >= CL.y && !(power > 0.0f);
-                    if (gs2m_ballot(cand ? 1 : 0) != 0ull) {
-                        const float alpha = fminf(0.99f, B.y * gs2m_fast_exp(power));
-                        const bool hit = cand && !(alpha < 1.0f / 255.0f);
-                        const float test_T = T[k] * (1.0f - alpha);
-                        const bool sat = hit && test_T < 0.0001f;
-                        const bool acc = hit && !sat;
-                        const float w = acc ? alpha : 0.0f;
-                        C0[k] += B.z * w * T[k];
-                        C1[k] += B.w * w * T[k];
-                        C2[k] += CL.x * w * T[k];
-                        T[k] = acc ? test_T : T[k];
-                        pyf[k] = sat ? GS2M_PARKED : pyf[k];
-                    }
-                }
-            }
-        }
-    }
-    const size_t plane = (size_t)H * W;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int pxi = px0 + 8 * (k & 1), pyi = py0 + 8 * (k >> 1);
-        if (pxi < W && pyi < H) {
-            const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];
-            const size_t pix = (size_t)pyi * W + pxi;
-            if (out_color) {
-                float* oc = out_color + (size_t)v * 3 * plane;
-                oc[pix] = o0;
-                oc[plane + pix] = o1;
-                oc[2 * plane + pix] = o2;
-            }
-            if (out_rgb8) {
-                unsigned char* o8 = out_rgb8 + ((size_t)v * plane + pix) * 3;
-                o8[0] = quantize_u8(o0);
-                o8[1] = quantize_u8(o1);
-                o8[2] = quantize_u8(o2);
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Variant 4 (k_blend_wave4e): variant 3 with the exponent kept in the log2 domain.  The staging lane
-// folds log2(e) into the conic and log2(opacity) into the constant term,
-//   q = (a' dx^2 + log2 o) + c' dy^2 - b' dx dy,   alpha = min(0.99, exp2(q))        (1 v_exp_f32),
-// so the per-pixel path has no multiply by log2(e) and none by the opacity; the alpha >= 1/255
-// pre-filter becomes q >= -log2(255) (constant), power > 0 becomes q > log2 o.  The accumulate path is
-// written for the fewest VALU ops: test_T = fma(-T, alpha, T), one w*T product shared by the three
-// colour FMAs.  Batch bounds are wave-uniform scalars (scalar loop control).  Differences from
-// variant 3 are roundings of ~1 ulp in q (|q| <= 8) -> relative 1e-6 in alpha; same tolerance.
-// ---------------------------------------------------------------------------------------------
-struct alignas(16) BlendInst {
+struct BlendInst {
     float4 a, b;
-    float2 c, pad;
+    float2 c;
 };
 
-template <int WPB, int ROWS, int LROWS>
-GS2M_KERNEL void __launch_bounds__(64 * WPB)
+template <int WPB, int LROWS, int OCC>
+GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
-    // 48-B staged instance: a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc, log2 o, r, g},
-    // c = {b, quadrant mask (bits)}; one LDS address + immediate offsets per instance.  2 pad slots: the
-    // software-pipelined reads run up to 2 instances ahead.
-    // ROWS = reference tiles (16 x 16) composited by one wave, stacked vertically: 1 = 4 pixels per lane, 2 = 8.
-    // LROWS = reference tiles per instance list (GS2M_OPT_TILE_ROWS): with 2 the binning stages handle ~30 % fewer
-    // (Gaussian, tile) instances.  <ROWS 1, LROWS 2>: two waves walk the same 16 x 32 list, each compositing its own
-    // 16 x 16 half (instances that miss the half cost a skipped iteration); <2, 2>: one wave, 8 pixels per lane
-    // (fewer instructions, but 103 VGPRs -> 4 waves/SIMD: measured slower).  A quadrant outside the instance's
-    // 16 x 16 tile rect is masked, so the reference's rect still bounds every contribution.
-    constexpr int NQ = 4 * ROWS, TH = GS2M_TILE * ROWS;
-    __shared__ BlendInst s_i[WPB][64 + 2];
+    // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
+    // log2 o, r, g}, c = {b, quadrant mask | general << 8 (bits)}; 2 pad slots: the software-pipelined reads run 2
+    // instances ahead.  5.6 KiB of LDS per wave with the DMA landing zone: 7 waves per SIMD fit the 160 KiB.
+    __shared__ float4 s_a[WPB][64 + 2], s_b[WPB][64 + 2];
+    __shared__ float2 s_c[WPB][64 + 2];
+    __shared__ float4 s_raw[WPB][3][64];   // DMA landing zone: the three 16-B vectors of the next batch's GeomRecs
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int v = (int)blockIdx.y;
     const CamUniform& cam = cams[v];
     const int W = cam.W, H = cam.H, gx = cam.gx;
-    const int tiles = gx * ((cam.gy + ROWS - 1) / ROWS);        // tiles composited by waves
+    const int tiles = gx * cam.gy;                              // tiles composited by waves
     const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);    // instance lists
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
@@ -585,20 +158,23 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const int tile = gs2m_uniform((int)(grp * (unsigned)WPB) + wave);
     if (tile >= tiles) return;
     const int tx = tile % gx, ty = tile / gx;
-    const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * TH + (lane >> 3);
-    float pxf0 = (float)px0, pxf1 = (float)(px0 + 8);
+    const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
+    float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
     GS2M_KEEP_F32(pxf0);
     GS2M_KEEP_F32(pxf1);
-    float pyf[NQ], T[NQ], C0[NQ], C1[NQ], C2[NQ];
+    GS2M_KEEP_F32(pyf0);
+    GS2M_KEEP_F32(pyf1);
+    float T[4], C0[4], C1[4], C2[4];
+    unsigned long long dn[4];  // finished (or outside-the-image) pixels of quadrant k: lane mask in scalar registers
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
-        pyf[k] = (x < W && y < H) ? (float)y : GS2M_PARKED;
         T[k] = 1.0f;
         C0[k] = C1[k] = C2[k] = 0.0f;
+        dn[k] = gs2m_ballot_b(!(x < W && y < H));
     }
-    const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * TH);
-    const int ltile = (ty * ROWS / LROWS) * gx + tx;
+    const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * GS2M_TILE);
+    const int ltile = (ty / LROWS) * gx + tx;
     unsigned r0 = tile_start[(size_t)v * (ltiles + 1) + ltile];
     unsigned r1 = tile_start[(size_t)v * (ltiles + 1) + ltile + 1];
     if (r0 > cap) r0 = cap;
@@ -609,49 +185,54 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const GeomRec* rv = recs + (size_t)v * P;
     const float LOG2E = 1.44269504088896340736f;
     const float QMIN = -7.99435343685885793770f;  // -log2(255): alpha >= 1/255 <=> q >= QMIN (decided in the log2 domain)
-    float4 ra, rb, rc;  // the three 16-B vectors of a GeomRec
-    ra.x = ra.y = ra.z = ra.w = 0.0f;
-    rb = ra;
-    rc = ra;
-    rb.y = 1.0f;
+    // ---- prefetch pipeline: ids two batches ahead (one VGPR), records one batch ahead (DMA into LDS) ----
     unsigned base = r0;
-    if (base + (unsigned)lane < r1) {
-        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-        const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-        ra = r4[0];
-        rb = r4[1];
-        rc = r4[2];
+    unsigned gid_next = 0u;   // Gaussian id of instance base + 64 + lane
+    {
+        unsigned gid = 0u;
+        if (base + (unsigned)lane < r1) gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+        if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)(kv[base + 64u + lane] & 0xffffffffull);
+        if (base + (unsigned)lane < r1) {
+            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+            gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
+            gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
+            gs2m_global_load_lds16(r4 + 2, &s_raw[wave][2][0]);
+        }
     }
     while (base < r1) {
-        bool live = false;
+        unsigned lq = 0u;  // quadrants that still have unfinished pixels
 #pragma unroll
-        for (int k = 0; k < NQ; ++k) live = live || pyf[k] < 1.0e17f;
-        if (gs2m_ballot(live ? 1 : 0) == 0ull) break;
-        gs2m_wave_sync();
+        for (int k = 0; k < 4; ++k) lq |= (dn[k] != ~0ull ? 1u : 0u) << k;
+        if (lq == 0u) break;
+        gs2m_wait_dma();       // this batch's records have landed in s_raw
+        gs2m_wave_sync();      // ... and the previous batch's staged instances have been read by every lane
         int nb_staged = 0;
         {
-            const float lo = gs2m_fast_log2(rb.y);                         // log2 o
-            const float t2 = fmaxf(2.0f * (gs2m_fast_log(rb.y * 255.0f) + 1.0e-4f), 0.0f);  // 2 ln(255 o) (+ margin)
+            const float4 ra = s_raw[wave][0][lane], rb = s_raw[wave][1][lane], rc = s_raw[wave][2][lane];
+            const bool have = base + (unsigned)lane < r1;
+            const float op = have ? rb.y : 1.0f;
+            const float lo = gs2m_fast_log2(op);                           // log2 o
+            const float t2 = fmaxf(2.0f * (gs2m_fast_log(op * 255.0f) + 1.0e-4f), 0.0f);  // 2 ln(255 o) (+ margin)
             const float det = ra.z * rb.x - ra.w * ra.w;                   // conic determinant (> 0)
             const float inv = 1.0f / det;
             const float hx = sqrtf(t2 * rb.x * inv) * 1.001f + 0.01f;      // cov_xx = cc/det
             const float hy = sqrtf(t2 * ra.z * inv) * 1.001f + 0.01f;      // cov_yy = ca/det
             const bool xl = ra.x - hx <= qx0 + 7.0f, xr = ra.x + hx >= qx0 + 8.0f;
-            const bool box = rb.y * 255.0f >= 0.9999f && det > 0.0f;
+            const bool box = op * 255.0f >= 0.9999f && det > 0.0f;
             const bool degenerate = !(det > 0.0f);  // no box: test every pixel of the tile rect
             const int ry0 = (int)(__float_as_uint(rc.z) >> 16), ry1 = (int)(__float_as_uint(rc.w) >> 16);  // rect rows, 16-px units
             unsigned m = 0u;
 #pragma unroll
-            for (int qr = 0; qr < 2 * ROWS; ++qr) {  // 8-pixel quadrant rows of the tile
+            for (int qr = 0; qr < 2; ++qr) {  // 8-pixel quadrant rows of the tile
                 const float top = qy0 + 8.0f * (float)qr;
                 bool row = degenerate || (box && ra.y - hy <= top + 7.0f && ra.y + hy >= top);
-                if (LROWS > 1) {  // the quadrant must lie in a 16 x 16 tile of the instance's rect
-                    const int y16 = ty * ROWS + (qr >> 1);
-                    row = row && y16 >= ry0 && y16 < ry1;
-                }
+                if (LROWS > 1) row = row && ty >= ry0 && ty < ry1;  // the 16 x 16 tile must lie in the instance's rect
                 if (row && (degenerate || xl)) m |= 1u << (2 * qr);
                 if (row && (degenerate || xr)) m |= 2u << (2 * qr);
             }
+            // general path (power > 0 test + alpha cap) only where it can matter: opacity near the 0.99 cap, or a conic so
+            // close to singular that rounding could make the quadratic form negative
+            const bool general = !(op <= 0.98f) || !(ra.z > 0.0f && rb.x > 0.0f && det >= 1.0e-3f * ra.z * rb.x);
             BlendInst bi;
             bi.a = ra;
             bi.b = rb;
@@ -660,55 +241,67 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             bi.b.x = (-0.5f * LOG2E) * rb.x;
             bi.b.y = lo;
             bi.c.x = rc.x;
-            bi.c.y = __uint_as_float(m);
-            bi.pad = bi.c;
-            if (LROWS > ROWS) {
+            bi.c.y = __uint_as_float(m | (general ? 0x100u : 0u));
+            if (LROWS > 1) {
                 // the list also serves the other half of the 16 x 32 tile: stage only the instances that reach this
                 // half (ballot compaction), so the compositing loop never iterates over the others
-                const bool mine = m != 0u && base + (unsigned)lane < r1;
-                const unsigned long long keep = gs2m_ballot(mine ? 1 : 0);
-                if (mine) s_i[wave][gs2m_popc64(keep & ((1ull << lane) - 1ull))] = bi;
+                const bool mine = m != 0u && have;
+                const unsigned long long keep = gs2m_ballot_b(mine);
+                const int slot = gs2m_popc64(keep & ((1ull << lane) - 1ull));
+                if (mine) {
+                    s_a[wave][slot] = bi.a;
+                    s_b[wave][slot] = bi.b;
+                    s_c[wave][slot] = bi.c;
+                }
                 nb_staged = gs2m_popc64(keep);
             } else {
-                s_i[wave][lane] = bi;
+                s_a[wave][lane] = bi.a;
+                s_b[wave][lane] = bi.b;
+                s_c[wave][lane] = bi.c;
             }
         }
-        gs2m_wave_sync();
-        const int nb = LROWS > ROWS ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
+        gs2m_wave_sync();   // s_raw has been consumed, the staged batch is complete
+        const int nb = LROWS > 1 ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
         base += 64u;
-        if (base + (unsigned)lane < r1) {
-            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-            ra = r4[0];
-            rb = r4[1];
-            rc = r4[2];
+        if (base + (unsigned)lane < r1) {  // records of the next batch -> LDS while this one is composited
+            const float4* r4 = reinterpret_cast<const float4*>(rv + gid_next);
+            gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
+            gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
+            gs2m_global_load_lds16(r4 + 2, &s_raw[wave][2][0]);
         }
+        if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)(kv[base + 64u + lane] & 0xffffffffull);
         // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
         // constants are in flight while instance j is composited (no LDS wait on the critical path).
-        auto step = [&](const int qm, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+        auto step = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+            const int qm = qmf & (int)lq;
             if (qm != 0) {
                 const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
                 const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
                 const float nbdx[2] = {-(A.w * dx0), -(A.w * dx1)};
 #pragma unroll
-                for (int k = 0; k < NQ; ++k) {
-                    if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box
-                        const float dy = A.y - pyf[k];
+                for (int k = 0; k < 4; ++k) {
+                    if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box and has unfinished pixels
+                        const float dy = A.y - ((k >> 1) ? pyf1 : pyf0);
                         // q = e + dy (c' dy - b' dx): two FMAs
                         const float qv = fmaf(fmaf(B.x, dy, nbdx[k & 1]), dy, e[k & 1]);
-                        const bool pre = qv >= QMIN;
-                        if (gs2m_ballot(pre ? 1 : 0) != 0ull) {
-                            const bool cand = pre && !(qv > B.y);  // power > 0 (numerically non-PSD conic): skipped
-                            const float alpha = fminf(0.99f, gs2m_fast_exp2(qv));
+                        const unsigned long long prem = gs2m_ballot_b(qv >= QMIN) & ~dn[k];   // v_cmp + s_andn2
+                        if (prem != 0ull) {
+                            float alpha = gs2m_fast_exp2(qv);
+                            unsigned long long candm = prem;
+                            if (qmf & 0x100) {                                 // scalar branch: general path (rare)
+                                GS2M_NO_IF_CONVERT();
+                                candm = prem & ~gs2m_ballot_b(qv > B.y);       // power > 0: skipped (forward.cu:336-337)
+                                alpha = fminf(0.99f, alpha);
+                            }
                             const float test_T = fmaf(-T[k], alpha, T[k]);
-                            const bool sat = cand && test_T < 0.0001f;
-                            const float Tn = (cand && !sat) ? test_T : T[k];
+                            const unsigned long long satm = gs2m_ballot_b(test_T < 0.0001f) & candm;
+                            const float Tn = gs2m_lanes(candm & ~satm) ? test_T : T[k];
                             const float wT = T[k] - Tn;  // = alpha * T for an accepted contribution, else 0
                             C0[k] = fmaf(B.z, wT, C0[k]);
                             C1[k] = fmaf(B.w, wT, C1[k]);
                             C2[k] = fmaf(CL.x, wT, C2[k]);
                             T[k] = Tn;
-                            pyf[k] = sat ? GS2M_PARKED : pyf[k];
+                            dn[k] |= satm;
                         }
                     }
                 }
@@ -716,31 +309,33 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         };
         // The quadrant mask is read (= the LDS wait) BEFORE the next instance's reads are issued, so the
         // wait never covers a read that was just issued (the compiler's waitcnt is lgkmcnt(0) in this loop).
-        const BlendInst* sp = &s_i[wave][0];
-        float4 A0 = sp[0].a, B0 = sp[0].b, A1, B1;
-        float2 K0 = sp[0].c, K1;
+        const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
+        const float2* spc = &s_c[wave][0];
+        float4 A0 = spa[0], B0 = spb[0], A1, B1;
+        float2 K0 = spc[0], K1;
         int j = 0;
         for (; j + 1 < nb; j += 2) {
             const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
             GS2M_SCHED_BARRIER();
-            A1 = sp[j + 1].a;
-            B1 = sp[j + 1].b;
-            K1 = sp[j + 1].c;
+            A1 = spa[j + 1];
+            B1 = spb[j + 1];
+            K1 = spc[j + 1];
             GS2M_SCHED_BARRIER();
             step(qm0, K0, A0, B0);
             const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
             GS2M_SCHED_BARRIER();
-            A0 = sp[j + 2].a;
-            B0 = sp[j + 2].b;
-            K0 = sp[j + 2].c;
+            A0 = spa[j + 2];
+            B0 = spb[j + 2];
+            K0 = spc[j + 2];
             GS2M_SCHED_BARRIER();
             step(qm1, K1, A1, B1);
         }
         if (j < nb) step(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
     }
+    gs2m_wait_dma();   // never leave with a DMA write to this workgroup's LDS in flight
     const size_t plane = (size_t)H * W;
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const int pxi = px0 + 8 * (k & 1), pyi = py0 + 8 * (k >> 1);
         if (pxi < W && pyi < H) {
             const float o0 = C0[k] + T[k] * cam.bg[0], o1 = C1[k] + T[k] * cam.bg[1], o2 = C2[k] + T[k] * cam.bg[2];

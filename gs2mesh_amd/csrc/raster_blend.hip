@@ -1,48 +1,40 @@
 // raster_blend.hip -- compositing stage (default FMA contraction; VALU-bound inner loop).
 #include <cstdlib>
 #include "raster_blend.h"
+#include "raster_blend_mfma.h"
 #include "raster_internal.h"
 
-// gy = rows of the 16 x 16 reference grid; variants 5 / 6 read instance lists of 16 x 32 tiles (GS2M_OPT_TILE_ROWS 2)
-void gs2m_launch_blend(hipStream_t st, int variant, int nv, int gx, int gy, const unsigned long long* keys,
-                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
-                       unsigned cap, float* out_color, unsigned char* out_rgb8) {
-    if (variant == 6) {  // 16 x 32 lists, one wave per 16 x 16 half
-        const int tiles = gx * gy;
-        GS2M_LAUNCH((k_blend_wave4e<4, 1, 2>), dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P,
-                    cap, out_color, out_rgb8);
-        return;
+// gy = rows of the 16 x 16 reference grid; tile_rows = 16 x 16 tiles per instance list (GS2M_OPT_TILE_ROWS)
+//   variant 7: exponents on the matrix cores (k_blend_mfma), 4: all-VALU wave-per-tile kernel (k_blend_wave4e),
+//   0: the reference's structure (256-thread workgroup per tile, 1 pixel per lane; 16 x 16 lists only)
+int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
+                      const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P, unsigned cap,
+                      float* out_color, unsigned char* out_rgb8) {
+    const int tiles = gx * gy;
+    const dim3 grid((tiles + 3) / 4, nv), block(256);
+#define GS2M_MFMA_CASE(V, MODE)                                                                                                  \
+    if (variant == V) {                                                                                                          \
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_mfma<4, 2, MODE>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8); \
+        else GS2M_LAUNCH((k_blend_mfma<4, 1, MODE>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);               \
+        return 0;                                                                                                                \
     }
-    if (variant == 5) {  // 16 x 32 lists, one wave per 16 x 32 tile (8 pixels per lane)
-        const int tiles = gx * ((gy + 1) / 2);
-        GS2M_LAUNCH((k_blend_wave4e<4, 2, 2>), dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P,
-                    cap, out_color, out_rgb8);
-        return;
+    GS2M_MFMA_CASE(7, 0)
+
+    if (variant == 4 || variant == 5 || variant == 6) {   // 5 / 6: occupancy experiments (8 / 6 waves per SIMD)
+#define GS2M_W4_CASE(V, OCC)                                                                                                     \
+        if (variant == V) {                                                                                                      \
+            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, OCC>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8); \
+            else GS2M_LAUNCH((k_blend_wave4e<4, 1, OCC>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);               \
+        }
+        GS2M_W4_CASE(4, 7)
+        GS2M_W4_CASE(5, 8)
+        GS2M_W4_CASE(6, 6)
+        return 0;
     }
-    if (variant == 4) {
-        const int tiles = gx * gy;
-        GS2M_LAUNCH((k_blend_wave4e<4, 1, 1>), dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
-                    out_color, out_rgb8);
-        return;
+    if (variant == 0 && tile_rows == 1) {
+        GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        return 0;
     }
-    if (variant == 3) {
-        const int tiles = gx * gy;
-        GS2M_LAUNCH(k_blend_wave4q, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
-                    out_color, out_rgb8);
-        return;
-    }
-    if (variant == 2) {
-        const int tiles = gx * gy;
-        GS2M_LAUNCH(k_blend_wave4p, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
-                    out_color, out_rgb8);
-        return;
-    }
-    if (variant == 1) {
-        const int tiles = gx * gy;
-        GS2M_LAUNCH(k_blend_wave4, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
-                    out_color, out_rgb8);
-        return;
-    }
-    GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap,
-                out_color, out_rgb8);
+    gs2m_set_error("blend variant %d is not available with GS2M_OPT_TILE_ROWS %d (variants: 0 [rows 1 only], 4, 7)", variant, tile_rows);
+    return 1;
 }

@@ -31,9 +31,9 @@ void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, u
                            ViewStatus* status, ViewStatus* sticky, unsigned cap);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap);
-void gs2m_launch_blend(hipStream_t st, int variant, int nv, int gx, int gy, const unsigned long long* keys,
-                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
-                       unsigned cap, float* out_color, unsigned char* out_rgb8);
+int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
+                      const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
+                      unsigned cap, float* out_color, unsigned char* out_rgb8);
 
 // error plumbing (common_api.hip)
 void gs2m_set_error(const char* fmt, ...);

@@ -55,11 +55,11 @@ enum {
                                      (DGR/cuda_rasterizer/auxiliary.h:46-56), 1 = also drop
                                      (Gaussian,tile) instances whose alpha < 1/255 on the
                                      whole tile (image unchanged, num_rendered smaller)   */
-    GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 0 = 16x16 tile per 256-thread workgroup
-                                     (1 px/lane); 1 = one wave per tile, 4 px/lane; 2 = 1 with
-                                     the alpha pre-filter; 3 = 2 with the quadrant layout +
-                                     per-instance quadrant mask; 4 (default) = 3 with the
-                                     exponent in the log2 domain.  Same image (to rounding). */
+    GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 7 = one wave per 16x16 tile, exponents of the
+                                     (pixel, instance) pairs computed on the matrix cores (bf16x3 split,
+                                     fp32 accumulate); 4 = the same wave-per-tile layout, all VALU;
+                                     0 = the reference's structure (16x16 tile per 256-thread workgroup,
+                                     1 px/lane; GS2M_OPT_TILE_ROWS 1 only).  Same image (to rounding). */
     GS2M_OPT_DEBUG_SYNC = 3,      /* 1 = synchronise + check after every launch (the
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4,    /* 1 = bracket every stage launch with hipEvents on the
@@ -67,8 +67,7 @@ enum {
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and
-                                     sort; two waves share a list, each compositing its 16 x 16 half (blend
-                                     variant 5 = one wave, 8 pixels per lane); same image -- the reference's
+                                     sort; two waves share a list, each compositing its 16 x 16 half; same image -- the reference's
                                      16 x 16 tile rect still bounds every contribution.  The binning taps then
                                      describe the 16 x 32 tiles.                                            */
 };

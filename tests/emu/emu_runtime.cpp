@@ -15,7 +15,7 @@ thread_local dim3 blockDim, gridDim;
 namespace emu {
 
 enum State { RUNNABLE = 0, WAIT_BLOCK = 1, WAIT_WAVE = 2, DONE = 3 };
-enum Op { OP_NONE = 0, OP_SYNC = 1, OP_COUNT = 2, OP_BALLOT = 3, OP_SHFL = 4 };
+enum Op { OP_NONE = 0, OP_SYNC = 1, OP_COUNT = 2, OP_BALLOT = 3, OP_SHFL = 4, OP_GATHER = 5 };
 
 struct Fiber {
     ucontext_t ctx;
@@ -26,6 +26,9 @@ struct Fiber {
     unsigned long long bits = 0;
     int src = 0;
     unsigned long long result = 0;
+    const void* g_src = nullptr;  // OP_GATHER
+    void* g_dst = nullptr;
+    size_t g_bytes = 0;
     emu_uint3 tid;
 };
 
@@ -87,6 +90,14 @@ unsigned long long shfl_bits(unsigned long long bits, int src_lane) {
     f.src = src_lane;
     yield_wait(WAIT_WAVE, OP_SHFL);
     return c->fibers[c->cur].result;
+}
+void wave_gather(const void* mine, size_t bytes, void* all) {
+    BlockCtx* c = tl_ctx;
+    Fiber& f = c->fibers[c->cur];
+    f.g_src = mine;
+    f.g_dst = all;
+    f.g_bytes = bytes;
+    yield_wait(WAIT_WAVE, OP_GATHER);
 }
 int lane() { return tl_ctx->cur & 63; }
 void* dyn_lds() { return tl_ctx->lds; }
@@ -152,6 +163,17 @@ static void run_block(BlockCtx* c, dim3 grid, dim3 block, unsigned bx, unsigned 
                         if (c->fibers[i].state == WAIT_WAVE && c->fibers[i].pred) m |= 1ull << (i - lo);
                     for (int i = lo; i < hi; ++i)
                         if (c->fibers[i].state == WAIT_WAVE) c->fibers[i].result = m;
+                } else if (op == OP_GATHER) {
+                    // all live lanes are suspended here: their payloads (on their own stacks) are stable
+                    for (int i = lo; i < hi; ++i) {
+                        Fiber& f = c->fibers[i];
+                        if (f.state != WAIT_WAVE) continue;
+                        for (int s = lo; s < lo + 64; ++s) {
+                            char* dst = (char*)f.g_dst + (size_t)(s - lo) * f.g_bytes;
+                            if (s < hi && c->fibers[s].state == WAIT_WAVE) memcpy(dst, c->fibers[s].g_src, f.g_bytes);
+                            else memset(dst, 0, f.g_bytes);
+                        }
+                    }
                 } else if (op == OP_SHFL) {
                     for (int i = lo; i < hi; ++i) {
                         Fiber& f = c->fibers[i];

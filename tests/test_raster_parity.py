@@ -286,7 +286,7 @@ def test_argument_validation_errors(backend):
         r.forward(*base, colors_precomp=d(np.ones((4, 3), np.float32)))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 4, 7])
 def test_blend_variants_match_the_oracle(backend, variant):
     """Every compositing kernel variant (GS2M_OPT_BLEND_VARIANT) on a ragged image, a crowded
     saturating tile stack and with exact culling on."""
