@@ -59,6 +59,8 @@ struct gs2m_raster {
     unsigned* d_tile_count = nullptr;
     unsigned* d_tile_start = nullptr;
     size_t tile_cap = 0;  // words per array
+    unsigned* d_sort_lists = nullptr;  // per view, per size class: count + tile ids (k_tile_scan -> k_sort_tiles_*)
+    size_t sort_lists_cap = 0;
     unsigned long long* d_keys = nullptr;
     unsigned long long* d_tmp = nullptr;
     size_t keys_cap_total = 0;  // entries in each of d_keys / d_tmp
@@ -116,6 +118,7 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     (void)hipFree(r->d_hist);
     (void)hipFree(r->d_tile_count);
     (void)hipFree(r->d_tile_start);
+    (void)hipFree(r->d_sort_lists);
     (void)hipFree(r->d_keys);
     (void)hipFree(r->d_tmp);
     (void)hipFree(r->d_status);
@@ -137,7 +140,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
     switch (option) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
         case GS2M_OPT_BLEND_VARIANT:
-            if (value != 0 && (value < 4 || value > 9)) {
+            if (value != 0 && value != 4 && value != 7) {
                 gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0, 4 or 7");
                 return 1;
             }
@@ -196,6 +199,7 @@ extern "C" int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, in
     size_t tc = r->tile_cap;
     if (ensure(&r->d_tile_count, &tc, (size_t)nv * (tiles + 1))) return 1;
     if (ensure(&r->d_tile_start, &r->tile_cap, (size_t)nv * (tiles + 1))) return 1;
+    if (ensure(&r->d_sort_lists, &r->sort_lists_cap, gs2m_sort_lists_words(nv, tiles))) return 1;
     if (instances > 0xfffffff0ll) {
         gs2m_set_error("instance count %lld exceeds the 32-bit offsets of the binning stage", (long long)instances);
         return 1;
@@ -296,7 +300,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "hist_colscan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
-        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + 1 + status_slot, r->d_status, cap);
+        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
     }
     if (dbg_check(r, st, "tile_scan")) return 1;
     {
@@ -308,7 +312,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "scatter")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SORT);
-        gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap);
+        gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists);
     }
     if (dbg_check(r, st, "sort_tiles")) return 1;
     {

@@ -6,11 +6,17 @@ void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, 
     GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(256), 0, st, hist, n_wg, tiles, tile_count);
 }
 void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles,
-                           ViewStatus* status, ViewStatus* sticky, unsigned cap) {
-    GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, status, sticky, cap);
+                           ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {
+    GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, status, sticky, cap, sort_lists);
 }
+size_t gs2m_sort_lists_words(int nv, int tiles) { return (size_t)nv * GS2M_SORT_CLASSES * (tiles + 1); }
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
-                            const unsigned* tile_start, int tiles, unsigned cap) {
+                            const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists) {
+    // <= 512 instances: one wave per tile; larger lists are walked from the work lists k_tile_scan wrote, by grids
+    // sized for residency (4 / 2 / 2 workgroups per CU by their LDS), not one mostly idle workgroup per tile
     GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap);
-    GS2M_LAUNCH(k_sort_tiles, dim3(tiles, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap);
+    const int g0 = tiles < 1024 ? tiles : 1024, g1 = tiles < 512 ? tiles : 512;
+    GS2M_LAUNCH((k_sort_tiles_bucket<4096, 256, 0>), dim3(g0, nv), dim3(256), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH((k_sort_tiles_bucket<8192, 512, 1>), dim3(g1, nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH(k_sort_tiles, dim3(g1, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
 }

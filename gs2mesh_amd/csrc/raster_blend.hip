@@ -12,23 +12,15 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
                       float* out_color, unsigned char* out_rgb8) {
     const int tiles = gx * gy;
     const dim3 grid((tiles + 3) / 4, nv), block(256);
-#define GS2M_MFMA_CASE(V, MODE)                                                                                                  \
-    if (variant == V) {                                                                                                          \
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_mfma<4, 2, MODE>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8); \
-        else GS2M_LAUNCH((k_blend_mfma<4, 1, MODE>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);               \
-        return 0;                                                                                                                \
+    if (variant == 7) {
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_mfma<4, 2, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        else GS2M_LAUNCH((k_blend_mfma<4, 1, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        return 0;
     }
-    GS2M_MFMA_CASE(7, 0)
 
-    if (variant == 4 || variant == 5 || variant == 6) {   // 5 / 6: occupancy experiments (8 / 6 waves per SIMD)
-#define GS2M_W4_CASE(V, OCC)                                                                                                     \
-        if (variant == V) {                                                                                                      \
-            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, OCC>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8); \
-            else GS2M_LAUNCH((k_blend_wave4e<4, 1, OCC>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);               \
-        }
-        GS2M_W4_CASE(4, 7)
-        GS2M_W4_CASE(5, 8)
-        GS2M_W4_CASE(6, 6)
+    if (variant == 4) {
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
         return 0;
     }
     if (variant == 0 && tile_rows == 1) {

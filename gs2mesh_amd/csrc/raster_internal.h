@@ -28,9 +28,10 @@ void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamU
 
 void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count);
 void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles,
-                           ViewStatus* status, ViewStatus* sticky, unsigned cap);
+                           ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists);
+size_t gs2m_sort_lists_words(int nv, int tiles);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
-                            const unsigned* tile_start, int tiles, unsigned cap);
+                            const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists);
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
                       unsigned cap, float* out_color, unsigned char* out_rgb8);

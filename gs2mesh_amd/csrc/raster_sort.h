@@ -8,6 +8,10 @@
 #pragma once
 #include "raster_common.h"
 
+#define GS2M_SORT_WAVE 512           // lists up to here: one wave, register bitonic (k_sort_tiles_small)
+#define GS2M_SORT_CLASSES 3          // work lists of the larger ones: (512, 4096], (4096, 8192], > 8192 instances
+#define GS2M_SORT_BUCKET_CAP 8192
+
 // hist[v][wg][t]: per-workgroup counts -> exclusive prefix over workgroups (in place);
 // tile_count[v][t] = column total.  A 256-thread workgroup owns 64 consecutive tiles (lane) x 4
 // segments of the workgroup axis (wave): pass 1 sums each segment with back-to-back independent
@@ -64,8 +68,9 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
 // tile_start[v][0..tiles]; status[v] = {N, N > cap}; sticky = {max N, any N > cap} since the last status query.
 GS2M_KERNEL void __launch_bounds__(1024)
 k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles,
-            ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap) {
+            ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap, unsigned* __restrict__ sort_lists) {
     __shared__ unsigned part[1024];
+    __shared__ unsigned n_class[GS2M_SORT_CLASSES];
     const int tid = (int)threadIdx.x;
     const int v = (int)blockIdx.x;
     const unsigned* cnt = tile_count + (size_t)v * tiles;
@@ -73,8 +78,20 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     const int per = (tiles + 1023) / 1024;
     const int lo = tid * per;
     const int hi = lo + per < tiles ? lo + per : tiles;
+    // work lists of the per-tile sort: tiles with more than GS2M_SORT_WAVE instances, by size class (k_sort_tiles_*
+    // walk them with a small grid instead of launching a workgroup per tile that mostly has nothing to do)
+    unsigned* lists = sort_lists + (size_t)v * GS2M_SORT_CLASSES * (tiles + 1);
+    if (tid < GS2M_SORT_CLASSES) n_class[tid] = 0u;
+    __syncthreads();
     unsigned s = 0;
-    for (int i = lo; i < hi; ++i) s += cnt[i];
+    for (int i = lo; i < hi; ++i) {
+        const unsigned c = cnt[i];
+        s += c;
+        if (c > GS2M_SORT_WAVE) {
+            const int cls = c <= 4096u ? 0 : (c <= GS2M_SORT_BUCKET_CAP ? 1 : 2);
+            lists[cls * (tiles + 1) + 1 + atomicAdd(&n_class[cls], 1u)] = (unsigned)i;
+        }
+    }
     part[tid] = s;
     __syncthreads();
     // Hillis-Steele inclusive scan over 1024 partials
@@ -89,6 +106,7 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
         start[i] = run;
         run += cnt[i];
     }
+    if (tid < GS2M_SORT_CLASSES) lists[tid * (tiles + 1)] = n_class[tid];   // complete: every thread passed the scan's barriers
     if (tid == 1023) {
         const unsigned total = part[1023];
         start[tiles] = total;
@@ -202,7 +220,6 @@ GS2M_DEVICE void bitonic_block_regs(unsigned long long (&v)[E], unsigned long lo
 
 // Small tiles (2 <= n <= GS2M_SORT_WAVE): ONE WAVE per (tile, view), 64-thread workgroups, no LDS and no
 // barrier: E = 1, 2, 4, 8 keys per lane for n <= 64, 128, 256, 512.
-#define GS2M_SORT_WAVE 512
 template <int E>
 GS2M_DEVICE void sort_wave_regs(unsigned long long* __restrict__ kv, int n, int lane) {
     unsigned long long v[E];
@@ -253,66 +270,249 @@ GS2M_DEVICE void sort_block_regs(unsigned long long* __restrict__ kv, int n, uns
     }
 }
 
-// One workgroup per (tile, view).  n <= GS2M_SORT_LDS: register-blocked bitonic (3 stages through LDS).  Larger tiles: LDS-sorted
-// runs of GS2M_SORT_LDS, then rank-based merge passes through HBM (keys <-> tmp) by the same
-// workgroup (keys are unique, so rank = index in own run + lower_bound in the sibling run).
+// ---- bucket + rank sort of one tile list (GS2M_SORT_WAVE < n <= GS2M_SORT_LDS keys) ---------------------------------
+// The keys of a tile are depth_bits << 32 | id with depths spread over the tile's frustum, so a monotone map of the
+// depth onto ~n equal-width buckets leaves 0-3 keys in almost every bucket: one LDS counting pass places every key in
+// its bucket, and the exact position inside the bucket is the number of smaller keys there (keys are unique, so the
+// ranks are a permutation and the result is the same total order as any comparison sort: ascending depth, ties by id).
+// O(n) LDS traffic instead of the O(n log^2 n) compare-exchanges of the bitonic network; replaces
+// cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:303-308) for the mid-size lists that dominate a 2 M-Gaussian
+// scene (C3: 7.5 M keys in 4 240 lists, 275 us -> see profiles/r2*).  A list whose depths are so clustered that a
+// bucket holds more than GS2M_BUCKET_MAX keys falls back to the bitonic network (same result).
+// CAP = keys per list this instantiation takes (> CAP / 2 is left to it, <= CAP / 2 to the smaller one), THREADS = CAP / 16:
+// <4096, 256> (40 KiB of LDS: 4 workgroups per CU) for the bulk, <8192, 512> (80 KiB: 2 per CU) for the densest tiles.
+#define GS2M_BUCKET_MAX 48
+template <int CAP, int THREADS>
+GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int n, unsigned long long* s_key, unsigned* s_cnt,
+                                  unsigned* s_red, const int tid) {
+    constexpr int NW = THREADS / 64, E = CAP / THREADS;
+    static_assert(E == 16, "16 keys per thread");
+    const int lane = tid & 63, wave = tid >> 6;
+    // ---- the keys (16 per thread, registers) and the depth range of the list
+    unsigned long long k[E];
+    unsigned dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = r * THREADS + tid;
+        k[r] = i < n ? kv[i] : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if (r * THREADS + tid < n) {
+            const unsigned d = (unsigned)(k[r] >> 32);
+            dmin = d < dmin ? d : dmin;
+            dmax = d > dmax ? d : dmax;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const unsigned a = gs2m_shfl_xor(dmin, m), c = gs2m_shfl_xor(dmax, m);
+        dmin = a < dmin ? a : dmin;
+        dmax = c > dmax ? c : dmax;
+    }
+    if (lane == 0) {
+        s_red[wave] = dmin;
+        s_red[NW + wave] = dmax;
+    }
+    int nb = THREADS * 4;                              // buckets: power of two >= n (>= 4 per thread for the scan)
+    while (nb < n) nb <<= 1;
+    for (int i = tid; i < nb / 2 + 1; i += THREADS) s_cnt[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        dmin = s_red[w] < dmin ? s_red[w] : dmin;
+        dmax = s_red[NW + w] > dmax ? s_red[NW + w] : dmax;
+    }
+    // monotone map depth -> bucket: float conversion, multiplication by a positive constant and truncation are all
+    // non-decreasing, so a key with a larger depth never lands in a smaller bucket (equal depths share a bucket)
+    const float scale = (float)nb / ((float)(dmax - dmin) + 1.0f) * 0.99999f;
+    auto bucket_of = [&](unsigned long long key) -> unsigned {
+        const unsigned b = (unsigned)((float)((unsigned)(key >> 32) - dmin) * scale);
+        return b < (unsigned)nb ? b : (unsigned)nb - 1u;
+    };
+    // ---- count (the returned old value is the key's arrival slot in its bucket), exclusive scan, place
+    unsigned short slot[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = r * THREADS + tid;
+        slot[r] = 0;
+        if (i < n) {
+            const unsigned b = bucket_of(k[r]);
+            const unsigned old = atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) << 4));
+            slot[r] = (unsigned short)((old >> ((b & 1u) << 4)) & 0xffffu);
+        }
+    }
+    __syncthreads();
+    // thread t owns buckets [t * per, (t + 1) * per): per >= 4, whole words
+    const int per = nb / THREADS;
+    unsigned sum = 0u, mx = 0u;
+    for (int w = 0; w < per / 2; ++w) {
+        const unsigned c = s_cnt[tid * (per / 2) + w];
+        const unsigned c0 = c & 0xffffu, c1 = c >> 16;
+        sum += c0 + c1;
+        mx = c0 > mx ? c0 : mx;
+        mx = c1 > mx ? c1 : mx;
+    }
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = gs2m_shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const unsigned o = gs2m_shfl_xor(mx, m);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 63) s_red[2 * NW + wave] = incl;
+    if (lane == 0) s_red[3 * NW + wave] = mx;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_red[2 * NW + w];
+    unsigned wg_max = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) wg_max = s_red[3 * NW + w] > wg_max ? s_red[3 * NW + w] : wg_max;
+    if (wg_max > GS2M_BUCKET_MAX) {
+        // clustered depths: LDS bitonic network over the whole list (same result; O(n log^2 n))
+        __syncthreads();
+        int m = 1024;
+        while (m < n) m <<= 1;
+        for (int i = tid; i < m; i += THREADS) s_key[i] = i < n ? kv[i] : ~0ull;
+        __syncthreads();
+        for (int kk = 2; kk <= m; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int i = tid; i < m / 2; i += THREADS) {
+                    const int lo_i = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), hi_i = lo_i | jj;   // pair (lo_i, lo_i + jj)
+                    const bool up = (lo_i & kk) == 0;
+                    const unsigned long long x = s_key[lo_i], y = s_key[hi_i];
+                    if ((y < x) == up) {
+                        s_key[lo_i] = y;
+                        s_key[hi_i] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < n; i += THREADS) kv[i] = s_key[i];
+        return;
+    }
+    for (int w = 0; w < per / 2; ++w) {
+        const unsigned c = s_cnt[tid * (per / 2) + w];
+        const unsigned c0 = c & 0xffffu, c1 = c >> 16;
+        s_cnt[tid * (per / 2) + w] = run | ((run + c0) << 16);   // starts (<= 4096 each)
+        run += c0 + c1;
+    }
+    if (tid == THREADS - 1) s_cnt[nb / 2] = (unsigned)n;                 // sentinel: start of bucket nb
+    __syncthreads();
+    auto start_of = [&](unsigned b) -> unsigned { return (s_cnt[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; };
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = r * THREADS + tid;
+        if (i < n) s_key[start_of(bucket_of(k[r])) + slot[r]] = k[r];
+    }
+    __syncthreads();
+    // ---- rank inside the bucket -> final position; slot j of the bucket-ordered array goes to lo + rank
+    for (int j = tid; j < n; j += THREADS) {
+        const unsigned long long key = s_key[j];
+        const unsigned b = bucket_of(key);
+        const unsigned lo = start_of(b), hi = start_of(b + 1u);
+        unsigned rank = 0u;
+        for (unsigned q = lo; q < hi; ++q) rank += s_key[q] < key ? 1u : 0u;
+        kv[lo + rank] = key;
+    }
+}
+
+// list = sort_lists[v][cls]: word 0 = number of tiles of the class, then their ids (k_tile_scan); a small grid walks it
+template <int CAP, int THREADS, int CLS>
+GS2M_KERNEL void __launch_bounds__(THREADS)
+k_sort_tiles_bucket(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles, unsigned cap,
+                    const unsigned* __restrict__ sort_lists) {
+    __shared__ unsigned long long s_key[CAP];   // keys grouped by bucket
+    __shared__ unsigned s_cnt[CAP / 2 + 2];     // two 16-bit counters / start offsets per word: <= CAP buckets
+    __shared__ unsigned s_red[4 * (THREADS / 64)];
+    const int tid = (int)threadIdx.x, v = (int)blockIdx.y;
+    const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + CLS) * (tiles + 1);
+    const unsigned count = list[0];
+    for (unsigned li = blockIdx.x; li < count; li += gridDim.x) {
+        const int t = (int)list[1 + li];
+        unsigned b0 = tile_start[(size_t)v * (tiles + 1) + t];
+        unsigned e0 = tile_start[(size_t)v * (tiles + 1) + t + 1];
+        if (b0 > cap) b0 = cap;
+        if (e0 > cap) e0 = cap;
+        const int n = (int)(e0 - b0);
+        if (n > 1) {
+            if (n <= CAP) sort_list_bucket<CAP, THREADS>(keys + (size_t)v * cap + b0, n, s_key, s_cnt, s_red, tid);
+        }
+        __syncthreads();   // the LDS arrays are reused by the next list
+    }
+}
+
+// Lists of more than GS2M_SORT_BUCKET_CAP instances (rare: a tile stack of a very dense scene): LDS-sorted runs of
+// GS2M_SORT_LDS keys (register-blocked bitonic, 3 stages through LDS), then rank-based merge passes through HBM
+// (keys <-> tmp) by the same workgroup (keys are unique, so rank = index in own run + lower_bound in the sibling run).
+// The merge passes read keys other threads of the workgroup wrote to global memory: same CU, same L1 -> visible after
+// the workgroup barrier.
 GS2M_KERNEL void __launch_bounds__(256)
 k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
-             const unsigned* __restrict__ tile_start, int tiles, unsigned cap) {
+             const unsigned* __restrict__ tile_start, int tiles, unsigned cap, const unsigned* __restrict__ sort_lists) {
     __shared__ unsigned long long s[GS2M_SORT_LDS];
     const int tid = (int)threadIdx.x;
-    const int t = (int)blockIdx.x, v = (int)blockIdx.y;
-    unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
-    unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
-    if (b > cap) b = cap;
-    if (e > cap) e = cap;
-    const int n = (int)(e - b);
-    if (n <= GS2M_SORT_WAVE) return;  // uniform across the workgroup; small tiles: k_sort_tiles_small
-    unsigned long long* kv = keys + (size_t)v * cap + b;
-    unsigned long long* tv = tmp + (size_t)v * cap + b;
-    const int nruns = (n + GS2M_SORT_LDS - 1) / GS2M_SORT_LDS;
-    for (int run = 0; run < nruns; ++run) {
-        const int r0 = run * GS2M_SORT_LDS;
-        const int rn = n - r0 < GS2M_SORT_LDS ? n - r0 : GS2M_SORT_LDS;
-        if (rn <= 1024) sort_block_regs<4>(kv + r0, rn, s, tid);
-        else if (rn <= 2048) sort_block_regs<8>(kv + r0, rn, s, tid);
-        else sort_block_regs<16>(kv + r0, rn, s, tid);
-        __syncthreads();
-    }
-    if (nruns == 1) return;
-    unsigned long long* src = kv;
-    unsigned long long* dst = tv;
-    for (int w = GS2M_SORT_LDS; w < n; w <<= 1) {
-        for (int i = tid; i < n; i += 256) {
-            const int blk = i / (2 * w);
-            const int a0 = blk * 2 * w;
-            const int a1 = a0 + w < n ? a0 + w : n;            // A = [a0,a1)
-            const int b1 = a0 + 2 * w < n ? a0 + 2 * w : n;    // B = [a1,b1)
-            const unsigned long long key = src[i];
-            int lo, hi, base;
-            if (i < a1) {  // element of A: count of B elements smaller than key
-                lo = a1;
-                hi = b1;
-                base = i - a0;
-            } else {
-                lo = a0;
-                hi = a1;
-                base = i - a1;
+    const int v = (int)blockIdx.y;
+    const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + 2) * (tiles + 1);   // lists of > 8192 instances
+    const unsigned count = list[0];
+    for (unsigned li = blockIdx.x; li < count; li += gridDim.x) {
+        const int t = (int)list[1 + li];
+        unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
+        unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
+        if (b > cap) b = cap;
+        if (e > cap) e = cap;
+        const int n = (int)(e - b);
+        unsigned long long* kv = keys + (size_t)v * cap + b;
+        unsigned long long* tv = tmp + (size_t)v * cap + b;
+        const int nruns = (n + GS2M_SORT_LDS - 1) / GS2M_SORT_LDS;
+        for (int run = 0; run < nruns; ++run) {
+            const int r0 = run * GS2M_SORT_LDS;
+            const int rn = n - r0 < GS2M_SORT_LDS ? n - r0 : GS2M_SORT_LDS;
+            if (rn <= 1024) sort_block_regs<4>(kv + r0, rn, s, tid);
+            else if (rn <= 2048) sort_block_regs<8>(kv + r0, rn, s, tid);
+            else sort_block_regs<16>(kv + r0, rn, s, tid);
+            __syncthreads();
+        }
+        unsigned long long* src = kv;
+        unsigned long long* dst = tv;
+        for (int w = GS2M_SORT_LDS; w < n; w <<= 1) {
+            for (int i = tid; i < n; i += 256) {
+                const int blk = i / (2 * w);
+                const int a0 = blk * 2 * w;
+                const int a1 = a0 + w < n ? a0 + w : n;            // A = [a0,a1)
+                const int b1 = a0 + 2 * w < n ? a0 + 2 * w : n;    // B = [a1,b1)
+                const unsigned long long key = src[i];
+                int lo, hi, base;
+                if (i < a1) {  // element of A: count of B elements smaller than key
+                    lo = a1;
+                    hi = b1;
+                    base = i - a0;
+                } else {
+                    lo = a0;
+                    hi = a1;
+                    base = i - a1;
+                }
+                const int lo0 = lo;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (src[mid] < key) lo = mid + 1;
+                    else hi = mid;
+                }
+                dst[a0 + base + (lo - lo0)] = key;
             }
-            const int lo0 = lo;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (src[mid] < key) lo = mid + 1;
-                else hi = mid;
-            }
-            dst[a0 + base + (lo - lo0)] = key;
+            __syncthreads();
+            unsigned long long* x = src;
+            src = dst;
+            dst = x;
+        }
+        if (src != kv) {
+            for (int i = tid; i < n; i += 256) kv[i] = src[i];
         }
         __syncthreads();
-        unsigned long long* x = src;
-        src = dst;
-        dst = x;
-    }
-    if (src != kv) {
-        for (int i = tid; i < n; i += 256) kv[i] = src[i];
     }
 }

@@ -192,11 +192,11 @@ def test_empty_and_fully_culled_scenes(backend):
         np.testing.assert_array_equal(img[c], np.float32(bg[c]))
 
 
-def test_crowded_tile_uses_the_merge_path_and_saturates(backend):
-    """> GS2M_SORT_LDS (4096) instances in single tiles: LDS-sorted runs + rank merges; pixels
+@pytest.mark.parametrize("P", [9000, 30000])
+def test_crowded_tile_uses_the_merge_path_and_saturates(backend, P):
+    """> 4096 instances in single tiles (9000: the 8192-key bucket sort; 30000: LDS-sorted runs + rank merges); pixels
     saturate (T < 1e-4) long before the list ends."""
     W, H, f = 48, 32, 60.0
-    P = 9000
     rng = np.random.default_rng(3)
     xyz = rng.normal(0, 0.02, (P, 3)).astype(np.float32)
     xyz[:, 2] = rng.uniform(-1, 1, P)
@@ -211,8 +211,44 @@ def test_crowded_tile_uses_the_merge_path_and_saturates(backend):
     geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
                                  cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
     ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
-    assert (ref_ranges[:, 1] - ref_ranges[:, 0]).max() > 4096
+    assert (ref_ranges[:, 1] - ref_ranges[:, 0]).max() > (4096 if P == 9000 else 8192)
     pl, ranges = r.download_binning(0, ref_n, 3 * 2)
+    np.testing.assert_array_equal(ranges, ref_ranges)
+    np.testing.assert_array_equal(pl, ref_pl)
+    assert_image_close(img, ref_img)
+
+
+@pytest.mark.parametrize("depths", ["uniform", "clustered", "equal"])
+def test_mid_size_lists_use_the_bucket_sort(backend, depths):
+    """512 < n <= 4096 instances per tile: bucket + rank sort (k_sort_tiles_bucket).  `uniform`: depths spread over the
+    frustum (0-2 keys per bucket); `clustered`: almost all depths inside a sliver of the range (a bucket overflows
+    GS2M_BUCKET_MAX -> the bitonic fallback); `equal`: many exactly equal depths (ties resolved by Gaussian id, like the
+    reference's stable radix sort).  The instance lists must equal the oracle's exactly."""
+    W, H, f = 64, 48, 70.0
+    P = 7000
+    rng = np.random.default_rng(17)
+    xyz = rng.normal(0, 0.35, (P, 3)).astype(np.float32)
+    if depths == "uniform":
+        xyz[:, 2] = rng.uniform(-1, 1, P)
+    elif depths == "clustered":
+        xyz[:, 2] = np.where(rng.uniform(size=P) < 0.97, rng.normal(0.3, 1e-4, P), rng.uniform(-1, 1, P))
+    else:
+        xyz[:, 2] = np.round(rng.uniform(-1, 1, P) * 8) / 8       # 17 distinct depths: long runs of exact ties
+    xyz = xyz.astype(np.float32)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    o = rng.uniform(0.02, 0.3, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    s = np.full((P, 3), 0.03, np.float32)
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    r, img, radii = run_forward(backend, cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    assert r.last_num_rendered == ref_n
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
+                                 cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+    sizes = (ref_ranges[:, 1] - ref_ranges[:, 0]).astype(np.int64)
+    assert ((sizes > 512) & (sizes <= 4096)).sum() >= 4, sizes
+    pl, ranges = r.download_binning(0, ref_n, 4 * 3)
     np.testing.assert_array_equal(ranges, ref_ranges)
     np.testing.assert_array_equal(pl, ref_pl)
     assert_image_close(img, ref_img)
