@@ -68,8 +68,8 @@ _PROTOS = {
     "gs2m_tsdf_status": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
     "gs2m_tsdf_download": (i32, [vp, vp, i64, vp, vp, vp, vp]),
     "gs2m_tsdf_block_keys": (i32, [vp, i64, vp, vp]),
-    "gs2m_tsdf_pack": (i32, [vp, vp, i64, vp, vp, vp, vp]),
-    "gs2m_tsdf_unpack": (i32, [vp, vp, i64, vp, vp, vp, vp]),
+    "gs2m_tsdf_pack_sum": (i32, [vp, vp, i64, vp, vp]),
+    "gs2m_tsdf_unpack_sum": (i32, [vp, vp, i64, vp, i32, vp]),
 }
 
 SYMBOLS = tuple(_PROTOS)

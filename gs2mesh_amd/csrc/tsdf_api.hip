@@ -78,11 +78,17 @@ static bool invert4x4(const double* m, double* inv) {
     return true;
 }
 
-static int zero_state(gs2m_tsdf* t, hipStream_t st) {
+// `whole_pool`: at creation (hipMalloc'ed memory is not zero); later resets only clear the slots that were handed out
+static int zero_state(gs2m_tsdf* t, hipStream_t st, bool whole_pool) {
     TsdfVolume& V = t->V;
-    HIPCHK(hipMemsetAsync(V.tsdf, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
-    HIPCHK(hipMemsetAsync(V.weight, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
-    if (V.rgb) HIPCHK(hipMemsetAsync(V.rgb, 0, sizeof(unsigned) * 3 * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+    if (whole_pool) {
+        HIPCHK(hipMemsetAsync(V.tsdf, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+        HIPCHK(hipMemsetAsync(V.weight, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+        if (V.rgb) HIPCHK(hipMemsetAsync(V.rgb, 0, sizeof(unsigned) * 3 * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
+        HIPCHK(hipMemsetAsync(V.halo, 0, (size_t)V.max_blocks, st));
+    } else {
+        gs2m_launch_tsdf_clear_used(st, V);   // reads counters[0] on the device: no host sync
+    }
     HIPCHK(hipMemsetAsync(V.hash_keys, 0xff, sizeof(unsigned long long) * (size_t)V.hash_cap, st));
     HIPCHK(hipMemsetAsync(V.hash_vals, 0xff, sizeof(int) * (size_t)V.hash_cap, st));
     HIPCHK(hipMemsetAsync(V.stamp, 0, sizeof(unsigned) * (size_t)V.hash_cap, st));
@@ -128,6 +134,7 @@ extern "C" int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf
               hipMalloc((void**)&V.weight, sizeof(float) * nvox) == hipSuccess &&
               (!V.has_color || hipMalloc((void**)&V.rgb, sizeof(unsigned) * 3 * nvox) == hipSuccess) &&
               hipMalloc((void**)&V.block_keys, sizeof(int) * 3 * (size_t)max_blocks) == hipSuccess &&
+              hipMalloc((void**)&V.halo, (size_t)max_blocks) == hipSuccess &&
               hipMalloc((void**)&V.hash_keys, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
               hipMalloc((void**)&V.hash_vals, sizeof(int) * (size_t)cap) == hipSuccess &&
               hipMalloc((void**)&V.stamp, sizeof(unsigned) * (size_t)cap) == hipSuccess &&
@@ -154,7 +161,7 @@ extern "C" int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf
             return 1;
         }
     }
-    if (zero_state(t, (hipStream_t)0)) {
+    if (zero_state(t, (hipStream_t)0, true)) {
         gs2m_tsdf_destroy(t);
         return 1;
     }
@@ -170,6 +177,7 @@ extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
     (void)hipFree(V.weight);
     (void)hipFree(V.rgb);
     (void)hipFree(V.block_keys);
+    (void)hipFree(V.halo);
     (void)hipFree(V.hash_keys);
     (void)hipFree(V.hash_vals);
     (void)hipFree(V.stamp);
@@ -196,7 +204,7 @@ extern "C" int gs2m_tsdf_reset(gs2m_tsdf* t, gs2m_stream stream) {
         return 1;
     }
     HIPCHK(hipSetDevice(t->device));
-    return zero_state(t, (hipStream_t)stream);
+    return zero_state(t, (hipStream_t)stream, false);
 }
 
 extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color, const uint8_t* mask,
@@ -394,27 +402,26 @@ extern "C" int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, i
     return 0;
 }
 
-extern "C" int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, float* weight,
-                              uint32_t* rgb_sum, gs2m_stream stream) {
-    if (!t || n < 0 || (n > 0 && (!keys || !wsum || !weight))) {
-        gs2m_set_error("gs2m_tsdf_pack: bad argument");
+extern "C" int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream) {
+    if (!t || n < 0 || (n > 0 && (!keys || !buf))) {
+        gs2m_set_error("gs2m_tsdf_pack_sum: bad argument");
         return 1;
     }
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(t->device));
-    gs2m_launch_tsdf_pack((hipStream_t)stream, (unsigned)n, t->V, keys, wsum, weight, rgb_sum);
+    gs2m_launch_tsdf_pack((hipStream_t)stream, (unsigned)n, t->V, keys, buf);
     return 0;
 }
 
-extern "C" int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
-                                const float* weight, const uint32_t* rgb_sum, gs2m_stream stream) {
-    if (!t || n < 0 || (n > 0 && (!keys || !wsum || !weight))) {
-        gs2m_set_error("gs2m_tsdf_unpack: bad argument");
+extern "C" int gs2m_tsdf_unpack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* buf, int halo,
+                                    gs2m_stream stream) {
+    if (!t || n < 0 || (n > 0 && (!keys || !buf))) {
+        gs2m_set_error("gs2m_tsdf_unpack_sum: bad argument");
         return 1;
     }
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(t->device));
-    gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, wsum, weight, rgb_sum);
+    gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, buf, halo);
     return 0;
 }
 

@@ -25,6 +25,7 @@ struct TsdfVolume {  // device pointers + sizes, passed by value
     float* weight;                 // [max_blocks][4096]
     unsigned* rgb;                 // [max_blocks][3][4096]
     int* block_keys;               // [max_blocks][3]
+    unsigned char* halo;           // [max_blocks]  1 = neighbour-only block (multi-GPU owner-side extraction)
     unsigned long long* hash_keys; // [hash_cap]
     int* hash_vals;                // [hash_cap]  slot or -1
     unsigned* stamp;               // [hash_cap]  last frame id that touched the entry

@@ -60,6 +60,10 @@ k_mc_count(TsdfVolume V, const McDevTables* __restrict__ T, unsigned n_blocks, u
     const int tid = (int)threadIdx.x;
     const int slot = (int)blockIdx.x;
     if ((unsigned)slot >= n_blocks) return;
+    if (V.halo[slot]) {   // neighbour-only block: another rank starts the cubes of this block
+        if (tid == 0) blk_tris[slot] = 0u;
+        return;
+    }
     if (tid == 0) total = 0u;
     mc_neighbour_slots(V, slot, nb_slot, tid);
     __syncthreads();
@@ -111,7 +115,7 @@ k_mc_emit(TsdfVolume V, const McDevTables* __restrict__ T, McGeom G, unsigned n_
     __shared__ unsigned scan[256];
     const int tid = (int)threadIdx.x;
     const int slot = (int)blockIdx.x;
-    if ((unsigned)slot >= n_blocks) return;
+    if ((unsigned)slot >= n_blocks || V.halo[slot]) return;
     mc_neighbour_slots(V, slot, nb_slot, tid);
     __syncthreads();
     const int bx = V.block_keys[3 * (size_t)slot], by = V.block_keys[3 * (size_t)slot + 1],

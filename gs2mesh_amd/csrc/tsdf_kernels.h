@@ -342,41 +342,62 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
     if (blockIdx.x == 0 && tid == 0) V.totals[0] += n_touched;
 }
 
-// ---- multi-GPU exchange -----------------------------------------------------------------------
-// pack: one workgroup per canonical key; sum form (wsum = tsdf*weight) so that the host can
-// all-reduce / reduce-scatter with RCCL.
+// Reset without touching the unused part of the pool: blocks are handed out in slot order, so only slots
+// [0, counters[0]) can hold state (a dense 512^3 pool is 2.7 GB; a scan touches a few hundred MB of it).
 GS2M_KERNEL void __launch_bounds__(256)
-k_tsdf_pack(TsdfVolume V, const int* __restrict__ keys, float* __restrict__ wsum, float* __restrict__ weight,
-            unsigned* __restrict__ rgb) {
+k_tsdf_clear_used(TsdfVolume V) {
+    unsigned n = V.counters[0];
+    if (n > V.max_blocks) n = V.max_blocks;
+    const float4 z = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        float4* t4 = reinterpret_cast<float4*>(V.tsdf + (size_t)slot * GS2M_TSDF_VOX);
+        float4* w4 = reinterpret_cast<float4*>(V.weight + (size_t)slot * GS2M_TSDF_VOX);
+        for (int i = (int)threadIdx.x; i < GS2M_TSDF_VOX / 4; i += 256) {
+            t4[i] = z;
+            w4[i] = z;
+        }
+        if (V.has_color) {
+            float4* c4 = reinterpret_cast<float4*>(V.rgb + (size_t)slot * 3 * GS2M_TSDF_VOX);
+            for (int i = (int)threadIdx.x; i < 3 * GS2M_TSDF_VOX / 4; i += 256) c4[i] = z;
+        }
+        if (threadIdx.x == 0) V.halo[slot] = 0;
+    }
+}
+
+// ---- multi-GPU exchange -----------------------------------------------------------------------
+// pack: one workgroup per canonical key; SUM form in ONE fp32 buffer [n][5][4096] -- planes wsum = tsdf * weight,
+// weight, sum r, sum g, sum b -- so that the host reduces everything with a single RCCL collective.  Counts and colour
+// sums are integers < 2^24 (255 x 65 793 views), hence exact in fp32 and independent of the reduction order.
+GS2M_KERNEL void __launch_bounds__(256)
+k_tsdf_pack(TsdfVolume V, const int* __restrict__ keys, float* __restrict__ buf) {
     const int tid = (int)threadIdx.x;
     const size_t b = blockIdx.x;
     const int bx = keys[3 * b], by = keys[3 * b + 1], bz = keys[3 * b + 2];
     const int slot = tsdf_key_in_range(bx, by, bz) ? tsdf_lookup(V, tsdf_pack_key(bx, by, bz)) : -1;
+    float* o = buf + b * 5 * GS2M_TSDF_VOX;
     for (int i = tid; i < GS2M_TSDF_VOX; i += 256) {
-        float w = 0.f, t = 0.f;
-        unsigned c0 = 0, c1 = 0, c2 = 0;
+        float w = 0.f, t = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
         if (slot >= 0) {
             w = V.weight[(size_t)slot * GS2M_TSDF_VOX + i];
             t = V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i] * w;
             if (V.has_color) {
-                c0 = V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i];
-                c1 = V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i];
-                c2 = V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i];
+                c0 = (float)V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i];
+                c1 = (float)V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i];
+                c2 = (float)V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i];
             }
         }
-        wsum[b * GS2M_TSDF_VOX + i] = t;
-        weight[b * GS2M_TSDF_VOX + i] = w;
-        if (rgb) {
-            rgb[b * 3 * GS2M_TSDF_VOX + i] = c0;
-            rgb[b * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i] = c1;
-            rgb[b * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i] = c2;
-        }
+        o[i] = t;
+        o[GS2M_TSDF_VOX + i] = w;
+        o[2 * GS2M_TSDF_VOX + i] = c0;
+        o[3 * GS2M_TSDF_VOX + i] = c1;
+        o[4 * GS2M_TSDF_VOX + i] = c2;
     }
 }
 
+// unpack: replaces the state of the listed blocks (allocating as needed) with tsdf = wsum / weight; `halo` marks them as
+// neighbour-only blocks of another rank's part of the volume (mesh extraction reads them but starts no cube there).
 GS2M_KERNEL void __launch_bounds__(256)
-k_tsdf_unpack(TsdfVolume V, const int* __restrict__ keys, const float* __restrict__ wsum,
-              const float* __restrict__ weight, const unsigned* __restrict__ rgb) {
+k_tsdf_unpack(TsdfVolume V, const int* __restrict__ keys, const float* __restrict__ buf, int halo) {
     __shared__ int s_slot;
     const int tid = (int)threadIdx.x;
     const size_t b = blockIdx.x;
@@ -389,20 +410,21 @@ k_tsdf_unpack(TsdfVolume V, const int* __restrict__ keys, const float* __restric
         } else {
             atomicOr(&V.counters[2], 4u);
         }
+        if (slot >= 0) V.halo[slot] = (unsigned char)(halo ? 1 : 0);
         s_slot = slot;
     }
     __syncthreads();
     const int slot = s_slot;
     if (slot < 0) return;
+    const float* in = buf + b * 5 * GS2M_TSDF_VOX;
     for (int i = tid; i < GS2M_TSDF_VOX; i += 256) {
-        const float w = weight[b * GS2M_TSDF_VOX + i];
+        const float w = in[GS2M_TSDF_VOX + i];
         V.weight[(size_t)slot * GS2M_TSDF_VOX + i] = w;
-        V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i] = w > 0.f ? wsum[b * GS2M_TSDF_VOX + i] / w : 0.f;
-        if (V.has_color && rgb) {
-            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i] = rgb[b * 3 * GS2M_TSDF_VOX + i];
-            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i] = rgb[b * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i];
-            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i] =
-                rgb[b * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i];
+        V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i] = w > 0.f ? in[i] / w : 0.f;
+        if (V.has_color) {
+            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i] = (unsigned)in[2 * GS2M_TSDF_VOX + i];
+            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i] = (unsigned)in[3 * GS2M_TSDF_VOX + i];
+            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i] = (unsigned)in[4 * GS2M_TSDF_VOX + i];
         }
     }
 }

@@ -14,13 +14,14 @@ void gs2m_launch_tsdf_integrate(hipStream_t st, int n_wg, const TsdfVolume& V, c
                                 const float* depth, const unsigned char* color, const unsigned char* mask) {
     GS2M_LAUNCH(k_tsdf_integrate, dim3(n_wg), dim3(256), 0, st, V, f, depth, color, mask);
 }
-void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, float* wsum,
-                           float* weight, unsigned* rgb) {
-    GS2M_LAUNCH(k_tsdf_pack, dim3(n), dim3(256), 0, st, V, keys, wsum, weight, rgb);
+void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V) {
+    GS2M_LAUNCH(k_tsdf_clear_used, dim3(2048), dim3(256), 0, st, V);
 }
-void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* wsum,
-                             const float* weight, const unsigned* rgb) {
-    GS2M_LAUNCH(k_tsdf_unpack, dim3(n), dim3(256), 0, st, V, keys, wsum, weight, rgb);
+void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, float* buf) {
+    GS2M_LAUNCH(k_tsdf_pack, dim3(n), dim3(256), 0, st, V, keys, buf);
+}
+void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* buf, int halo) {
+    GS2M_LAUNCH(k_tsdf_unpack, dim3(n), dim3(256), 0, st, V, keys, buf, halo);
 }
 
 size_t gs2m_mc_tables_bytes() { return sizeof(McDevTables); }

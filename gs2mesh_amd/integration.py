@@ -154,13 +154,14 @@ class ScalableTSDFVolume:
             if len(self._keep) > 64:
                 self.status(stream)
 
-    def status(self, stream=None):
-        """Synchronises -> (n_blocks, block_updates, overflow_flags); raises on overflow."""
+    def status(self, stream=None, raise_on_overflow=True):
+        """Synchronises -> (n_blocks, block_updates, overflow_flags); raises on overflow (unless told not to: the
+        multi-GPU reduction first agrees on the flag across ranks, then raises everywhere together)."""
         nb, bu, ov = C.c_int64(0), C.c_int64(0), C.c_int(0)
         _lib.check(self._lib.gs2m_tsdf_status(self._h, stream or C.c_void_p(0), C.byref(nb), C.byref(bu),
                                               C.byref(ov)), self._lib)
         self._keep.clear()
-        if ov.value:
+        if ov.value and raise_on_overflow:
             what = [n for b, n in ((1, "block pool exhausted (raise max_blocks)"), (2, "hash table full"),
                                    (4, "block index out of the +-2^20 range")) if ov.value & b]
             raise RuntimeError("TSDF volume overflow: " + ", ".join(what))
@@ -223,8 +224,8 @@ class ScalableTSDFVolume:
         return TriangleMesh.from_triangle_soup(verts, cols if has_color else None)
 
     # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
-    def block_keys(self, like=None, stream=None):
-        n = self.status(stream)[0]
+    def block_keys(self, like=None, stream=None, raise_on_overflow=True):
+        n = min(self.status(stream, raise_on_overflow)[0], self.max_blocks)
         if _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available()):
             keys = np.zeros((n, 3), np.int32)
         else:
@@ -232,12 +233,14 @@ class ScalableTSDFVolume:
         _lib.check(self._lib.gs2m_tsdf_block_keys(self._h, n, _ptr(keys), _stream_of(keys, stream)), self._lib)
         return keys
 
-    def pack(self, keys, wsum, weight, rgb_sum, stream=None):
+    def pack_sum(self, keys, buf, stream=None):
+        """``gs2m_tsdf_pack_sum``: accumulators of the blocks ``keys`` [n,3] in sum form -> ``buf`` [n,5,4096] f32."""
         n = int(keys.shape[0])
-        _lib.check(self._lib.gs2m_tsdf_pack(self._h, _ptr(keys), n, _ptr(wsum), _ptr(weight), _ptr(rgb_sum),
-                                            _stream_of(keys, stream)), self._lib)
+        _lib.check(self._lib.gs2m_tsdf_pack_sum(self._h, _ptr(keys), n, _ptr(buf), _stream_of(keys, stream)), self._lib)
 
-    def unpack(self, keys, wsum, weight, rgb_sum, stream=None):
+    def unpack_sum(self, keys, buf, halo=False, stream=None):
+        """``gs2m_tsdf_unpack_sum``: replace the state of the blocks ``keys`` by ``buf`` (tsdf = wsum / weight);
+        ``halo`` = neighbour-only blocks (read by the mesh extraction, never the base of a cube)."""
         n = int(keys.shape[0])
-        _lib.check(self._lib.gs2m_tsdf_unpack(self._h, _ptr(keys), n, _ptr(wsum), _ptr(weight), _ptr(rgb_sum),
-                                              _stream_of(keys, stream)), self._lib)
+        _lib.check(self._lib.gs2m_tsdf_unpack_sum(self._h, _ptr(keys), n, _ptr(buf), int(bool(halo)),
+                                                  _stream_of(keys, stream)), self._lib)

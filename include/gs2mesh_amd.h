@@ -270,16 +270,17 @@ int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, int32_t* key
 int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m_stream stream);
 
 /*
- * Multi-GPU exchange (new; the reference is single-GPU).  pack: for the n canonical block
- * keys (device [n,3]) write this volume's accumulators in SUM form to device buffers
- * wsum[n,4096] = tsdf*weight, weight[n,4096], rgb_sum[n,4096,3] (zeros where the block is
- * not allocated here).  The host all-reduces/reduce-scatters them with RCCL, then unpack
- * replaces the state of those blocks (allocating as needed) with tsdf = wsum/weight.
+ * Multi-GPU exchange (new; the reference is single-GPU).  pack_sum: for the n canonical block keys (device [n,3])
+ * write this volume's accumulators in SUM form to ONE device buffer buf[n,5,4096] of fp32 planes
+ * {wsum = tsdf*weight, weight, sum r, sum g, sum b} (zeros where the block is not allocated here).  Counts and colour
+ * sums are integers < 2^24, exact in fp32: the host reduces the whole buffer with a single RCCL collective
+ * (reduce-scatter or all-reduce), then unpack_sum replaces the state of the listed blocks (allocating as needed)
+ * with tsdf = wsum/weight.  halo != 0 marks the blocks as neighbour-only: gs2m_tsdf_extract reads them for the +1
+ * corners of its cubes but starts no cube in them (the rank that owns them does): owner-side mesh extraction.
  */
-int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* wsum, float* weight,
-                   uint32_t* rgb_sum, gs2m_stream stream);
-int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* wsum,
-                     const float* weight, const uint32_t* rgb_sum, gs2m_stream stream);
+int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream);
+int gs2m_tsdf_unpack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* buf, int halo,
+                         gs2m_stream stream);
 
 /*
  * Replaces volume.extract_triangle_mesh() (tsdf_utils.py:108; Open3D ScalableTSDFVolume::

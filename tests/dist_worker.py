@@ -16,7 +16,7 @@ def main():
     import torch.distributed as dist
     from backends import make
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
-    from gs2mesh_amd.parallel import reduce_volume, shard_range
+    from gs2mesh_amd.parallel import exchange_halo, reduce_volume, shard_range
     from test_tsdf_parity import frames
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -29,10 +29,20 @@ def main():
     intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
     for d, c, E in frs[lo:hi]:
         vol.integrate(RGBDImage(c, d), intr, E)
-    info = reduce_volume(vol, mode=mode)
+    mesh_mode = mode.endswith("+mesh")
+    info = reduce_volume(vol, mode=mode.replace("+mesh", ""))
+    extra = {}
+    if mesh_mode:
+        # owner-side finalisation: halo blocks from the other ranks, then this rank's part of the mesh
+        owned_keys = vol.download()[0]
+        extra["n_halo"] = exchange_halo(vol, info)
+        m = vol.extract_triangle_mesh()
+        extra["tri_xyz"] = m.vertices[m.triangles] if len(m.triangles) else np.zeros((0, 3, 3))
+        extra["owned_keys"] = owned_keys
+        assert info["collectives"] == 2
     keys, tsdf, weight, rgb = vol.download()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, tsdf=tsdf, weight=weight, rgb=rgb,
-             union=info["n_blocks_union"], owned=np.array(info["owned"]))
+             union=info["n_blocks_union"], owned=np.array(info["owned"]), **extra)
     dist.barrier()
     dist.destroy_process_group()
 

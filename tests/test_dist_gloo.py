@@ -32,21 +32,7 @@ def test_shard_range_is_a_balanced_contiguous_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def single_process_reference():
-    from backends import make
-    from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
-    from test_tsdf_parity import frames
-    be = make("emu")
-    frs, K = frames(5, 128, 96, 140.0)
-    W, H, fx, fy, cx, cy = K
-    vol = ScalableTSDFVolume(2.0 / 96, 0.1, max_blocks=2048, lib=be.lib)
-    for d, c, E in frs:
-        vol.integrate(RGBDImage(c, d), PinholeCameraIntrinsic(W, H, fx, fy, cx, cy), E)
-    return vol.download()
-
-
-@pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "reduce_scatter"), (3, "allreduce")])
-def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
+def run_world(tmp_path, world, mode):
     for attempt in range(3):   # the rendezvous port is picked, released and re-bound by rank 0: retry if it was taken
         port = free_port()
         procs = []
@@ -57,9 +43,30 @@ def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
                                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
         if all(p.returncode == 0 for p in procs):
-            break
+            return
         rendezvous = any("address already in use" in o.lower() or "connect" in o.lower() or "timed out" in o.lower() for o in outs)
         assert rendezvous and attempt < 2, "\n".join(o[-3000:] for o in outs)
+
+
+def single_process_reference(with_mesh=False):
+    from backends import make
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+    from test_tsdf_parity import frames
+    be = make("emu")
+    frs, K = frames(5, 128, 96, 140.0)
+    W, H, fx, fy, cx, cy = K
+    vol = ScalableTSDFVolume(2.0 / 96, 0.1, max_blocks=2048, lib=be.lib)
+    for d, c, E in frs:
+        vol.integrate(RGBDImage(c, d), PinholeCameraIntrinsic(W, H, fx, fy, cx, cy), E)
+    if with_mesh:
+        m = vol.extract_triangle_mesh()
+        return vol.download(), m.vertices[m.triangles]
+    return vol.download()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "reduce_scatter"), (3, "allreduce")])
+def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
+    run_world(tmp_path, world, mode)
     kf, tf, wf, cf = single_process_reference()
     ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
     seen = set()
@@ -77,3 +84,28 @@ def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
         np.testing.assert_array_equal(z["rgb"], cf[idx])
         np.testing.assert_allclose(z["tsdf"], tf[idx], atol=1e-5, rtol=0)
     assert seen == set(ref)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_owner_side_mesh_extraction_with_halo_blocks(tmp_path, world):
+    """After the reduce-scatter every rank holds 1/R of the blocks; `exchange_halo` brings in the +1 neighbour blocks
+    of other ranks as neighbour-only blocks, and the ranks' partial meshes together are exactly the single-process
+    mesh: every triangle once, none missing on the ownership boundaries (vertex positions only depend on the weights
+    / tsdf of the 8 corners, and tsdf differs by fp32 reassociation only)."""
+    run_world(tmp_path, world, "reduce_scatter+mesh")
+    (kf, tf, wf, cf), tri_ref = single_process_reference(with_mesh=True)
+    parts, n_halo = [], 0
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        parts.append(z["tri_xyz"])
+        n_halo += int(z["n_halo"])
+        assert len(z["keys"]) == len(z["owned_keys"]) + int(z["n_halo"])     # halo blocks were added to the volume
+    assert n_halo > 0
+    got = np.concatenate(parts, axis=0)
+    assert got.shape == tri_ref.shape and len(got) > 1000
+
+    def canon(t):      # order-independent: sort triangles by their (rounded) centroid + first vertex
+        key = np.round(np.concatenate([t.mean(axis=1), t[:, 0]], axis=1) * 1e5).astype(np.int64)
+        return t[np.lexsort(key.T[::-1])]
+
+    np.testing.assert_allclose(canon(got), canon(tri_ref), atol=2e-6, rtol=0)

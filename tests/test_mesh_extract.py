@@ -38,7 +38,8 @@ def test_injected_plane_field_is_extracted_exactly(backend):
         wsum[b, vidx.reshape(-1)] = f.reshape(-1)
         rgb[b, 0, :] = 255
         rgb[b, 1, vidx.reshape(-1)] = ((k[0] * 16 + x) * 4).reshape(-1)
-    vol.unpack(be.dev(keys), be.dev(wsum), be.dev(w), be.dev(rgb.view(np.int32) if be.name == "gpu" else rgb))
+    buf = np.concatenate([wsum[:, None], w[:, None], rgb.astype(np.float32)], axis=1)     # [n, 5, 4096] sum form
+    vol.unpack_sum(be.dev(keys), be.dev(np.ascontiguousarray(buf)))
     mesh = vol.extract_triangle_mesh()
     assert mesh.triangles.shape[0] == 2 * 31 * 31          # 31 x 31 cubes across 2 x 2 blocks, one quad each
     assert mesh.vertices.shape[0] == 32 * 32

@@ -88,44 +88,39 @@ def test_pipeline_steady_state_without_reading_back():
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
-def test_reduce_volume_over_rccl_single_rank(mode):
-    """The RCCL calls of parallel.reduce_volume (all_gather of keys, all_reduce / reduce_scatter of the f32 and
-    i32 accumulators) on device tensors, world size 1 (one GPU on the box): the volume must come back unchanged
-    up to the tsdf*w/w round trip."""
-    import subprocess, sys, os, textwrap
-    code = textwrap.dedent(f"""
-        import os, numpy as np, torch, torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
-        from gs2mesh_amd import synthetic
-        from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
-        from gs2mesh_amd.parallel import reduce_volume
-        cfg = synthetic.CONFIGS["C1"]; W, H = cfg.width, cfg.height
-        dev = torch.device("cuda:0")
-        vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
-        intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
-        for p in synthetic.ring_poses(3, cfg.ring_radius, 0, 3):
-            d = synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2, H / 2, cfg.sphere_radius, dev)
-            E = np.eye(4); E[:3] = p
-            img = torch.from_numpy(synthetic.color_pattern(W, H)).to(dev)
-            vol.integrate(RGBDImage(img, d, depth_trunc=cfg.baseline * 20), intr, E)
-        k0, t0, w0, c0 = vol.download()
-        o0 = np.lexsort(k0.T[::-1])
-        info = reduce_volume(vol, mode="{mode}", always_collective=True)
-        k1, t1, w1, c1 = vol.download()
-        o1 = np.lexsort(k1.T[::-1])
-        assert np.array_equal(k0[o0], k1[o1]) and np.array_equal(w0[o0], w1[o1]) and np.array_equal(c0[o0], c1[o1])
-        assert np.abs(t0[o0] - t1[o1]).max() <= 2e-6
-        assert info["n_blocks_union"] == len(k0) > 10
-        dist.destroy_process_group()
-        print("RCCL_OK")
-    """)
+def _run_rccl(world, mode, tmp_path):
+    import os
     import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MASTER_PORT=str(port))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, PYTHONPATH=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                   WORLD_SIZE=str(world), LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "dist_worker_gpu.py"), str(tmp_path), mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and "RCCL_OK" in outs[0], "\n".join(o[-3000:] for o in outs)
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
+def test_reduce_volume_over_rccl_single_rank(mode, tmp_path):
+    """The RCCL calls of parallel.reduce_volume (fixed-size all_gather of the keys + flags, ONE all_reduce / reduce_scatter
+    of the packed fp32 accumulators, the all_to_all of the halo exchange) on device tensors, world size 1 (one GPU on the
+    box): the volume must come back unchanged up to the tsdf*w/w round trip, and its mesh with it."""
+    _run_rccl(1, mode, tmp_path)
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
+def test_reduce_volume_over_rccl_two_ranks(mode, tmp_path):
+    """The same on two GPUs when the box has them: views sharded over 2 ranks, RCCL over xGMI, the union of the ranks'
+    volumes / partial meshes equals the single-GPU result (counts and colour sums exact, tsdf within 2e-6)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (one-GPU boxes run the single-rank RCCL test)")
+    _run_rccl(2, mode, tmp_path)

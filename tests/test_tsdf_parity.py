@@ -157,17 +157,14 @@ def test_pack_unpack_round_trip_and_merge(backend):
     n = canon.shape[0]
     bufs = []
     for v in (a, b):
-        ws = be.dev(np.zeros((n, 4096), np.float32))
-        w = be.dev(np.zeros((n, 4096), np.float32))
-        c = be.dev(np.zeros((n, 3, 4096), np.uint32))
-        v.pack(be.dev(canon), ws, w, c)
+        buf = be.dev(np.zeros((n, 5, 4096), np.float32))
+        v.pack_sum(be.dev(canon), buf)
         be.sync()
-        bufs.append((be.host(ws).copy(), be.host(w).copy(), be.host(c).copy().view(np.uint32)))
-    ws = bufs[0][0] + bufs[1][0]
-    w = bufs[0][1] + bufs[1][1]
-    c = bufs[0][2] + bufs[1][2]
+        bufs.append(be.host(buf).copy())
+    total = bufs[0] + bufs[1]                      # what the RCCL sum-reduction computes
+    assert np.array_equal(total[:, 1:], np.rint(total[:, 1:]))   # counts / colour sums: integers, exact in fp32
     merged = ScalableTSDFVolume(voxel, trunc, max_blocks=2048, lib=be.lib)
-    merged.unpack(be.dev(canon), be.dev(ws), be.dev(w), be.dev(c))
+    merged.unpack_sum(be.dev(canon), be.dev(total))
     km, tm, wm, cm = merged.download()
     kf, tf, wf, cf = full.download()
     im = {tuple(k): i for i, k in enumerate(km.tolist())}
