@@ -127,6 +127,8 @@ def main():
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "4")),
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
+    ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "32")),
+                    help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way)")
     ap.add_argument("--min-repeats", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -181,17 +183,35 @@ def main():
     # `inflight` stereo pairs in flight on separate streams (own rasteriser handle + images each), integration
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
-                              exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows)
+                              exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows,
+                              fuse_batch=args.fuse_batch)
     R = pipe.rasterizers[0]
     color, rgb8 = pipe.color[0], pipe.rgb8[0]
 
     def step(i):
         pipe.submit(cams[i], depths[i], Es[i], depth_scale=1.0, depth_trunc=depth_trunc, min_depth=min_depth)
 
+    serial_imgs = ([torch.empty((Ht, Wd, 3), dtype=torch.uint8, device=dev) for _ in range(args.fuse_batch)]
+                   if args.fuse_batch > 1 else [])
+    serial_pending = []
+
+    def serial_flush():
+        if serial_pending:
+            vol.integrate_batch([RGBDImage(serial_imgs[k], depths[i], depth_scale=1.0, depth_trunc=depth_trunc)
+                                 for k, i in enumerate(serial_pending)], intr, [Es[i] for i in serial_pending],
+                                min_depth=min_depth)
+            serial_pending.clear()
+
     def step_serial(i):
         R.render_views(gd, cams[i], out_color=color, out_rgb8=rgb8, sync=False)
-        vol.integrate(RGBDImage(rgb8[0], depths[i], depth_scale=1.0, depth_trunc=depth_trunc), intr, Es[i],
-                      min_depth=min_depth)
+        if args.fuse_batch > 1:
+            serial_imgs[len(serial_pending)].copy_(rgb8[0], non_blocking=True)
+            serial_pending.append(i)
+            if len(serial_pending) == args.fuse_batch:
+                serial_flush()
+        else:
+            vol.integrate(RGBDImage(rgb8[0], depths[i], depth_scale=1.0, depth_trunc=depth_trunc), intr, Es[i],
+                          min_depth=min_depth)
 
     def barrier():
         torch.cuda.synchronize()
@@ -251,6 +271,7 @@ def main():
     t1 = time.perf_counter()
     for i in range(Wm, Wm + K):
         step_serial(i)
+    serial_flush()
     torch.cuda.synchronize()
     dt_instr = time.perf_counter() - t1
     st_r = R.stage_times()
@@ -413,6 +434,7 @@ def main():
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
                         exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, pairs_in_flight=args.inflight,
+                        tsdf_fuse_batch=args.fuse_batch,
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
             timing=dict(repeats=len(dts), timed_region_s=round(sum(dts), 4), statistic="median over repeats of the K-step job",
                         ms_per_step_min=round(1e3 * min(dts) / K, 4), ms_per_step_max=round(1e3 * max(dts) / K, 4)),

@@ -63,6 +63,8 @@ _PROTOS = {
     "gs2m_tsdf_destroy": (i32, [vp]),
     "gs2m_tsdf_reset": (i32, [vp, vp]),
     "gs2m_tsdf_integrate": (i32, [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, C.POINTER(f64), f64, f64, f64, vp]),
+    "gs2m_tsdf_integrate_batch": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, f64, f64, f64, f64,
+                                        C.POINTER(f64), f64, f64, f64, vp]),
     "gs2m_tsdf_set_stage_timing": (i32, [vp, i32]),
     "gs2m_tsdf_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
     "gs2m_tsdf_status": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),

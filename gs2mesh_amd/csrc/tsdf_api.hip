@@ -35,9 +35,16 @@ struct gs2m_tsdf {
     struct EvPair {
         int stage;
         hipEvent_t a, b;
+        int frames;   // frames the timed launch covered (a batch counts as that many launches)
     };
     std::vector<EvPair> ev_live;
     std::vector<hipEvent_t> ev_free;
+    TsdfBatchFrame* d_bframes = nullptr;   // [GS2M_TSDF_MAX_BATCH] frame descriptors of the batch in flight
+    // pinned staging ring for the descriptors (a pageable source would make the "async" copy wait for the stream)
+    static const int kRing = 8;
+    TsdfBatchFrame* h_bframes = nullptr;   // [kRing][GS2M_TSDF_MAX_BATCH]
+    hipEvent_t ring_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned ring_next = 0;
 };
 
 static hipEvent_t tsdf_ev_get(gs2m_tsdf* t) {
@@ -92,6 +99,7 @@ static int zero_state(gs2m_tsdf* t, hipStream_t st, bool whole_pool) {
     HIPCHK(hipMemsetAsync(V.hash_keys, 0xff, sizeof(unsigned long long) * (size_t)V.hash_cap, st));
     HIPCHK(hipMemsetAsync(V.hash_vals, 0xff, sizeof(int) * (size_t)V.hash_cap, st));
     HIPCHK(hipMemsetAsync(V.stamp, 0, sizeof(unsigned) * (size_t)V.hash_cap, st));
+    HIPCHK(hipMemsetAsync(V.fmask, 0, sizeof(unsigned long long) * (size_t)V.hash_cap, st));
     HIPCHK(hipMemsetAsync(V.counters, 0, sizeof(unsigned) * 4, st));
     HIPCHK(hipMemsetAsync(V.totals, 0, sizeof(unsigned long long), st));
     return 0;
@@ -139,6 +147,9 @@ extern "C" int gs2m_tsdf_create(gs2m_tsdf** out, double voxel_length, double sdf
               hipMalloc((void**)&V.hash_vals, sizeof(int) * (size_t)cap) == hipSuccess &&
               hipMalloc((void**)&V.stamp, sizeof(unsigned) * (size_t)cap) == hipSuccess &&
               hipMalloc((void**)&V.touched, sizeof(unsigned) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void**)&V.fmask, sizeof(unsigned long long) * (size_t)cap) == hipSuccess &&
+              hipMalloc((void**)&t->d_bframes, sizeof(TsdfBatchFrame) * GS2M_TSDF_MAX_BATCH) == hipSuccess &&
+              hipHostMalloc((void**)&t->h_bframes, sizeof(TsdfBatchFrame) * GS2M_TSDF_MAX_BATCH * gs2m_tsdf::kRing) == hipSuccess &&
               hipMalloc((void**)&V.counters, sizeof(unsigned) * 4) == hipSuccess &&
               hipMalloc((void**)&V.totals, sizeof(unsigned long long)) == hipSuccess &&
               hipMalloc((void**)&t->d_mc, gs2m_mc_tables_bytes()) == hipSuccess &&
@@ -182,6 +193,11 @@ extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
     (void)hipFree(V.hash_vals);
     (void)hipFree(V.stamp);
     (void)hipFree(V.touched);
+    (void)hipFree(V.fmask);
+    (void)hipFree(t->d_bframes);
+    (void)hipHostFree(t->h_bframes);
+    for (auto e : t->ring_done)
+        if (e) (void)hipEventDestroy(e);
     (void)hipFree(V.counters);
     (void)hipFree(V.totals);
     (void)hipFree(t->d_mc);
@@ -207,26 +223,9 @@ extern "C" int gs2m_tsdf_reset(gs2m_tsdf* t, gs2m_stream stream) {
     return zero_state(t, (hipStream_t)stream, false);
 }
 
-extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color, const uint8_t* mask,
-                                   int width, int height, double fx, double fy, double cx, double cy,
-                                   const double* extrinsic_w2c, double depth_scale, double depth_trunc,
-                                   double min_depth, gs2m_stream stream) {
-    if (!t || !depth || !extrinsic_w2c) {
-        gs2m_set_error("gs2m_tsdf_integrate: NULL argument");
-        return 1;
-    }
-    if (t->V.has_color && !color) {
-        // Open3D: "[ScalableTSDFVolume::Integrate] Unsupported image format."
-        gs2m_set_error("[ScalableTSDFVolume::Integrate] Unsupported image format.");
-        return 1;
-    }
-    if (width <= 0 || height <= 0 || !(fx != 0) || !(fy != 0) || !(depth_scale != 0)) {
-        gs2m_set_error("gs2m_tsdf_integrate: bad intrinsics / size");
-        return 1;
-    }
-    HIPCHK(hipSetDevice(t->device));
-    hipStream_t st = (hipStream_t)stream;
-    TsdfFrame f;
+// per-frame uniforms (intrinsics, pose, truncation constants) of one integrate call
+static int fill_frame(gs2m_tsdf* t, TsdfFrame& f, int width, int height, double fx, double fy, double cx, double cy,
+                      const double* extrinsic_w2c, double depth_scale, double depth_trunc, double min_depth, bool has_mask) {
     memset(&f, 0, sizeof(f));
     double pose[16];
     if (!invert4x4(extrinsic_w2c, pose)) {
@@ -261,14 +260,42 @@ extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8
     f.safe_h = height - 0.0001f;
     f.depth_scale_f = (float)depth_scale;
     f.min_depth_f = (float)min_depth;
+    // Image::ConvertDepthToFloatImage compares the float depth with the double threshold; the same decision in fp32:
+    f.depth_trunc_up_f = (float)depth_trunc;
+    if ((double)f.depth_trunc_up_f < depth_trunc) f.depth_trunc_up_f = nextafterf(f.depth_trunc_up_f, INFINITY);
     f.W = width;
     f.H = height;
     f.stride = t->stride;
     f.nx = (width + t->stride - 1) / t->stride;
     f.ny = (height + t->stride - 1) / t->stride;
     f.frame_id = ++t->frame_id;
-    f.use_mask = mask != nullptr;
+    f.use_mask = has_mask;
     f.use_min = min_depth > 0;
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color, const uint8_t* mask,
+                                   int width, int height, double fx, double fy, double cx, double cy,
+                                   const double* extrinsic_w2c, double depth_scale, double depth_trunc,
+                                   double min_depth, gs2m_stream stream) {
+    if (!t || !depth || !extrinsic_w2c) {
+        gs2m_set_error("gs2m_tsdf_integrate: NULL argument");
+        return 1;
+    }
+    if (t->V.has_color && !color) {
+        // Open3D: "[ScalableTSDFVolume::Integrate] Unsupported image format."
+        gs2m_set_error("[ScalableTSDFVolume::Integrate] Unsupported image format.");
+        return 1;
+    }
+    if (width <= 0 || height <= 0 || !(fx != 0) || !(fy != 0) || !(depth_scale != 0)) {
+        gs2m_set_error("gs2m_tsdf_integrate: bad intrinsics / size");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    TsdfFrame f;
+    if (fill_frame(t, f, width, height, fx, fy, cx, cy, extrinsic_w2c, depth_scale, depth_trunc, min_depth, mask != nullptr))
+        return 1;
     HIPCHK(hipMemsetAsync(t->V.counters + 1, 0, sizeof(unsigned), st));  // touched_count = 0
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     if (t->timing) {
@@ -288,8 +315,74 @@ extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8
     gs2m_launch_tsdf_integrate(st, t->n_cu * 7, t->V, f, depth, color, mask);
     if (tm) {
         (void)hipEventRecord(e3, st);
-        t->ev_live.push_back({0, e0, e1});
-        t->ev_live.push_back({1, e2, e3});
+        t->ev_live.push_back({0, e0, e1, 1});
+        t->ev_live.push_back({1, e2, e3, 1});
+    }
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_integrate_batch(gs2m_tsdf* t, int n_frames, const float* const* depth, const uint8_t* const* color,
+                                         const uint8_t* const* mask, int width, int height, double fx, double fy, double cx,
+                                         double cy, const double* extrinsics_w2c, double depth_scale, double depth_trunc,
+                                         double min_depth, gs2m_stream stream) {
+    if (!t || n_frames < 0 || (n_frames > 0 && (!depth || !extrinsics_w2c))) {
+        gs2m_set_error("gs2m_tsdf_integrate_batch: NULL argument");
+        return 1;
+    }
+    if (t->V.has_color && n_frames > 0 && !color) {
+        gs2m_set_error("[ScalableTSDFVolume::Integrate] Unsupported image format.");
+        return 1;
+    }
+    if (n_frames > 0 && (width <= 0 || height <= 0 || !(fx != 0) || !(fy != 0) || !(depth_scale != 0))) {
+        gs2m_set_error("gs2m_tsdf_integrate_batch: bad intrinsics / size");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (int f0 = 0; f0 < n_frames; f0 += GS2M_TSDF_MAX_BATCH) {
+        const int nf = n_frames - f0 < GS2M_TSDF_MAX_BATCH ? n_frames - f0 : GS2M_TSDF_MAX_BATCH;
+        // next slot of the pinned staging ring; its previous copy (kRing batches ago) has long completed
+        const unsigned slot = t->ring_next++ % gs2m_tsdf::kRing;
+        if (t->ring_done[slot]) HIPCHK(hipEventSynchronize(t->ring_done[slot]));
+        else HIPCHK(hipEventCreateWithFlags(&t->ring_done[slot], hipEventDisableTiming));
+        TsdfBatchFrame* hb = t->h_bframes + (size_t)slot * GS2M_TSDF_MAX_BATCH;
+        for (int k = 0; k < nf; ++k) {
+            const int i = f0 + k;
+            if (!depth[i] || (t->V.has_color && !color[i])) {
+                gs2m_set_error("gs2m_tsdf_integrate_batch: frame %d has a NULL image", i);
+                return 1;
+            }
+            const unsigned char* m = mask ? mask[i] : nullptr;
+            if (fill_frame(t, hb[k].f, width, height, fx, fy, cx, cy, extrinsics_w2c + 16 * (size_t)i, depth_scale, depth_trunc,
+                           min_depth, m != nullptr))
+                return 1;
+            hb[k].depth = depth[i];
+            hb[k].color = color ? color[i] : nullptr;
+            hb[k].mask = m;
+        }
+        HIPCHK(hipMemcpyAsync(t->d_bframes, hb, sizeof(TsdfBatchFrame) * nf, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(t->ring_done[slot], st));
+        HIPCHK(hipMemsetAsync(t->V.counters + 1, 0, sizeof(unsigned), st));  // touched_count = 0
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+        if (t->timing) {
+            e0 = tsdf_ev_get(t);
+            e1 = tsdf_ev_get(t);
+            e2 = tsdf_ev_get(t);
+            e3 = tsdf_ev_get(t);
+        }
+        const bool tm = e0 && e1 && e2 && e3;
+        if (tm) (void)hipEventRecord(e0, st);
+        gs2m_launch_tsdf_touch_batch(st, t->V, hb[0].f, nf, t->d_bframes);
+        if (tm) {
+            (void)hipEventRecord(e1, st);
+            (void)hipEventRecord(e2, st);
+        }
+        gs2m_launch_tsdf_integrate_batch(st, t->n_cu * 2, t->V, t->d_bframes);
+        if (tm) {
+            (void)hipEventRecord(e3, st);
+            t->ev_live.push_back({0, e0, e1, nf});
+            t->ev_live.push_back({1, e2, e3, nf});
+        }
     }
     return 0;
 }
@@ -313,7 +406,7 @@ extern "C" int gs2m_tsdf_stage_times(gs2m_tsdf* t, gs2m_stream stream, double* t
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && (p.stage == 0 || p.stage == 1)) {
             total_ms[p.stage] += ms;
-            launches[p.stage] += 1;
+            launches[p.stage] += p.frames;   // a batch launch counts as its frames: averages stay per frame
         }
         t->ev_free.push_back(p.a);
         t->ev_free.push_back(p.b);

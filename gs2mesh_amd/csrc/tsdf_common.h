@@ -29,7 +29,8 @@ struct TsdfVolume {  // device pointers + sizes, passed by value
     unsigned long long* hash_keys; // [hash_cap]
     int* hash_vals;                // [hash_cap]  slot or -1
     unsigned* stamp;               // [hash_cap]  last frame id that touched the entry
-    unsigned* touched;             // [hash_cap]  hash indices touched this frame
+    unsigned* touched;             // [hash_cap]  hash indices touched this frame / batch
+    unsigned long long* fmask;     // [hash_cap]  batch mode: bit f = frame f of the batch touched the block (0 between batches)
     unsigned* counters;            // [0] n_blocks  [1] touched_count  [2] overflow flags
     unsigned long long* totals;    // [0] block updates (sum over frames of touched blocks)
     unsigned hash_cap;             // power of two
@@ -47,10 +48,21 @@ struct TsdfFrame {  // per-frame uniforms, passed by value in the launch packet
     float Es02, Es12, Es22;  // E[:,2] * voxel_length (incremental z step)
     float safe_w, safe_h;
     float depth_scale_f, min_depth_f;
+    float depth_trunc_up_f;  // smallest float >= depth_trunc:  (double)d >= depth_trunc  <=>  d >= depth_trunc_up_f
     int W, H, stride, nx, ny;
     unsigned frame_id;
     int use_mask, use_min;
 };
+
+// One frame of a batch (gs2m_tsdf_integrate_batch): the per-frame uniforms + its images.  An array of these lives in
+// device memory; the frame index is wave-uniform, so the kernels read it with scalar loads.
+struct TsdfBatchFrame {
+    TsdfFrame f;
+    const float* depth;
+    const unsigned char* color;
+    const unsigned char* mask;
+};
+#define GS2M_TSDF_MAX_BATCH 64   // frames per batch: one bit per frame in the per-block touch mask
 
 // device-internal voxel index (see header); host code uses the same formula in gs2m_tsdf_download
 #define GS2M_TSDF_VINDEX(x, y, z) (((((z) >> 2) * 16 + ((x) >> 2) * 4 + ((y) >> 2)) * 64) + ((z)&3) * 16 + ((x)&3) * 4 + ((y)&3))

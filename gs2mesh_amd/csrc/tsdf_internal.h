@@ -6,6 +6,9 @@ void gs2m_launch_tsdf_touch(hipStream_t st, const TsdfVolume& V, const TsdfFrame
                             const unsigned char* mask);
 void gs2m_launch_tsdf_integrate(hipStream_t st, int n_wg, const TsdfVolume& V, const TsdfFrame& f,
                                 const float* depth, const unsigned char* color, const unsigned char* mask);
+void gs2m_launch_tsdf_touch_batch(hipStream_t st, const TsdfVolume& V, const TsdfFrame& f, int n_frames,
+                                  const TsdfBatchFrame* frames);
+void gs2m_launch_tsdf_integrate_batch(hipStream_t st, int n_wg, const TsdfVolume& V, const TsdfBatchFrame* frames);
 void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V);
 void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, float* buf);
 void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* buf, int halo);

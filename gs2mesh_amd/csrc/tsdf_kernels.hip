@@ -14,6 +14,15 @@ void gs2m_launch_tsdf_integrate(hipStream_t st, int n_wg, const TsdfVolume& V, c
                                 const float* depth, const unsigned char* color, const unsigned char* mask) {
     GS2M_LAUNCH(k_tsdf_integrate, dim3(n_wg), dim3(256), 0, st, V, f, depth, color, mask);
 }
+void gs2m_launch_tsdf_touch_batch(hipStream_t st, const TsdfVolume& V, const TsdfFrame& f, int n_frames,
+                                  const TsdfBatchFrame* frames) {
+    const int n = f.nx * f.ny;
+    GS2M_LAUNCH(k_tsdf_touch_batch, dim3((n + 255) / 256, n_frames), dim3(256), 0, st, V, frames);
+    GS2M_LAUNCH(k_tsdf_compact, dim3((V.hash_cap + 1023u) / 1024u), dim3(1024), 0, st, V, 0u);
+}
+void gs2m_launch_tsdf_integrate_batch(hipStream_t st, int n_wg, const TsdfVolume& V, const TsdfBatchFrame* frames) {
+    GS2M_LAUNCH(k_tsdf_integrate_batch, dim3(n_wg), dim3(1024), 0, st, V, frames);
+}
 void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V) {
     GS2M_LAUNCH(k_tsdf_clear_used, dim3(2048), dim3(256), 0, st, V);
 }

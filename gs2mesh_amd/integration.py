@@ -154,6 +154,43 @@ class ScalableTSDFVolume:
             if len(self._keep) > 64:
                 self.status(stream)
 
+    def integrate_batch(self, images, intrinsic: PinholeCameraIntrinsic, extrinsics, masks=None, min_depth=0.0, stream=None):
+        """``gs2m_tsdf_integrate_batch``: the frames ``images`` (list of RGBDImage sharing depth_scale / depth_trunc) under
+        ``extrinsics`` (list of 4x4 world -> camera) in one voxel-stationary sweep; bit-identical to calling
+        ``integrate`` on them in list order."""
+        n = len(images)
+        if n == 0:
+            return
+        if len(extrinsics) != n or (masks is not None and len(masks) != n):
+            raise ValueError("integrate_batch: images / extrinsics / masks must have the same length")
+        f32 = torch.float32 if torch is not None else None
+        u8 = torch.uint8 if torch is not None else None
+        has_color = self.color_type == TSDFVolumeColorType.RGB8
+        keep, dp, cp, mp = [], (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+        for i, im in enumerate(images):
+            if (im.depth_scale, im.depth_trunc) != (images[0].depth_scale, images[0].depth_trunc):
+                raise ValueError("integrate_batch: the frames of a batch share one depth_scale / depth_trunc")
+            d = self._to_dev(im.depth, f32)
+            c = self._to_dev(im.color, u8) if has_color else None
+            m = self._to_dev(masks[i], u8) if masks is not None and masks[i] is not None else None
+            H, W = int(d.shape[0]), int(d.shape[1])
+            bad = W != intrinsic.width or H != intrinsic.height or d.ndim != 2
+            if has_color:
+                bad = bad or c is None or c.ndim != 3 or tuple(c.shape) != (H, W, 3)
+            if bad:
+                raise RuntimeError("[ScalableTSDFVolume::Integrate] Unsupported image format.")
+            keep += [d, c, m]
+            dp[i], cp[i], mp[i] = _ptr(d), _ptr(c), _ptr(m)
+        E = np.ascontiguousarray(np.stack([np.asarray(e, np.float64).reshape(4, 4) for e in extrinsics]))
+        st = _stream_of(keep[0], stream)
+        _lib.check(self._lib.gs2m_tsdf_integrate_batch(
+            self._h, n, dp, cp if has_color else None, mp if masks is not None else None, intrinsic.width, intrinsic.height,
+            intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)),
+            float(images[0].depth_scale), float(images[0].depth_trunc), float(min_depth), st), self._lib)
+        self._keep.append(keep)      # the frames stay alive until the next synchronising call
+        if len(self._keep) > 64:
+            self.status(stream)
+
     def status(self, stream=None, raise_on_overflow=True):
         """Synchronises -> (n_blocks, block_updates, overflow_flags); raises on overflow (unless told not to: the
         multi-GPU reduction first agrees on the flag across ranks, then raises everywhere together)."""

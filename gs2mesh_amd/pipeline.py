@@ -28,7 +28,7 @@ class RenderFusePipeline:
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None,
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0,
                  exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
-                 lib=None):
+                 lib=None, fuse_batch: int = 1):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
@@ -54,6 +54,17 @@ class RenderFusePipeline:
         else:
             self.render_streams = [torch.cuda.Stream(device=dev) for _ in range(self.inflight)]
             self.fuse_stream = torch.cuda.Stream(device=dev)
+        # fuse_batch > 1: the views are integrated `fuse_batch` at a time by the voxel-stationary batch kernel
+        # (gs2m_tsdf_integrate_batch: same result as view by view, one voxel-state read + write per batch).  The left
+        # image of every pending view is kept in its own buffer (a slot's image is re-rendered before the batch runs).
+        self.fuse_batch = max(1, min(int(fuse_batch), 64))
+        self._pending = []
+        # two sets of image buffers: batch b + 1 is collected while batch b is still being integrated
+        nb = self.fuse_batch if self.fuse_batch > 1 else 0
+        self._bimg = [[torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)] for _ in range(2)]
+        self._bcopied = [[torch.cuda.Event() for _ in range(nb)] for _ in range(2)]
+        self._batch_done = [None, None]
+        self._bset = 0
         self._rendered = [torch.cuda.Event() for _ in range(self.inflight)]
         self._fused = [torch.cuda.Event() for _ in range(self.inflight)]
         self._n = 0
@@ -84,7 +95,13 @@ class RenderFusePipeline:
         r = self.rasterizers[j]
         if self.inflight == 1:
             r.render_views(self.g, cams, bg=self.bg, out_color=self.color[0], out_rgb8=self.rgb8[0], sync=False)
-            if depth is not None:
+            if depth is not None and self.fuse_batch > 1:
+                k = len(self._pending)
+                self._bimg[self._bset][k].copy_(self.rgb8[0][0], non_blocking=True)
+                self._pending.append((k, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
+                if len(self._pending) == self.fuse_batch:
+                    self._flush_batch()
+            elif depth is not None:
                 self.volume.integrate(RGBDImage(self.rgb8[0][0], depth, depth_scale=depth_scale, depth_trunc=depth_trunc),
                                       self.intrinsic, extrinsic, mask=mask, min_depth=min_depth)
             return 0
@@ -98,7 +115,21 @@ class RenderFusePipeline:
             rs.wait_event(self._fused[j])          # the view that last used this slot's images is integrated
             r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j], sync=False)
             self._rendered[j].record(rs)
-        if depth is not None:
+            if depth is not None and self.fuse_batch > 1:
+                k = len(self._pending)
+                if self._batch_done[self._bset] is not None:
+                    rs.wait_event(self._batch_done[self._bset])   # the batch that last read this buffer set (two batches ago)
+                self._bimg[self._bset][k].copy_(self.rgb8[j][0], non_blocking=True)
+                self._bcopied[self._bset][k].record(rs)
+        if depth is not None and self.fuse_batch > 1:
+            for t in (depth, mask):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.fuse_stream)
+            self._pending.append((len(self._pending), depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
+            self._fused[j].record(rs)                      # the slot's image has been copied out: free to re-render
+            if len(self._pending) == self.fuse_batch:
+                self._flush_batch(cur)
+        elif depth is not None:
             fs = self.fuse_stream
             fs.wait_stream(cur)
             for t in (depth, mask):
@@ -111,6 +142,33 @@ class RenderFusePipeline:
                 self._fused[j].record(fs)
         return j
 
+    def _flush_batch(self, cur=None):
+        """Integrate the pending views (in submission order) with one batch sweep."""
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        p0 = pend[0]
+        if any((p[4], p[5], p[6]) != (p0[4], p0[5], p0[6]) for p in pend):
+            raise ValueError("fuse_batch: the views of a batch must share depth_scale / depth_trunc / min_depth")
+        bset = self._bset
+        self._bset ^= 1
+        images = [RGBDImage(self._bimg[bset][k], d, depth_scale=p0[4], depth_trunc=p0[5]) for k, d, *_ in pend]
+        masks = [p[3] for p in pend]
+        args = (images, self.intrinsic, [p[2] for p in pend])
+        kw = dict(masks=masks if any(m is not None for m in masks) else None, min_depth=p0[6])
+        if self.inflight == 1:
+            self.volume.integrate_batch(*args, **kw)
+            return
+        fs = self.fuse_stream
+        if cur is not None:
+            fs.wait_stream(cur)
+        with torch.cuda.stream(fs):
+            for k, *_ in pend:
+                fs.wait_event(self._bcopied[bset][k])
+            self.volume.integrate_batch(*args, **kw)
+            self._batch_done[bset] = torch.cuda.Event()
+            self._batch_done[bset].record(fs)
+
     def wait_rendered(self, slot: int):
         if self.inflight > 1:
             self._rendered[slot].synchronize()
@@ -118,7 +176,9 @@ class RenderFusePipeline:
             torch.cuda.current_stream(self.device).synchronize()
 
     def drain(self):
-        """Host waits for everything submitted so far (render + fuse streams); no status query, no device-wide sync."""
+        """Host waits for everything submitted so far (render + fuse streams; a partial batch is integrated first); no
+        status query, no device-wide sync."""
+        self._flush_batch(torch.cuda.current_stream(self.device) if self.inflight > 1 else None)
         if self.inflight > 1:
             for s in self.render_streams:
                 s.synchronize()
@@ -131,12 +191,7 @@ class RenderFusePipeline:
         `finish` (the handle's overflow word is sticky on the device: a later pair that fits does not erase it).
         The images of an overflowing pair were composited from a truncated instance list, so the views integrated
         from them are invalid: grow the arenas (`prepare(..., headroom=)`) and redo the loop."""
-        if self.inflight > 1:
-            for s in self.render_streams:
-                s.synchronize()
-            self.fuse_stream.synchronize()
-        else:
-            torch.cuda.current_stream(self.device).synchronize()
+        self.drain()
         for j, r in enumerate(self.rasterizers):
             nr, ov, req = r.status(2)
             if ov:

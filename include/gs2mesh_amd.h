@@ -249,10 +249,23 @@ int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8_t* color,
                         double cx, double cy, const double* extrinsic_w2c, double depth_scale,
                         double depth_trunc, double min_depth, gs2m_stream stream);
 
+/*
+ * The same for n_frames frames of one size / intrinsics in ONE sweep over the touched blocks (SURVEY.md 7 step 6 iii):
+ * every block keeps its voxels in registers while the frames that touch it are applied IN FRAME ORDER, so the result is
+ * bit-identical to n_frames gs2m_tsdf_integrate calls in that order, with one state read + write per batch instead of
+ * per frame.  depth / color / mask: HOST arrays of n_frames DEVICE pointers (mask may be NULL, or hold NULLs);
+ * extrinsics_w2c: HOST [n_frames][16].  Batches of up to 64 frames per sweep (longer lists are split).  Asynchronous; the
+ * images must stay valid until the stream reaches the end of the call.
+ */
+int gs2m_tsdf_integrate_batch(gs2m_tsdf* t, int n_frames, const float* const* depth, const uint8_t* const* color,
+                              const uint8_t* const* mask, int width, int height, double fx, double fy, double cx,
+                              double cy, const double* extrinsics_w2c, double depth_scale, double depth_trunc,
+                              double min_depth, gs2m_stream stream);
+
 /* Stage timing as for the rasteriser: enable != 0 brackets k_tsdf_touch (index 0) and
  * k_tsdf_integrate (index 1) with hipEvents; gs2m_tsdf_stage_times synchronises and
  * accumulates into total_ms[2] / launches[2]. */
-int gs2m_tsdf_set_stage_timing(gs2m_tsdf* t, int enable);
+int gs2m_tsdf_set_stage_timing(gs2m_tsdf* t, int enable);   /* a batch counts as n_frames launches of each stage */
 int gs2m_tsdf_stage_times(gs2m_tsdf* t, gs2m_stream stream, double* total_ms, int64_t* launches);
 
 /* Synchronises; n_blocks = allocated blocks, block_updates = sum over frames of blocks

@@ -188,6 +188,7 @@ static inline int atomicMax(int* p, int v) {
 static inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) {
     __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
     return cmp;
@@ -235,6 +236,8 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 template <typename F>
 static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event(); return hipSuccess; }
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event(); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

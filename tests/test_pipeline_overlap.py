@@ -8,7 +8,7 @@ from gs2mesh_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-def _run(inflight, n_views=6):
+def _run(inflight, n_views=6, fuse_batch=1):
     import torch
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
     from gs2mesh_amd.pipeline import RenderFusePipeline
@@ -22,7 +22,7 @@ def _run(inflight, n_views=6):
     poses = synthetic.ring_poses(n_views, cfg.ring_radius, 0, n_views)
     intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
     vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
-    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0, fuse_batch=fuse_batch)
     cams, depths, Es = [], [], []
     for p in poses:
         l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
@@ -47,6 +47,18 @@ def _run(inflight, n_views=6):
 def test_overlapped_pipeline_equals_serial(inflight):
     ref = _run(1)
     got = _run(inflight)
+    for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
+        assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
+    for a, b in zip(ref[1:], got[1:]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("inflight,fuse_batch", [(1, 4), (3, 4), (2, 2)])
+def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
+    """fuse_batch > 1: the views are integrated by the voxel-stationary batch kernel, 4 (then the remaining 2) at a time,
+    from per-view copies of the left image: images and volume are bit-identical to the serial view-by-view order."""
+    ref = _run(1)
+    got = _run(inflight, fuse_batch=fuse_batch)
     for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
         assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
     for a, b in zip(ref[1:], got[1:]):

@@ -173,3 +173,42 @@ def test_pack_unpack_round_trip_and_merge(backend):
     np.testing.assert_array_equal(wm[order], wf)
     np.testing.assert_array_equal(cm[order], cf)
     np.testing.assert_allclose(tm[order], tf, atol=1e-6)
+
+
+@pytest.mark.parametrize("color,use_mask", [(True, False), (True, True), (False, False)])
+def test_batch_integrate_is_bit_identical_to_frame_by_frame(backend, color, use_mask):
+    """gs2m_tsdf_integrate_batch (voxel-stationary: all frames of the batch in one sweep over the touched blocks) vs the
+    per-frame path in the same frame order and vs the oracle: block sets, counts, tsdf and colour sums bit for bit, with
+    min-depth, depth scale / truncation and (optionally) per-frame masks; a second batch continues the same volume."""
+    be = backend
+    frs, K = frames(7, 160, 120, 170.0)
+    W, H, fx, fy, cx, cy = K
+    voxel, trunc = 2.0 / 128, 0.08
+    rng = np.random.default_rng(4)
+    masks = [(rng.uniform(size=(H, W)) > 0.2).astype(np.uint8) if (use_mask and k % 2 == 0) else None for k in range(len(frs))]
+    ct = TSDFVolumeColorType.RGB8 if color else TSDFVolumeColorType.NoColor
+    intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
+    kw = dict(depth_scale=1.25, depth_trunc=3.4)
+    seq = ScalableTSDFVolume(voxel, trunc, ct, max_blocks=2048, lib=be.lib)
+    ref = oracle.ScalableTSDFVolume(voxel, trunc, int(ct))
+    for (d, c, E), m in zip(frs, masks):
+        seq.integrate(RGBDImage(be.dev(c), be.dev(d), **kw), intr, E, mask=None if m is None else be.dev(m), min_depth=2.9)
+        dd = d * (m != 0) if m is not None else d
+        dd = np.where(dd < np.float32(2.9), 0, dd).astype(np.float32)
+        ref.integrate(oracle.ScalableTSDFVolume.convert_depth(dd, 1.25, 3.4), c if color else None, W, H, fx, fy, cx, cy, E)
+    bat = ScalableTSDFVolume(voxel, trunc, ct, max_blocks=2048, lib=be.lib)
+    for lo, hi in ((0, 4), (4, 7)):                 # two batches: the second one continues the running means
+        bat.integrate_batch([RGBDImage(be.dev(c), be.dev(d), **kw) for d, c, E in frs[lo:hi]], intr,
+                            [E for _, _, E in frs[lo:hi]],
+                            masks=[None if m is None else be.dev(m) for m in masks[lo:hi]] if use_mask else None,
+                            min_depth=2.9)
+    assert bat.status()[1] == seq.status()[1] == ref.block_updates        # blocks integrated, summed over the frames
+    ks, ts, ws, cs = seq.download()
+    kb, tb, wb, cb = bat.download()
+    ib = {tuple(k): i for i, k in enumerate(kb.tolist())}
+    assert set(ib) == set(map(tuple, ks.tolist())) and len(ib) > 20
+    order = np.array([ib[tuple(k)] for k in ks.tolist()])
+    np.testing.assert_array_equal(wb[order], ws)
+    np.testing.assert_array_equal(tb[order], ts)
+    np.testing.assert_array_equal(cb[order], cs)
+    compare(bat, ref, color=color)
