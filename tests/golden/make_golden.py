@@ -1,6 +1,8 @@
 """Generate golden vectors from the REFERENCE's own Python (run in the build container only).
 
-    python tests/golden/make_golden.py        # needs /root/reference, writes tests/golden/*.npz
+    python tests/golden/make_golden.py            # needs /root/reference, writes tests/golden/*.npz
+    python tests/golden/make_golden.py --ply      # only the splat PLY fixture (the reference's save_ply, executed)
+    python tests/golden/make_golden.py --open3d   # only where open3d==0.17.0 is installed: golden TSDF volume + mesh
 
 The reference has no unit tests or golden vectors.  What it does have
 are independent pure-Python implementations of sub-steps of the hot path that import on CPU:
@@ -48,7 +50,93 @@ def _import_reference():
     return sh_utils, graphics_utils, general_utils, tu
 
 
+def make_ply_fixture():
+    """The splat PLY as the REFERENCE writes it: GaussianModel.construct_list_of_attributes + save_ply
+    (GS/scene/gaussian_model.py:177-208) are lifted out of the file with ast and executed on CPU tensors; `plyfile`
+    (absent here) is replaced by a 20-line stand-in that serialises the structured array the reference builds exactly as
+    plyfile's binary writer does (header: `property float <name>` per field in dtype order, then the raw records).  The
+    loader under test (gs2mesh_amd/gaussian_model.py) never sees our own writer."""
+    import ast
+    src = open(os.path.join(GS, "scene", "gaussian_model.py")).read()
+    cls = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.ClassDef) and n.name == "GaussianModel")
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("construct_list_of_attributes", "save_ply")]
+    assert len(fns) == 2
+    captured = {}
+
+    class PlyElement:
+        @staticmethod
+        def describe(elements, name):
+            return (name, elements)
+
+    class PlyData:
+        def __init__(self, els):
+            self.els = els
+
+        def write(self, path):
+            (name, arr), = self.els
+            with open(path, "wb") as f:
+                f.write(b"ply\nformat binary_little_endian 1.0\n")
+                f.write(f"element {name} {len(arr)}\n".encode())
+                for field in arr.dtype.names:
+                    assert arr.dtype[field] == np.dtype("f4")
+                    f.write(f"property float {field}\n".encode())
+                f.write(b"end_header\n")
+                f.write(arr.astype(arr.dtype.newbyteorder("<")).tobytes())
+            captured["n"] = len(arr)
+
+    ns = {"np": np, "torch": torch, "os": os, "mkdir_p": lambda p: None, "PlyElement": PlyElement, "PlyData": PlyData}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "gaussian_model.py", "exec"), ns)
+    rng = np.random.default_rng(77)
+    P = 7
+    me = types.SimpleNamespace(
+        _xyz=torch.tensor(rng.normal(0, 1, (P, 3)), dtype=torch.float32),
+        _features_dc=torch.tensor(rng.normal(0, 1, (P, 1, 3)), dtype=torch.float32),
+        _features_rest=torch.tensor(rng.normal(0, 0.1, (P, 15, 3)), dtype=torch.float32),
+        _opacity=torch.tensor(rng.normal(0, 2, (P, 1)), dtype=torch.float32),
+        _scaling=torch.tensor(rng.normal(-4, 0.5, (P, 3)), dtype=torch.float32),
+        _rotation=torch.tensor(rng.normal(0, 1, (P, 4)), dtype=torch.float32))
+    me.construct_list_of_attributes = lambda: ns["construct_list_of_attributes"](me)
+    out = os.path.join(OUT, "reference_point_cloud.ply")
+    ns["save_ply"](me, out)
+    assert captured["n"] == P
+    np.savez(os.path.join(OUT, "reference_point_cloud.npz"), **{k[1:]: getattr(me, k).numpy() for k in
+                                                                ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")})
+    print("wrote", out)
+
+
+def make_open3d_golden():
+    """Golden volumes from the REAL dependency (open3d==0.17.0, requirements.txt:15) -- only where it is installed
+    (it is not in the build image: the tests that read tests/golden/open3d_tsdf.npz skip with that reason).  Same
+    frames as tests/test_tsdf_parity.py::frames(3, 160, 120, 170.0), the reference's call sequence
+    (gs2mesh_utils/tsdf_utils.py:53-56,88-93,106-108)."""
+    import open3d as o3d
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    sys.path.insert(0, os.path.dirname(OUT))
+    from test_tsdf_parity import frames
+    frs, (W, H, fx, fy, cx, cy) = frames(3, 160, 120, 170.0)
+    voxel, trunc = 2.0 / 128, 0.08
+    vol = o3d.pipelines.integration.ScalableTSDFVolume(voxel_length=voxel, sdf_trunc=trunc,
+                                                       color_type=o3d.pipelines.integration.TSDFVolumeColorType.RGB8)
+    intr = o3d.camera.PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
+    for d, c, E in frs:
+        rgbd = o3d.geometry.RGBDImage.create_from_color_and_depth(
+            o3d.geometry.Image(np.ascontiguousarray(c)), o3d.geometry.Image(np.ascontiguousarray(d, np.float32)),
+            depth_scale=1.0, depth_trunc=1e9, convert_rgb_to_intensity=False)
+        vol.integrate(rgbd, intr, E)
+    mesh = vol.extract_triangle_mesh()
+    pc = vol.extract_voxel_point_cloud()          # voxel centres with weight > 0; colour channel = (tsdf + 1) / 2
+    np.savez_compressed(os.path.join(OUT, "open3d_tsdf.npz"), version=o3d.__version__, voxel=voxel, trunc=trunc,
+                        vertices=np.asarray(mesh.vertices), triangles=np.asarray(mesh.triangles),
+                        vertex_colors=np.asarray(mesh.vertex_colors), voxel_points=np.asarray(pc.points),
+                        voxel_tsdf01=np.asarray(pc.colors)[:, 0])
+    print("wrote open3d_tsdf.npz from open3d", o3d.__version__)
+
+
 def main():
+    if "--open3d" in sys.argv:
+        return make_open3d_golden()
+    if "--ply" in sys.argv:
+        return make_ply_fixture()
     sh_utils, graphics_utils, general_utils, tu = _import_reference()
     rng = np.random.default_rng(20240611)
 
@@ -178,6 +266,7 @@ def main():
         bg=bg, viewmatrix=np.asarray(cam.world_view_transform, np.float32), projmatrix=np.asarray(cam.full_proj_transform, np.float32),
         campos=np.asarray(cam.camera_center, np.float32), tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
         **{"out_" + k: v for k, v in ref.items() if k != "num_rendered"}, out_num_rendered=ref["num_rendered"])
+    make_ply_fixture()
     print("golden fixtures written to", OUT)
 
 
