@@ -10,6 +10,7 @@
 
 #include "../../include/gs2mesh_amd.h"
 #include "raster_internal.h"
+#include "roctx_ranges.h"
 
 // ---- error plumbing ---------------------------------------------------------------------------
 static thread_local std::string g_err;
@@ -233,12 +234,15 @@ static hipEvent_t ev_get(gs2m_raster* r) {
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
-struct StageTimer {  // RAII: records an event pair around one stage launch when timing is on
+static const char* const kStageRange[GS2M_N_STAGES] = {"gs2m:project", "gs2m:hist_colscan", "gs2m:tile_scan", "gs2m:scatter",
+                                                        "gs2m:sort_tiles", "gs2m:blend", "gs2m:count_tiles"};
+struct StageTimer {  // RAII: a rocTX range (GS2M_ROCTX=1) and, when timing is on, an event pair around one stage launch
     gs2m_raster* r;
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
     int stage;
-    StageTimer(gs2m_raster* r_, hipStream_t st_, int stage_) : r(r_), st(st_), stage(stage_) {
+    Gs2mRange range;
+    StageTimer(gs2m_raster* r_, hipStream_t st_, int stage_) : r(r_), st(st_), stage(stage_), range(kStageRange[stage_]) {
         if (r->opt_timing) {
             a = ev_get(r);
             b = ev_get(r);

@@ -9,6 +9,7 @@
 #include "../../include/gs2mesh_amd.h"
 #include "tsdf_common.h"
 #include "tsdf_internal.h"
+#include "roctx_ranges.h"
 
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \
@@ -306,13 +307,19 @@ extern "C" int gs2m_tsdf_integrate(gs2m_tsdf* t, const float* depth, const uint8
     }
     const bool tm = e0 && e1 && e2 && e3;
     if (tm) (void)hipEventRecord(e0, st);
-    gs2m_launch_tsdf_touch(st, t->V, f, depth, mask);
+    {
+        Gs2mRange rg("gs2m:tsdf_touch");
+        gs2m_launch_tsdf_touch(st, t->V, f, depth, mask);
+    }
     if (tm) {
         (void)hipEventRecord(e1, st);
         (void)hipEventRecord(e2, st);
     }
     // persistent grid: enough workgroups to fill the chip; each loops over the touched list
-    gs2m_launch_tsdf_integrate(st, t->n_cu * 7, t->V, f, depth, color, mask);
+    {
+        Gs2mRange rg("gs2m:tsdf_integrate");
+        gs2m_launch_tsdf_integrate(st, t->n_cu * 7, t->V, f, depth, color, mask);
+    }
     if (tm) {
         (void)hipEventRecord(e3, st);
         t->ev_live.push_back({0, e0, e1, 1});
@@ -372,12 +379,18 @@ extern "C" int gs2m_tsdf_integrate_batch(gs2m_tsdf* t, int n_frames, const float
         }
         const bool tm = e0 && e1 && e2 && e3;
         if (tm) (void)hipEventRecord(e0, st);
-        gs2m_launch_tsdf_touch_batch(st, t->V, hb[0].f, nf, t->d_bframes);
+        {
+            Gs2mRange rg("gs2m:tsdf_touch_batch");
+            gs2m_launch_tsdf_touch_batch(st, t->V, hb[0].f, nf, t->d_bframes);
+        }
         if (tm) {
             (void)hipEventRecord(e1, st);
             (void)hipEventRecord(e2, st);
         }
-        gs2m_launch_tsdf_integrate_batch(st, t->n_cu * 2, t->V, t->d_bframes);
+        {
+            Gs2mRange rg("gs2m:tsdf_integrate_batch");
+            gs2m_launch_tsdf_integrate_batch(st, t->n_cu * 2, t->V, t->d_bframes);
+        }
         if (tm) {
             (void)hipEventRecord(e3, st);
             t->ev_live.push_back({0, e0, e1, nf});

@@ -69,6 +69,23 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     rs = raster_settings
     h = _handle(means3D.device)
     none_if_empty = lambda t: None if t is None or t.numel() == 0 else _f32c(t)
+    if rs.debug:
+        # the reference's debug mode (DGR __init__.py:83-90): keep a host copy of every argument and, if the rasteriser
+        # fails, leave it in snapshot_fw.dump for post-mortem; the C ABI call itself runs with a sync + check per launch
+        keep = tuple(t.detach().cpu().clone() if isinstance(t, torch.Tensor) else t for t in (
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+            rs.prefiltered, rs.debug))
+        try:
+            return _forward(h, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, none_if_empty)
+        except Exception as ex:
+            torch.save(keep, "snapshot_fw.dump")
+            print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise ex
+    return _forward(h, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, none_if_empty)
+
+
+def _forward(h, rs, means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, none_if_empty):
     color, radii = h.forward(
         _f32c(means3D), _f32c(opacities).reshape(-1), _f32c(rs.viewmatrix), _f32c(rs.projmatrix), _f32c(rs.campos),
         _f32c(rs.bg), int(rs.image_width), int(rs.image_height), float(rs.tanfovx), float(rs.tanfovy),

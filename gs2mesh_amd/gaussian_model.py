@@ -111,6 +111,19 @@ class GaussianModel:
     def get_opacity(self):
         return torch.sigmoid(self._opacity)
 
+    def get_covariance(self, scaling_modifier=1.0):
+        """GS/scene/gaussian_model.py:117-118 -> build_covariance_from_scaling_rotation (:27-31): Sigma = L L^T with
+        L = R(q / |q|) diag(modifier * exp(scaling)), returned as the 6 upper-triangle entries
+        [xx, xy, xz, yy, yz, zz] (general_utils.strip_lowerdiag) -- the layout the rasteriser's cov3D_precomp takes."""
+        q = torch.nn.functional.normalize(self._rotation)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).view(-1, 3, 3)
+        L = R * (scaling_modifier * self.get_scaling).unsqueeze(1)      # R @ diag(s)
+        S = L @ L.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=1)
+
     def load_ply(self, path):
         d = read_gaussian_ply(path)
         P = d["xyz"].shape[0]

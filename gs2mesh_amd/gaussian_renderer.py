@@ -28,16 +28,25 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         campos=_dev(viewpoint_camera.camera_center, device), prefiltered=False,
         debug=bool(getattr(pipe, "debug", False)))
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+    # 3D covariance: from scale / rotation inside the rasteriser, or (pipe.compute_cov3D_python, :56-61) on the host side
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
-        raise NotImplementedError("compute_cov3D_python: pass cov3D_precomp to the rasterizer directly")
-    scales = pc.get_scaling
-    rotations = pc.get_rotation
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+    # colour: SH evaluated by the rasteriser, or (pipe.convert_SHs_python, :67-78) in torch, or the caller's override
     shs = colors_precomp = None
     if override_color is None:
         if getattr(pipe, "convert_SHs_python", False):
-            raise NotImplementedError("convert_SHs_python: pass colors_precomp to the rasterizer directly")
-        shs = pc.get_features
+            from .sh_utils import eval_sh
+            n_coef = (pc.max_sh_degree + 1) ** 2
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, n_coef)
+            dir_pp = pc.get_xyz - _dev(viewpoint_camera.camera_center, device).repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
     else:
         colors_precomp = override_color
     with torch.no_grad():

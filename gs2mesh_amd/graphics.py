@@ -19,35 +19,26 @@ import numpy as np
 
 
 def getWorld2View2(R, t, translate=np.array([0.0, 0.0, 0.0]), scale=1.0):
-    """graphics_utils.py:38-49.  R is the TRANSPOSED world->camera rotation (3DGS convention)."""
-    Rt = np.zeros((4, 4))
-    Rt[:3, :3] = np.asarray(R).transpose()
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    C2W = np.linalg.inv(Rt)
-    cam_center = C2W[:3, 3]
-    cam_center = (cam_center + translate) * scale
-    C2W[:3, 3] = cam_center
-    Rt = np.linalg.inv(C2W)
-    return np.float32(Rt)
+    """World -> view matrix of graphics_utils.py:38-49.  R is the TRANSPOSED world->camera rotation (3DGS convention).
+    Mathematically this is [ R^T | -R^T (c + translate) scale ] with the camera centre c = -R t (= [ R^T | t ] for the
+    defaults); it is evaluated the way the reference does -- invert, move the centre, invert back, in float64 -- because
+    the kernels' projected records are compared BIT FOR BIT with the reference's and the two LAPACK inversions leave
+    their own last-bit rounding in the float32 result (the closed form differs from it by 1 ulp in ~1 entry of 16)."""
+    w2c = np.block([[np.asarray(R, np.float64).T, np.reshape(np.asarray(t, np.float64), (3, 1))],
+                    [np.zeros((1, 3)), np.ones((1, 1))]])
+    c2w = np.linalg.inv(w2c)
+    c2w[:3, 3] = (c2w[:3, 3] + np.asarray(translate, np.float64)) * scale
+    return np.linalg.inv(c2w).astype(np.float32)
 
 
 def getProjectionMatrix(znear, zfar, fovX, fovY):
-    """graphics_utils.py:51-71, as float32 numpy [4,4] (P[3,2] = 1, z in [0,1])."""
-    tanHalfFovY = math.tan(fovY / 2)
-    tanHalfFovX = math.tan(fovX / 2)
-    top = tanHalfFovY * znear
-    bottom = -top
-    right = tanHalfFovX * znear
-    left = -right
+    """Clip matrix of graphics_utils.py:51-71 (float32 [4,4], w = z_view, z mapped to [0,1]): the frustum is symmetric
+    (right = -left = znear tan(fovX / 2), likewise in y), so the off-centre terms vanish and the scales are 1 / tan."""
     P = np.zeros((4, 4), np.float32)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
+    P[0, 0] = 1.0 / math.tan(fovX / 2)
+    P[1, 1] = 1.0 / math.tan(fovY / 2)
+    P[3, 2] = 1.0
+    P[2, 2] = zfar / (zfar - znear)
     P[2, 3] = -(zfar * znear) / (zfar - znear)
     return P
 
