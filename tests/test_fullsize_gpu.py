@@ -136,11 +136,16 @@ def test_c2_tsdf_frames_vs_oracle_and_order_invariance():
 # Measured on MI355X (gpurun_out/parity_<cfg>.json, copied to profiles/r2a_parity_<cfg>.json); every bound below is
 # <= 2x the measured worst case over the checked eyes.
 BENCH_PARITY_BOUNDS = {
-    #        max_abs  mean_abs  psnr_db  frac>1e-5  u8 flipped px  radii mismatches (fused exp/sigmoid vs numpy)
-    # measured r2a: C2 max 2.0e-3 (2.6e-3 on the bench's pair), mean 4.7e-8, PSNR 115.8 / 114.2 dB, 8.0e-6 of the values off by
-    # > 1e-5, 70 u8 pixels off by 1 LSB, 1 radius;  C3 max 3.8e-4, mean 3.0e-8, PSNR 130.8 dB, 1.6e-6, 26 pixels, 1 radius
-    "C2": dict(max_abs=5e-3, mean_abs=1e-7, psnr_db=111.0, frac_gt_1e5=1.6e-5, u8_flipped_pixels=140, radii_mismatches=2),
-    "C3": dict(max_abs=8e-4, mean_abs=6e-8, psnr_db=127.0, frac_gt_1e5=3.2e-6, u8_flipped_pixels=52, radii_mismatches=2),
+    # all-VALU compositing (blend 4, the default).  Measured r2a/r2i: C2 max 2.0e-3 (2.6e-3 on the bench's pair), mean 4.7e-8,
+    # PSNR 115.8 / 114.2 dB, 8.0e-6 of the values off by > 1e-5, 70 u8 pixels off by 1 LSB, 1 radius;  C3 max 3.8e-4,
+    # mean 3.0e-8, PSNR 130.8 dB, 1.6e-6, 26 pixels, 1 radius
+    ("C2", 4): dict(max_abs=5e-3, mean_abs=1e-7, psnr_db=111.0, frac_gt_1e5=1.6e-5, u8_flipped_pixels=140, radii_mismatches=2),
+    ("C3", 4): dict(max_abs=8e-4, mean_abs=6e-8, psnr_db=127.0, frac_gt_1e5=3.2e-6, u8_flipped_pixels=52, radii_mismatches=2),
+    # exponents on the matrix cores (blend 7: bf16x3 split, fp32 accumulate -> ~1e-7 of the largest polynomial term instead
+    # of ~1e-7 of q).  Measured r2b: C2 max 2.0e-3, mean 4.8e-8, PSNR 115.8 dB, 6.9e-6, 71 pixels;  C3 (sharp 1.3-px
+    # Gaussians: larger terms) max 1.35e-3, mean 5.3e-8, PSNR 121.8 dB, 6.5e-6, 44 pixels
+    ("C2", 7): dict(max_abs=5e-3, mean_abs=1e-7, psnr_db=111.0, frac_gt_1e5=1.6e-5, u8_flipped_pixels=142, radii_mismatches=2),
+    ("C3", 7): dict(max_abs=2.7e-3, mean_abs=1.1e-7, psnr_db=118.5, frac_gt_1e5=1.3e-5, u8_flipped_pixels=88, radii_mismatches=2),
 }
 
 
@@ -195,7 +200,7 @@ def test_bench_configuration_full_size_vs_oracle(cfg_name, blend):
     with open(os.path.join("gpurun_out", f"parity_{cfg_name}_blend{blend}.json"), "w") as fh:
         json.dump(worst, fh, indent=1)
     print("PARITY", cfg_name, "blend", blend, json.dumps(worst))
-    b = BENCH_PARITY_BOUNDS[cfg_name]
+    b = BENCH_PARITY_BOUNDS[(cfg_name, blend)]
     assert worst["max_abs"] <= b["max_abs"], worst
     assert worst["mean_abs"] <= b["mean_abs"], worst
     assert worst["psnr_db"] >= b["psnr_db"], worst
