@@ -52,6 +52,7 @@ _PROTOS = {
     "gs2m_render_views": (i32, [vp, C.POINTER(Gaussians), C.POINTER(Camera), i32, C.POINTER(f32), f32, vp, vp, vp,
                                 vp]),
     "gs2m_raster_pack_sh": (i32, [vp, C.POINTER(Gaussians), vp]),
+    "gs2m_raster_pack_model": (i32, [vp, C.POINTER(Gaussians), vp, vp]),
     "gs2m_raster_status": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
     "gs2m_raster_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
     "gs2m_raster_download_geometry": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -54,6 +54,19 @@ struct gs2m_raster {
     const float* pack_src = nullptr;
     const float* pack_src_rest = nullptr;
     int pack_P = 0;
+    // gs2m_raster_pack_model: spatially ordered packed copy of the per-Gaussian parameters (the SH copy above is then in
+    // the same order), order = position -> id, rank = id -> position
+    float* d_pk_xyz = nullptr;
+    float* d_pk_scales = nullptr;
+    float* d_pk_rots = nullptr;
+    float* d_pk_opac = nullptr;
+    int* d_order = nullptr;
+    int* d_rank = nullptr;
+    size_t pk_cap3 = 0, pk_cap3s = 0, pk_cap4 = 0, pk_cap1 = 0, order_cap = 0, rank_cap = 0;
+    const float* model_src[4] = {nullptr, nullptr, nullptr, nullptr};  // xyz, scales, rotations, opacities packed from
+    bool model_packed = false;
+    bool last_packed = false;        // the last pass ran on the packed copy (parity taps map positions back to ids)
+    const int* run_rank = nullptr;   // rank table of the pass being launched (null: keys carry record positions)
     size_t mask_cap = 0;
     unsigned* d_hist = nullptr;
     size_t hist_cap = 0;  // words
@@ -116,6 +129,12 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     (void)hipFree(r->d_recs);
     (void)hipFree(r->d_tilemask);
     (void)hipFree(r->d_shpack);
+    (void)hipFree(r->d_pk_xyz);
+    (void)hipFree(r->d_pk_scales);
+    (void)hipFree(r->d_pk_rots);
+    (void)hipFree(r->d_pk_opac);
+    (void)hipFree(r->d_order);
+    (void)hipFree(r->d_rank);
     (void)hipFree(r->d_hist);
     (void)hipFree(r->d_tile_count);
     (void)hipFree(r->d_tile_start);
@@ -141,7 +160,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
     switch (option) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
         case GS2M_OPT_BLEND_VARIANT:
-            if (value != 0 && value != 4 && value != 7) {
+            if (value != 0 && value != 4 && value != 7 && !(value >= 40 && value < 60)) {  // 40..59: development A/B variants
                 gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0, 4 or 7");
                 return 1;
             }
@@ -178,7 +197,7 @@ static void geometry(int P, int* chunk, int* n_wg) {
     int c = (P + target - 1) / target;
     c = (c + 255) / 256 * 256;
     if (c < 256) c = 256;
-    if (c > 65280) c = 65280;  // k_count_tiles keeps 16-bit per-tile counters per workgroup
+    if (c > 64000) c = 64000;  // k_count_tiles keeps 16-bit per-tile counters per workgroup (chunk + one sub-chunk < 65536)
     *chunk = c;
     *n_wg = (P + c - 1) / c;
     if (*n_wg < 1) *n_wg = 1;
@@ -293,7 +312,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     {
         StageTimer tm(r, st, GS2M_STAGE_COUNT);
         if (gs2m_launch_count_tiles(nv, n_wg, wg_threads, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
-                                    cull_arg_p))
+                                    cull_arg_p, g.ids != nullptr))
             return 1;
     }
     if (dbg_check(r, st, "count_tiles")) return 1;
@@ -310,7 +329,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
         if (gs2m_launch_scatter(nv, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
-                                r->d_tilemask, r->d_keys, cap, cull_arg_s))
+                                r->d_tilemask, r->d_keys, cap, cull_arg_s, g.ids, g.ids != nullptr))
             return 1;
     }
     if (dbg_check(r, st, "scatter")) return 1;
@@ -322,11 +341,12 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     {
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
         if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
-                              g.P, cap, out_color, out_rgb8))
+                              g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr))
             return 1;
     }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;
+    r->last_packed = g.ids != nullptr;
     r->last_nv = nv;
     r->last_tiles = tiles;
     r->last_cap = cap;
@@ -392,6 +412,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     g.shs_packed = nullptr;
     g.cov3D_precomp = cov3D_precomp;
     g.colors_precomp = colors_precomp;
+    g.ids = nullptr;
     g.P = P;
     g.D = D;
     g.M = M;
@@ -467,6 +488,19 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
                        ? r->d_shpack : nullptr;
     g.cov3D_precomp = nullptr;
     g.colors_precomp = nullptr;
+    g.ids = nullptr;
+    r->run_rank = nullptr;
+    if (r->model_packed && g.shs_packed && r->model_src[0] == gs->xyz && r->model_src[1] == gs->scales &&
+        r->model_src[2] == gs->rotations && r->model_src[3] == gs->opacities) {
+        // the spatially ordered packed copy of THESE Gaussians (gs2m_raster_pack_model): every stage works on positions of
+        // the copy; ids only enter the sort keys (tie order of the reference) and the radii output
+        g.xyz = r->d_pk_xyz;
+        g.scales = r->d_pk_scales;
+        g.rots = r->d_pk_rots;
+        g.opac = r->d_pk_opac;
+        g.ids = r->d_order;
+        r->run_rank = r->d_rank;
+    }
     g.P = gs->P;
     g.D = gs->sh_degree;
     g.M = gs->M;
@@ -508,23 +542,67 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     return 0;
 }
 
-extern "C" int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* gs, gs2m_stream stream) {
+static int pack_common(gs2m_raster* r, const gs2m_gaussians* gs, const int32_t* order, gs2m_stream stream, const char* who) {
     if (!r || !gs) {
-        gs2m_set_error("gs2m_raster_pack_sh: NULL argument");
+        gs2m_set_error("%s: NULL argument", who);
         return 1;
     }
     r->pack_src = nullptr;
     r->pack_src_rest = nullptr;
     r->pack_P = 0;
+    r->model_packed = false;
     if (gs->P <= 0 || gs->M != 16 || !gs->shs) return 0;  // nothing to pack: the kernels read the caller's layout
     HIPCHK(hipSetDevice(r->device));
-    const size_t groups = ((size_t)gs->P + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t P = (size_t)gs->P;
+    const size_t groups = (P + 63) / 64;
     if (ensure(&r->d_shpack, &r->shpack_cap, groups * 12 * 64 * 4)) return 1;
-    gs2m_launch_pack_sh((hipStream_t)stream, gs->P, gs->shs, gs->shs_rest, r->d_shpack);
+    if (order) {
+        if (!gs->xyz || !gs->scales || !gs->rotations || !gs->opacities) {
+            gs2m_set_error("%s: NULL Gaussian array", who);
+            return 1;
+        }
+        if (ensure(&r->d_pk_xyz, &r->pk_cap3, 3 * P) || ensure(&r->d_pk_scales, &r->pk_cap3s, 3 * P) ||
+            ensure(&r->d_pk_rots, &r->pk_cap4, 4 * P) || ensure(&r->d_pk_opac, &r->pk_cap1, P) ||
+            ensure(&r->d_order, &r->order_cap, P) || ensure(&r->d_rank, &r->rank_cap, P + 1))
+            return 1;
+        HIPCHK(hipMemcpyAsync(r->d_order, order, sizeof(int) * P, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemsetAsync(r->d_rank, 0xff, sizeof(int) * P, st));          // holes = -1
+        HIPCHK(hipMemsetAsync(r->d_rank + P, 0, sizeof(int), st));             // word P: "not a permutation" flag
+        gs2m_launch_pack_model(st, gs->P, r->d_order, gs->xyz, gs->scales, gs->rotations, gs->opacities, r->d_pk_xyz,
+                               r->d_pk_scales, r->d_pk_rots, r->d_pk_opac, r->d_rank, reinterpret_cast<unsigned*>(r->d_rank + P));
+        int bad = 0;
+        HIPCHK(hipMemcpyAsync(&bad, r->d_rank + P, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));   // one-time preparation: a checked result is worth the sync
+        if (bad) {
+            gs2m_set_error("%s: order is not a permutation of 0..P-1", who);
+            return 1;
+        }
+    }
+    gs2m_launch_pack_sh(st, gs->P, gs->shs, gs->shs_rest, r->d_shpack, order ? r->d_order : nullptr);
     r->pack_src = gs->shs;
     r->pack_src_rest = gs->shs_rest;
     r->pack_P = gs->P;
+    if (order) {
+        r->model_src[0] = gs->xyz;
+        r->model_src[1] = gs->scales;
+        r->model_src[2] = gs->rotations;
+        r->model_src[3] = gs->opacities;
+        r->model_packed = true;
+    }
     return 0;
+}
+
+extern "C" int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* gs, gs2m_stream stream) {
+    return pack_common(r, gs, nullptr, stream, "gs2m_raster_pack_sh");
+}
+
+extern "C" int gs2m_raster_pack_model(gs2m_raster* r, const gs2m_gaussians* gs, const int32_t* order, gs2m_stream stream) {
+    if (!order) {
+        gs2m_set_error("gs2m_raster_pack_model: order is NULL (gs2m_raster_pack_sh packs without reordering)");
+        return 1;
+    }
+    return pack_common(r, gs, order, stream, "gs2m_raster_pack_model");
 }
 
 extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_views, int64_t* num_rendered,
@@ -594,8 +672,19 @@ extern "C" int gs2m_raster_download_geometry(gs2m_raster* r, gs2m_stream stream,
         gs2m_set_error("hipMemcpy: %s", hipGetErrorString(e));
         return 1;
     }
-    for (int i = 0; i < P; ++i) {
-        const GeomRec& q = h[i];
+    int* ord = nullptr;   // packed model: record position -> Gaussian id (the taps are indexed by id, like the reference's arrays)
+    if (r->last_packed) {
+        ord = (int*)malloc(sizeof(int) * (size_t)P);
+        if (!ord || hipMemcpy(ord, r->d_order, sizeof(int) * (size_t)P, hipMemcpyDeviceToHost) != hipSuccess) {
+            free(ord);
+            free(h);
+            gs2m_set_error("gs2m_raster_download_geometry: cannot read the packed order");
+            return 1;
+        }
+    }
+    for (int pos = 0; pos < P; ++pos) {
+        const GeomRec& q = h[pos];
+        const int i = ord ? ord[pos] : pos;
         const unsigned x0 = q.rect0 & 0xffffu, y0 = q.rect0 >> 16, x1 = q.rect1 & 0xffffu, y1 = q.rect1 >> 16;
         const bool vis = x1 > x0 && y1 > y0;
         if (means2D) {
@@ -622,6 +711,7 @@ extern "C" int gs2m_raster_download_geometry(gs2m_raster* r, gs2m_stream stream,
         }
         if (tiles_touched) tiles_touched[i] = vis ? (x1 - x0) * (y1 - y0) : 0u;
     }
+    free(ord);
     free(h);
     return 0;
 }

@@ -26,7 +26,7 @@ GS2M_DEVICE unsigned char quantize_u8(float c) {
 GS2M_KERNEL void __launch_bounds__(256)
 k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                 const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
+                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank) {
     __shared__ float4 s_a[256];  // mx, my, ca, cb
     __shared__ float4 s_b[256];  // cc, op, r, g
     __shared__ float s_c[256];   // b
@@ -53,7 +53,8 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
         const int num_done = gs2m_syncthreads_count(done ? 1 : 0);
         if (num_done == 256) break;
         if (base + (unsigned)tid < r1) {
-            const unsigned gid = (unsigned)(kv[base + tid] & 0xffffffffull);
+            unsigned gid = (unsigned)(kv[base + tid] & 0xffffffffull);
+            if (rank) gid = (unsigned)rank[gid];   // packed model: id in the key -> position of the record
             const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
             s_a[tid] = r4[0];
             s_b[tid] = r4[1];
@@ -134,11 +135,11 @@ struct BlendInst {
     float2 c;
 };
 
-template <int WPB, int LROWS, int OCC>
+template <int WPB, int LROWS, int OCC, int STEP = 0>
 GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
+               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank) {
     // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
     // log2 o, r, g}, c = {b, quadrant mask | general << 8 (bits)}; 2 pad slots: the software-pipelined reads run 2
     // instances ahead.  5.6 KiB of LDS per wave with the DMA landing zone: 7 waves per SIMD fit the 160 KiB.
@@ -185,13 +186,21 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const GeomRec* rv = recs + (size_t)v * P;
     const float LOG2E = 1.44269504088896340736f;
     const float QMIN = -7.99435343685885793770f;  // -log2(255): alpha >= 1/255 <=> q >= QMIN (decided in the log2 domain)
-    // ---- prefetch pipeline: ids two batches ahead (one VGPR), records one batch ahead (DMA into LDS) ----
+    // ---- prefetch pipeline: ids two batches ahead (one VGPR), records one batch ahead (DMA into LDS).  With a packed
+    // (spatially ordered) model the low word of a key is the Gaussian's id and `rank` maps it to the position of its
+    // record: one more stage, keys three batches ahead (`kid_next2`, ids) and their ranks two batches ahead.
     unsigned base = r0;
-    unsigned gid_next = 0u;   // Gaussian id of instance base + 64 + lane
+    unsigned gid_next = 0u;   // record index of instance base + 64 + lane
+    unsigned kid_next2 = 0u;  // (rank != null) id of instance base + 128 + lane
     {
         unsigned gid = 0u;
         if (base + (unsigned)lane < r1) gid = (unsigned)(kv[base + lane] & 0xffffffffull);
         if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)(kv[base + 64u + lane] & 0xffffffffull);
+        if (rank) {
+            if (base + 128u + (unsigned)lane < r1) kid_next2 = (unsigned)(kv[base + 128u + lane] & 0xffffffffull);
+            if (base + (unsigned)lane < r1) gid = (unsigned)rank[gid];
+            if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)rank[gid_next];
+        }
         if (base + (unsigned)lane < r1) {
             const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
             gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
@@ -269,7 +278,13 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
             gs2m_global_load_lds16(r4 + 2, &s_raw[wave][2][0]);
         }
-        if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)(kv[base + 64u + lane] & 0xffffffffull);
+        if (rank) {
+            // both loads are consumed after the next gs2m_wait_dma: the rank of the ids fetched a batch ago, and new ids
+            if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)rank[kid_next2];
+            if (base + 128u + (unsigned)lane < r1) kid_next2 = (unsigned)(kv[base + 128u + lane] & 0xffffffffull);
+        } else if (base + 64u + (unsigned)lane < r1) {
+            gid_next = (unsigned)(kv[base + 64u + lane] & 0xffffffffull);
+        }
         // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
         // constants are in flight while instance j is composited (no LDS wait on the critical path).
         auto step = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
@@ -307,6 +322,53 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 }
             }
         };
+        // STEP 1: the exponents and threshold compares of all four quadrants are formed up front (one block of
+        // independent VALU work, the lane masks are in scalar registers before the first branch needs them); one branch
+        // skips an instance no pixel of the tile sees, one per quadrant guards its accumulate path.
+        auto step_h = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+            const int qm = qmf & (int)lq;
+            if (qm != 0) {
+                const float dx0 = A.x - pxf0, dx1 = A.x - pxf1, dy0 = A.y - pyf0, dy1 = A.y - pyf1;
+                const float e0 = fmaf(A.z * dx0, dx0, B.y), e1 = fmaf(A.z * dx1, dx1, B.y);
+                const float n0 = -(A.w * dx0), n1 = -(A.w * dx1);
+                float qv[4];
+                qv[0] = fmaf(fmaf(B.x, dy0, n0), dy0, e0);
+                qv[1] = fmaf(fmaf(B.x, dy0, n1), dy0, e1);
+                qv[2] = fmaf(fmaf(B.x, dy1, n0), dy1, e0);
+                qv[3] = fmaf(fmaf(B.x, dy1, n1), dy1, e1);
+                unsigned long long prem[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    prem[k] = (qm & (1 << k)) ? (gs2m_ballot_b(qv[k] >= QMIN) & ~dn[k]) : 0ull;
+                if ((prem[0] | prem[1] | prem[2] | prem[3]) != 0ull) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (prem[k] != 0ull) {
+                            float alpha = gs2m_fast_exp2(qv[k]);
+                            unsigned long long candm = prem[k];
+                            if (qmf & 0x100) {
+                                GS2M_NO_IF_CONVERT();
+                                candm = prem[k] & ~gs2m_ballot_b(qv[k] > B.y);
+                                alpha = fminf(0.99f, alpha);
+                            }
+                            const float test_T = fmaf(-T[k], alpha, T[k]);
+                            const unsigned long long satm = gs2m_ballot_b(test_T < 0.0001f) & candm;
+                            const float Tn = gs2m_lanes(candm & ~satm) ? test_T : T[k];
+                            const float wT = T[k] - Tn;
+                            C0[k] = fmaf(B.z, wT, C0[k]);
+                            C1[k] = fmaf(B.w, wT, C1[k]);
+                            C2[k] = fmaf(CL.x, wT, C2[k]);
+                            T[k] = Tn;
+                            dn[k] |= satm;
+                        }
+                    }
+                }
+            }
+        };
+        auto step_any = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+            if (STEP == 1) step_h(qmf, CL, A, B);
+            else step(qmf, CL, A, B);
+        };
         // The quadrant mask is read (= the LDS wait) BEFORE the next instance's reads are issued, so the
         // wait never covers a read that was just issued (the compiler's waitcnt is lgkmcnt(0) in this loop).
         const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
@@ -321,16 +383,16 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             B1 = spb[j + 1];
             K1 = spc[j + 1];
             GS2M_SCHED_BARRIER();
-            step(qm0, K0, A0, B0);
+            step_any(qm0, K0, A0, B0);
             const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
             GS2M_SCHED_BARRIER();
             A0 = spa[j + 2];
             B0 = spb[j + 2];
             K0 = spc[j + 2];
             GS2M_SCHED_BARRIER();
-            step(qm1, K1, A1, B1);
+            step_any(qm1, K1, A1, B1);
         }
-        if (j < nb) step(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
+        if (j < nb) step_any(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
     }
     gs2m_wait_dma();   // never leave with a DMA write to this workgroup's LDS in flight
     const size_t plane = (size_t)H * W;

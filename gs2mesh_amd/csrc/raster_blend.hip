@@ -9,22 +9,36 @@
 //   0: the reference's structure (256-thread workgroup per tile, 1 pixel per lane; 16 x 16 lists only)
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P, unsigned cap,
-                      float* out_color, unsigned char* out_rgb8) {
+                      float* out_color, unsigned char* out_rgb8, const int* rank) {
     const int tiles = gx * gy;
     const dim3 grid((tiles + 3) / 4, nv), block(256);
     if (variant == 7) {
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_mfma<4, 2, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
-        else GS2M_LAUNCH((k_blend_mfma<4, 1, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_mfma<4, 2, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
+        else GS2M_LAUNCH((k_blend_mfma<4, 1, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
         return 0;
     }
 
     if (variant == 4) {
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
-        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
+        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
         return 0;
     }
+    // development variants (A/B on the GPU box; not part of the documented option values)
+#define GS2M_BLEND_DEV(V, WPB, OCC, STEP)                                                                                              \
+    if (variant == V) {                                                                                                                \
+        const dim3 g2((tiles + WPB - 1) / WPB, nv), b2(64 * WPB);                                                                      \
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<WPB, 2, OCC, STEP>), g2, b2, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank); \
+        else GS2M_LAUNCH((k_blend_wave4e<WPB, 1, OCC, STEP>), g2, b2, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank); \
+        return 0;                                                                                                                      \
+    }
+    GS2M_BLEND_DEV(41, 4, 7, 1)
+    GS2M_BLEND_DEV(42, 2, 7, 0)
+    GS2M_BLEND_DEV(43, 1, 7, 0)
+    GS2M_BLEND_DEV(44, 2, 7, 1)
+    GS2M_BLEND_DEV(45, 4, 6, 1)
+    GS2M_BLEND_DEV(46, 8, 7, 0)
     if (variant == 0 && tile_rows == 1) {
-        GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8);
+        GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
         return 0;
     }
     gs2m_set_error("blend variant %d is not available with GS2M_OPT_TILE_ROWS %d (variants: 0 [rows 1 only], 4, 7)", variant, tile_rows);

@@ -85,7 +85,7 @@ template <int WPB, int LROWS, int MODE>
 GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_blend_mfma(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
              const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-             float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8) {
+             float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank) {
     __shared__ MfmaInst s_i[WPB][64];
     __shared__ uint4 s_B[4][2][64];  // pixel-feature operand of quadrant k, pixel half h (the same for every tile)
     const int tid = (int)threadIdx.x;
@@ -159,7 +159,8 @@ k_blend_mfma(const unsigned long long* __restrict__ keys, const unsigned* __rest
     rb.y = 1.0f;
     unsigned base = r0;
     if (base + (unsigned)lane < r1) {
-        const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+        unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+        if (rank) gid = (unsigned)rank[gid];
         const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
         ra = r4[0];
         rb = r4[1];
@@ -214,7 +215,8 @@ k_blend_mfma(const unsigned long long* __restrict__ keys, const unsigned* __rest
         gs2m_wave_sync();
         base += 64u;
         if (base + (unsigned)lane < r1) {  // gather the next batch while this one is composited
-            const unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+            unsigned gid = (unsigned)(kv[base + lane] & 0xffffffffull);
+            if (rank) gid = (unsigned)rank[gid];
             const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
             ra = r4[0];
             rb = r4[1];

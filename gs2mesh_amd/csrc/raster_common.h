@@ -44,9 +44,21 @@ struct GaussIn {
     const float* shs_packed;      // null or wave-transposed SH [ceil(P/64)][12][64] float4 (M = 16 only)
     const float* cov3D_precomp;   // null or [P,6]
     const float* colors_precomp;  // null or [P,3]
+    const int* ids;               // null, or [P]: Gaussian id of array position j (a spatially ordered packed copy of the
+                                  // model, gs2m_raster_pack_model): ids go into the sort keys (the reference's order among
+                                  // equal depths) and index the radii output; everything else is indexed by position
     int P, D, M, raw;
     float scale_modifier;
 };
+
+// Workgroup -> work-item index such that the workgroups of one XCD (block b runs on XCD b % 8) own a CONTIGUOUS run of
+// indices: a bijection of [0, nwg).  Used for the tile groups of the compositing kernel (neighbouring tiles share
+// Gaussians -> same L2) and for the Gaussian chunks of the counting sort (the segments one XCD writes into a tile's key
+// range are then adjacent, so the partial lines of its 8-B key stores merge in ITS L2 before they are written back).
+GS2M_DEVICE unsigned gs2m_xcd_contiguous(unsigned bid, unsigned nwg) {
+    const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
+    return (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
+}
 
 // Per-view status words written by the tile scan.
 struct ViewStatus {

@@ -12,13 +12,17 @@ void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUnif
                          int exact_cull);
 int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
-                            int exact_cull);
+                            int exact_cull, int interleave);
 int gs2m_count_threads(int chunk);
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads);
 int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
-                        const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull);
-void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed);
+                        const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
+                        const int* ids, int interleave);
+void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed, const int* order);
+void gs2m_launch_pack_model(hipStream_t st, int P, const int* order, const float* xyz, const float* scales, const float* rots,
+                            const float* opac, float* p_xyz, float* p_scales, float* p_rots, float* p_opac, int* rank,
+                            unsigned* bad);
 void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,
                               unsigned char* present);
 void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,
@@ -34,7 +38,7 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
                             const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists);
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
-                      unsigned cap, float* out_color, unsigned char* out_rgb8);
+                      unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank);
 
 // error plumbing (common_api.hip)
 void gs2m_set_error(const char* fmt, ...);

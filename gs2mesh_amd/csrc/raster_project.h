@@ -210,7 +210,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 GeomRec* rec = recs + (size_t)v * g.P + gi;
-                if (radii) radii[(size_t)v * g.P + gi] = pv[v].radius;
+                if (radii) radii[(size_t)v * g.P + (g.ids ? g.ids[gi] : gi)] = pv[v].radius;
                 if (!pv[v].ok) {
                     // invisible: only the vector holding the (empty) rect is written
                     float4 w2;
@@ -280,6 +280,28 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
     }
 }
 
+// Gaussian -> workgroup assignment of the counting sort (k_count_tiles and k_scatter must agree: the histogram row of a
+// workgroup describes exactly the Gaussians it scatters).  Step `it` of wave `wave` of the workgroup with histogram row
+// `row` starts at the returned index (64 consecutive Gaussians, one per lane); *end = one past the last index it may take;
+// returns -1 when the wave is done.
+//   contiguous (models in their stored order): the workgroup owns [row * chunk, (row + 1) * chunk) and walks it
+//     blockDim.x Gaussians at a time;
+//   interleaved (spatially ordered packed model, gs2m_raster_pack_model): blocks of 64 consecutive Gaussians are dealt
+//     round-robin to the rows.  A block is a compact screen region (its instances fall into a few tiles: the keys of a
+//     store instruction form runs), while every workgroup samples the whole model, so the work stays balanced (contiguous
+//     chunks of a Morton-ordered model differ by 2.4x in instances on C2).
+GS2M_DEVICE int bin_step_begin(int it, int wave, int nwaves, int row, int n_wg, int chunk, int P, int interleave, int* end) {
+    if (interleave) {
+        const long long first = (((long long)it * nwaves + wave) * n_wg + row) * 64ll;
+        *end = P;
+        return first < (long long)P ? (int)first : -1;
+    }
+    const int stop = gs2m_imin(P, (row + 1) * chunk);   // chunk <= 64000, rows < 2^15: no overflow
+    const long long first = (long long)row * chunk + ((long long)it * nwaves + wave) * 64ll;
+    *end = stop;
+    return first < (long long)stop ? (int)first : -1;
+}
+
 // Tile counting: same Gaussian -> workgroup assignment as k_scatter.  Re-reads the geometry half of the
 // GeomRecs written by k_project, expands every rect into (Gaussian, tile) pairs with the balanced walk,
 // bumps the workgroup-private LDS tile histogram, records the kept tiles of small rects as bit masks and
@@ -287,7 +309,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(1024)
 k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
-              unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull) {
+              unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull, int interleave) {
     GS2M_DYN_LDS(unsigned, lds);
     struct { int P; } g = {P};
     const int tid = (int)threadIdx.x;
@@ -302,10 +324,13 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     WaveStage* stage = reinterpret_cast<WaveStage*>(lds + ((NV * hw + 3) & ~3)) + wave;
     for (int i = tid; i < NV * hw; i += nthreads) lhist[i] = 0u;
     __syncthreads();
-    const int begin = (int)blockIdx.x * chunk;
-    const int end = gs2m_imin(P, begin + chunk);
-    for (int base = begin; base < end; base += nthreads) {
-        const int gi = base + tid;
+    // histogram row of this workgroup: the workgroups of an XCD own consecutive rows (see k_scatter)
+    const int row = (int)gs2m_xcd_contiguous(blockIdx.x, (unsigned)n_wg);
+    for (int it = 0;; ++it) {
+        int end;
+        const int first = bin_step_begin(it, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
+        if (first < 0) break;   // wave-uniform; the loop body only uses wave collectives
+        const int gi = first + lane;
         const bool valid = gi < end;
         struct {
             float mx, my, ca, cb, cc;
@@ -442,7 +467,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     __syncthreads();
     for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
-        hist[((size_t)v * n_wg + blockIdx.x) * tiles + t] = (lhist[v * hw + (t >> 1)] >> ((t & 1) << 4)) & 0xffffu;
+        hist[((size_t)v * n_wg + row) * tiles + t] = (lhist[v * hw + (t >> 1)] >> ((t & 1) << 4)) & 0xffffu;
     }
 }
 
@@ -463,27 +488,36 @@ GS2M_KERNEL void __launch_bounds__(1024)
 k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
           const unsigned* __restrict__ hist, const unsigned* __restrict__ tile_start,
           const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
-          int exact_cull) {
+          int exact_cull, const int* __restrict__ ids, int interleave) {
     GS2M_DYN_LDS(unsigned, cursor);
     const int tid = (int)threadIdx.x;
     const int nthreads = (int)blockDim.x;
     const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
+    // Chunk (= histogram row = position of this workgroup's segment inside every tile's key range).  The workgroups of
+    // one XCD own consecutive rows, so the segments an XCD writes into a tile are adjacent: its 8-B key stores fill
+    // whole lines in ITS L2 instead of leaving 1/8-written lines in eight L2s (4x write amplification, PMC WRITE_SIZE).
+    const int row = (int)gs2m_xcd_contiguous(blockIdx.x, (unsigned)n_wg);
     for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
-        cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + blockIdx.x) * tiles + t];
+        cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + row) * tiles + t];
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     ScatterStage* stage = reinterpret_cast<ScatterStage*>(cursor + ((NV * tiles + 3) & ~3)) + wave;
-    const int begin = (int)blockIdx.x * chunk;
-    const int end = gs2m_imin(P, begin + chunk);
-    for (int base = begin; base < end; base += nthreads) {
-        const int gi = base + tid;
+    // one view after the other: the key lines this XCD is filling at any time belong to ONE view's array (half the L2
+    // working set of a walk that alternates between the views)
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
+    for (int v = 0; v < NV; ++v) {
+        for (int it = 0;; ++it) {
+            int end;
+            const int first = bin_step_begin(it, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
+            if (first < 0) break;   // wave-uniform
+            const int gi = first + lane;
             unsigned rect0 = 0u, rect1 = 0u, dbits = 0u;
+            unsigned kid = (unsigned)gi;   // low word of the sort key: the Gaussian's id (ties in depth resolve as in the reference)
             if (gi < end) {
+                if (ids) kid = (unsigned)ids[gi];
                 const float4 w2 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi)[2];
                 rect0 = __float_as_uint(w2.z);
                 rect1 = __float_as_uint(w2.w);
@@ -518,7 +552,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                     stage->swh[k] = start | (w << 16) | (h << 24);
                     stage->xy0[k] = rect0;
                     stage->dbits[k] = dbits;
-                    stage->gid[k] = (unsigned)gi;
+                    stage->gid[k] = kid;
                     stage->mlo[k] = (unsigned)msk;
                     stage->mhi[k] = (unsigned)(msk >> 32);
                     atomicOr(&stage->heads[start >> 5], 1u << (start & 31u));
@@ -553,7 +587,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                 const int o = __ffsll(bigs) - 1;
                 bigs &= bigs - 1ull;
                 const unsigned ow = gs2m_shfl(w, o), oa = gs2m_shfl(area, o), oxy = gs2m_shfl(rect0, o);
-                const unsigned long long key = ((unsigned long long)gs2m_shfl(dbits, o) << 32) | (unsigned)gs2m_shfl(gi, o);
+                const unsigned long long key = ((unsigned long long)gs2m_shfl(dbits, o) << 32) | gs2m_shfl(kid, o);
                 float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
                 if (exact_cull) {
                     const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gs2m_shfl(gi, o));
@@ -588,17 +622,49 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
 // thread-per-Gaussian kernel reads as 12 float4 loads strided by 192 B (64 cache lines per wave
 // instruction, L1 thrash).  Packed: [P/64][12][64] float4 -- every load instruction of a wave is one
 // contiguous KiB.
+// `order` (null = identity): position gi of the packed copy holds Gaussian order[gi] (gs2m_raster_pack_model).
 GS2M_KERNEL void __launch_bounds__(256)
-k_pack_sh(int P, const float* __restrict__ shs, const float* __restrict__ shs_rest, float* __restrict__ packed) {
+k_pack_sh(int P, const float* __restrict__ shs, const float* __restrict__ shs_rest, float* __restrict__ packed,
+          const int* __restrict__ order) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one float of the [P,48] matrix
     if (i >= (size_t)P * 48) return;
     const size_t gi = i / 48;
     const int c = (int)(i - gi * 48);
+    const size_t src = order ? (size_t)order[gi] : gi;
     float v;
-    if (shs_rest == nullptr) v = shs[i];
-    else v = c < 3 ? shs[gi * 3 + c] : shs_rest[gi * 45 + (c - 3)];
+    if (shs_rest == nullptr) v = shs[src * 48 + c];
+    else v = c < 3 ? shs[src * 3 + c] : shs_rest[src * 45 + (c - 3)];
     const int k = c >> 2, e = c & 3;
     packed[(((gi >> 6) * 12 + k) * 64 + (gi & 63)) * 4 + e] = v;
+}
+
+// Spatially ordered packed copy of the per-Gaussian parameters (gs2m_raster_pack_model): position j <- Gaussian
+// order[j]; rank[order[j]] = j is the inverse the compositing stage uses to find a record from the id in a sort key.
+GS2M_KERNEL void __launch_bounds__(256)
+k_pack_model(int P, const int* __restrict__ order, const float* __restrict__ xyz, const float* __restrict__ scales,
+             const float* __restrict__ rots, const float* __restrict__ opac, float* __restrict__ p_xyz,
+             float* __restrict__ p_scales, float* __restrict__ p_rots, float* __restrict__ p_opac, int* __restrict__ rank) {
+    const int j = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (j >= P) return;
+    const int id = order[j];
+    if (id < 0 || id >= P) return;   // not a permutation: rank keeps a hole, k_check_rank reports it
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p_xyz[3 * (size_t)j + c] = xyz[3 * (size_t)id + c];
+        p_scales[3 * (size_t)j + c] = scales[3 * (size_t)id + c];
+    }
+    *reinterpret_cast<float4*>(p_rots + 4 * (size_t)j) = *reinterpret_cast<const float4*>(rots + 4 * (size_t)id);
+    p_opac[j] = opac[id];
+    rank[id] = j;
+}
+
+// order is a permutation of 0..P-1 <=> every rank entry was written exactly once (holes stay -1)
+GS2M_KERNEL void __launch_bounds__(256)
+k_check_rank(int P, const int* __restrict__ rank, const int* __restrict__ order, unsigned* __restrict__ bad) {
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= P) return;
+    const int j = rank[i];
+    if (j < 0 || j >= P || order[j] != i) atomicOr(bad, 1u);
 }
 
 // checkFrustum (rasterizer_impl.cu:54-66): present = z_view > 0.2

@@ -27,7 +27,7 @@ void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUnif
 
 int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
-                            int exact_cull) {
+                            int exact_cull, int interleave) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_count_tiles<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -40,16 +40,17 @@ int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hip
     }
     if (nv == 2)
         GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
-                    exact_cull);
+                    exact_cull, interleave);
     else
         GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
-                    exact_cull);
+                    exact_cull, interleave);
     return 0;
 }
 
 int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
-                        const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull) {
+                        const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
+                        const int* ids, int interleave) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_scatter<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -62,16 +63,24 @@ int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStre
     }
     if (nv == 2)
         GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
-                    tile_start, tilemask, keys, cap, exact_cull);
+                    tile_start, tilemask, keys, cap, exact_cull, ids, interleave);
     else
         GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
-                    tile_start, tilemask, keys, cap, exact_cull);
+                    tile_start, tilemask, keys, cap, exact_cull, ids, interleave);
     return 0;
 }
 
-void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed) {
+void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed, const int* order) {
     const size_t n = (size_t)P * 48;
-    GS2M_LAUNCH(k_pack_sh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, shs, shs_rest, packed);
+    GS2M_LAUNCH(k_pack_sh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, shs, shs_rest, packed, order);
+}
+
+void gs2m_launch_pack_model(hipStream_t st, int P, const int* order, const float* xyz, const float* scales, const float* rots,
+                            const float* opac, float* p_xyz, float* p_scales, float* p_rots, float* p_opac, int* rank,
+                            unsigned* bad) {
+    const unsigned n = (unsigned)((P + 255) / 256);
+    GS2M_LAUNCH(k_pack_model, dim3(n), dim3(256), 0, st, P, order, xyz, scales, rots, opac, p_xyz, p_scales, p_rots, p_opac, rank);
+    GS2M_LAUNCH(k_check_rank, dim3(n), dim3(256), 0, st, P, rank, order, bad);
 }
 
 void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const float* viewmatrix,

@@ -28,10 +28,11 @@ class RenderFusePipeline:
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None,
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0,
                  exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
-                 lib=None, fuse_batch: int = 1):
+                 lib=None, fuse_batch: int = 1, spatial_order: bool = True):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
+        self.spatial_order = bool(spatial_order)   # Morton-ordered packed copy of the model in every handle (same results)
         self.W, self.H = int(width), int(height)
         self.volume, self.intrinsic = volume, intrinsic
         self.inflight = int(inflight)
@@ -74,8 +75,14 @@ class RenderFusePipeline:
         """Sizes every handle's instance arena from one synchronous render of ``cams`` (grow + retry
         happens here, not in the pipelined loop) and packs the SH block once.  Returns the render."""
         first = None
+        order = None
         for j, r in enumerate(self.rasterizers):
-            r.pack_sh(self.g)      # the wave-transposed SH copy is cached per handle
+            # one-time re-layout, cached per handle: Morton-ordered packed copy of the model (+ wave-transposed SH);
+            # the order is computed once and shared by the handles
+            if self.spatial_order:
+                order = r.pack_model(self.g, order=order)
+            else:
+                r.pack_sh(self.g)
             res = r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j],
                                  want_radii=(j == 0))
             r.reserve(int(self.g["xyz"].shape[0]), 2, self.W, self.H, int(max(res["num_rendered"]) * headroom))

@@ -91,6 +91,30 @@ def camera_from(cam) -> _lib.Camera:
                        cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
 
 
+def morton_order(xyz, bits: int = 10):
+    """Permutation (int32, position -> Gaussian id) that sorts the Gaussians along the 3-D Morton curve of their centres
+    (``bits`` per axis over the bounding box; stable, so equal codes keep their id order).  One-time preparation on the
+    device with torch (numpy for the emulator tests); any spatially coherent order serves ``pack_model`` equally."""
+    if _is_torch(xyz):
+        lo = xyz.amin(dim=0)
+        span = (xyz.amax(dim=0) - lo).clamp_min(1e-20)
+        q = ((xyz - lo) / span * (2 ** bits - 1)).to(torch.int64).clamp_(0, 2 ** bits - 1)
+        code = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+        for b in range(bits):
+            for a in range(3):
+                code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        return torch.argsort(code, stable=True).to(torch.int32).contiguous()
+    x = np.asarray(xyz, np.float64)
+    lo = x.min(axis=0)
+    span = np.maximum(x.max(axis=0) - lo, 1e-20)
+    q = np.clip(((x - lo) / span * (2 ** bits - 1)).astype(np.int64), 0, 2 ** bits - 1)
+    code = np.zeros(x.shape[0], np.int64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return np.ascontiguousarray(np.argsort(code, kind="stable").astype(np.int32))
+
+
 class Rasterizer:
     """Owns one ``gs2m_raster`` handle (persistent arenas).  Not thread-safe; one stream at a time."""
 
@@ -210,6 +234,21 @@ class Rasterizer:
         these Gaussians in the handle; ``render_views`` with the same tensors then reads it."""
         g = self._gaussians_struct(gaussians)
         _lib.check(self._lib.gs2m_raster_pack_sh(self._h, C.byref(g), _stream_of(gaussians["xyz"], stream)), self._lib)
+
+    def pack_model(self, gaussians: dict, order=None, stream=None):
+        """One-time preparation (``gs2m_raster_pack_model``, a superset of ``pack_sh``): cache a SPATIALLY ORDERED packed
+        copy of these Gaussians in the handle.  ``order`` = int32 permutation (position -> Gaussian id) on the device;
+        default: the Morton order of ``xyz`` (``morton_order``).  ``render_views`` with the same tensors then works on
+        the copy; images, radii and taps are those of the unordered model."""
+        if order is None:
+            order = morton_order(gaussians["xyz"])
+        g = self._gaussians_struct(gaussians)
+        i32 = torch.int32 if _is_torch(order) else None
+        if not _is_torch(order):
+            order = np.ascontiguousarray(order, np.int32)
+        _lib.check(self._lib.gs2m_raster_pack_model(self._h, C.byref(g), _ptr(order, i32, "order"),
+                                                    _stream_of(gaussians["xyz"], stream)), self._lib)
+        return order
 
     def render_views(self, gaussians: dict, cams, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, want_color=True,
                      want_rgb8=False, want_radii=False, out_color=None, out_rgb8=None, stream=None, sync=True):

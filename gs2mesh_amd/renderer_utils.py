@@ -160,7 +160,9 @@ class Renderer:
         self._raster = Rasterizer(torch.device(dev).index or 0)
         self._raster.set_option(_lib.OPT_EXACT_TILE_CULL, 1)      # image-preserving; fewer instances to sort/blend
         self._raster.set_option(_lib.OPT_TILE_ROWS, 2)            # 16 x 32 binning tiles: same image, ~30 % fewer instances
-        self._raster.pack_sh(self.gaussians.raw())                # one-time SH re-layout for coalesced loads
+        # one-time re-layout: Morton-ordered packed copy of the splat (a trained splat is stored in densification order,
+        # i.e. spatially random) + wave-transposed SH; images / radii are those of the model as loaded
+        self._raster.pack_model(self.gaussians.raw())
         self._views = {}
 
     def _pair(self, camera_number):

@@ -184,6 +184,21 @@ int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* g, const gs2m_camera
  */
 int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* g, gs2m_stream stream);
 
+/*
+ * Superset of gs2m_raster_pack_sh (same stage, same matching rule, extended to xyz / scales / rotations /
+ * opacities): keeps a SPATIALLY ORDERED packed copy of the whole model inside the handle (+236 B per Gaussian).
+ * order[P] (device, int32) is a permutation: position j of the copy holds Gaussian order[j] -- e.g. the Morton
+ * order of xyz (gs2mesh_amd.rasterizer.morton_order).  A trained splat is stored in densification order
+ * (GS/scene/gaussian_model.py:372-409 appends clones and splits), i.e. spatially random: every workgroup of the
+ * counting sort then touches every tile.  In a spatially ordered copy consecutive Gaussians project to a few
+ * neighbouring tiles: the keys a workgroup scatters form long runs and the records a tile gathers lie close together.
+ * Results are those of the unordered model: the sort keys carry the Gaussian IDS (ties in depth resolve in id order,
+ * as the reference's stable sort does), out_radii and the parity taps are indexed by id.  Synchronises `stream` once
+ * (the permutation is verified); returns an error if `order` is not a permutation.
+ */
+int gs2m_raster_pack_model(gs2m_raster* r, const gs2m_gaussians* g, const int32_t* order /* device [P] */,
+                           gs2m_stream stream);
+
 /* Synchronises `stream` (pass the stream the handle is used on) and reports num_rendered[v] for
  * v < n_views of the LAST forward/render_views call on the handle (host array, may be NULL), and
  * whether the instance arena overflowed in ANY call since the previous status query

@@ -425,6 +425,64 @@ def test_packed_sh_layout_gives_identical_results(backend):
         np.testing.assert_array_equal(geom["rgb"], r2.download_geometry(1, 2537)["rgb"])
 
 
+@pytest.mark.parametrize("rows", [1, 2])
+def test_spatially_ordered_packed_model_gives_identical_results(backend, rows):
+    """gs2m_raster_pack_model (Morton-ordered packed copy of the model) must not change a bit: image, radii, the
+    per-Gaussian taps and the instance lists are those of the unordered model -- including the order of Gaussians at
+    EXACTLY equal depth (duplicated centres with different colours: the keys carry ids, so ties resolve in id order
+    as the reference's stable sort does).  Also checks that a non-permutation is refused."""
+    from gs2mesh_amd.rasterizer import morton_order
+    W, H, f = 176, 136, 160.0
+    P = 3000 + 21
+    g, s, q, o, shs, left, right = scene(P, 29, W, H, f)
+    rng = np.random.default_rng(5)
+    # exact depth ties: 300 Gaussians share the centre of another one (different shape / colour / opacity)
+    src = rng.choice(P, 300, replace=False)
+    dst = rng.choice(P, 300, replace=False)
+    g["xyz"][dst] = g["xyz"][src]
+    be = backend
+    cams = [camera_from(left), camera_from(right)]
+    gd = dict(xyz=be.dev(g["xyz"]), scaling=be.dev(g["scaling"]), rotation=be.dev(g["rotation"]),
+              opacity=be.dev(g["opacity"]), features_dc=be.dev(g["features_dc"]), features_rest=be.dev(g["features_rest"]),
+              raw=True, sh_degree=3)
+    tiles = ((W + 15) // 16) * (((H + 15) // 16 + rows - 1) // rows)
+    outs = []
+    for packed in (False, True):
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+        r.set_option(_lib.OPT_TILE_ROWS, rows)
+        if packed:
+            order = r.pack_model(gd)
+            assert sorted(np.asarray(be.host(order)).tolist()) == list(range(P))
+            assert not np.array_equal(np.asarray(be.host(order)), np.arange(P))
+        res = r.render_views(gd, cams, want_radii=True, want_rgb8=True)
+        geom = r.download_geometry(1, P)
+        lists = [r.download_binning(v, res["num_rendered"][v], tiles) for v in range(2)]
+        outs.append((be.host(res["color"]).copy(), be.host(res["rgb8"]).copy(), be.host(res["radii"]).copy(), geom, lists,
+                     list(res["num_rendered"])))
+    a, b = outs
+    assert a[5] == b[5] and min(a[5]) > 3000
+    np.testing.assert_array_equal(a[2], b[2])
+    for k in a[3]:
+        np.testing.assert_array_equal(a[3][k], b[3][k], err_msg=k)
+    for v in range(2):
+        np.testing.assert_array_equal(a[4][v][0], b[4][v][0])   # point lists (ids), ties included
+        np.testing.assert_array_equal(a[4][v][1], b[4][v][1])
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    # ties really occur inside the lists
+    geom = a[3]
+    pl = a[4][1][0]
+    d = geom["depths"][pl]
+    assert (d[1:] == d[:-1]).sum() > 20
+    # a non-permutation is refused
+    bad = np.arange(P, dtype=np.int32)
+    bad[7] = 8
+    r = Rasterizer(0, lib=be.lib)
+    with pytest.raises(RuntimeError, match="permutation"):
+        r.pack_model(gd, order=be.dev(bad))
+
+
 def test_hip_path_against_reference_golden(backend):
     """The HIP rasteriser against outputs of the REFERENCE'S OWN KERNELS (tests/golden/ref_forward.npz, produced by
     oracle/_ref = forward.cu / rasterizer_impl.cu kernels compiled for the CPU, tests/golden/make_golden.py):

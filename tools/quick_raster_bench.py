@@ -18,14 +18,15 @@ ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--cull", type=int, default=0)
 ap.add_argument("--blend", type=int, default=4)
 ap.add_argument("--rows", type=int, default=1)
-ap.add_argument("--morton", type=int, default=0)
+ap.add_argument("--morton", type=int, default=0, help="cells per axis of the Morton pre-sort (0 = original order); order inside a cell stays the original (random) one")
 ap.add_argument("--stages", type=int, default=1)
 ap.add_argument("--pack", type=int, default=1)
 a = ap.parse_args()
 cfg = synthetic.CONFIGS[a.config]
 g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
 if a.morton:
-    q = np.clip(((g["xyz"] + 1.0) * 0.5 * 1023).astype(np.int64), 0, 1023)
+    cells = 1024 if a.morton == 1 else a.morton
+    q = np.clip(((g["xyz"] + 1.0) * 0.5 * cells).astype(np.int64), 0, cells - 1)
     def spread(x):
         x = (x | (x << 16)) & 0x030000FF
         x = (x | (x << 8)) & 0x0300F00F
@@ -46,7 +47,9 @@ R = Rasterizer(0)
 R.set_option(_lib.OPT_EXACT_TILE_CULL, a.cull)
 R.set_option(_lib.OPT_BLEND_VARIANT, a.blend)
 R.set_option(_lib.OPT_TILE_ROWS, a.rows)
-if a.pack:
+if a.pack == 2:
+    R.pack_model(gd)
+elif a.pack:
     R.pack_sh(gd)
 out = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
 res = R.render_views(gd, cams[0], out_color=out)
