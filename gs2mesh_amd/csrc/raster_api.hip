@@ -160,7 +160,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
     switch (option) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
         case GS2M_OPT_BLEND_VARIANT:
-            if (value != 0 && value != 4 && value != 7 && !(value >= 40 && value < 60)) {  // 40..59: development A/B variants
+            if (value != 0 && value != 4 && value != 7) {
                 gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0, 4 or 7");
                 return 1;
             }

@@ -127,15 +127,22 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
 // miss the half are dropped while staging, by ballot compaction).  A quadrant outside the instance's 16 x 16 tile rect is
 // masked, so the reference's rect still bounds every contribution: the image is the 16 x 16 image bit for bit.
 // Measured ladder (C2, us per pair): r1 all-VALU kernel 250 -> lane masks + flagged general path 245 -> 7 waves/SIMD 235
-// -> DMA prefetch (this file).  The kernel is bound by VALU issue (one wave64 op per 4 cycles per SIMD in practice:
-// 136 M ops -> 221 us); PMC in profiles/r2*.
+// -> DMA prefetch (this file).  PMC (profiles/r2b_pmc.json): 138 M VALU + 85 M SALU + 36 M branch instructions per
+// launch, 41 % of the wave cycles issuing / 27 % issue stalls / 32 % waits.  tools/ubench/valu_rates.hip prices the VALU
+// mix at 7 waves per SIMD: plain fp32 op 2.4 cycles per wave64 instruction per SIMD, v_exp_f32 8.1, v_cmp + v_cndmask
+// through a lane mask ~4 each, v_pk_fma_f32 7 (no gain over two v_fma) -> the mix of this loop costs >= 166 us at
+// 2.4 GHz; the kernel runs at ~0.7 of that bound, the rest is the scalar / branch traffic of the skips.
+// Rejected after A/B on the GPU (same image, slower): exponents + compares of all four quadrants hoisted in front of
+// the branches (+17 %: 2.8 more VALU ops per instance), accepted lanes by execution mask instead of v_cndmask (+3 %:
+// one VALU op less, two scalar ops and a branch more), column terms only for the columns an instance reaches (+6 %),
+// 1 / 2 / 8 waves per workgroup (+-1 %), packed-f32 SLP (+18 %).
 // ---------------------------------------------------------------------------------------------
 struct BlendInst {
     float4 a, b;
     float2 c;
 };
 
-template <int WPB, int LROWS, int OCC, int STEP = 0>
+template <int WPB, int LROWS, int OCC>
 GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
@@ -322,53 +329,6 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 }
             }
         };
-        // STEP 1: the exponents and threshold compares of all four quadrants are formed up front (one block of
-        // independent VALU work, the lane masks are in scalar registers before the first branch needs them); one branch
-        // skips an instance no pixel of the tile sees, one per quadrant guards its accumulate path.
-        auto step_h = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
-            const int qm = qmf & (int)lq;
-            if (qm != 0) {
-                const float dx0 = A.x - pxf0, dx1 = A.x - pxf1, dy0 = A.y - pyf0, dy1 = A.y - pyf1;
-                const float e0 = fmaf(A.z * dx0, dx0, B.y), e1 = fmaf(A.z * dx1, dx1, B.y);
-                const float n0 = -(A.w * dx0), n1 = -(A.w * dx1);
-                float qv[4];
-                qv[0] = fmaf(fmaf(B.x, dy0, n0), dy0, e0);
-                qv[1] = fmaf(fmaf(B.x, dy0, n1), dy0, e1);
-                qv[2] = fmaf(fmaf(B.x, dy1, n0), dy1, e0);
-                qv[3] = fmaf(fmaf(B.x, dy1, n1), dy1, e1);
-                unsigned long long prem[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    prem[k] = (qm & (1 << k)) ? (gs2m_ballot_b(qv[k] >= QMIN) & ~dn[k]) : 0ull;
-                if ((prem[0] | prem[1] | prem[2] | prem[3]) != 0ull) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (prem[k] != 0ull) {
-                            float alpha = gs2m_fast_exp2(qv[k]);
-                            unsigned long long candm = prem[k];
-                            if (qmf & 0x100) {
-                                GS2M_NO_IF_CONVERT();
-                                candm = prem[k] & ~gs2m_ballot_b(qv[k] > B.y);
-                                alpha = fminf(0.99f, alpha);
-                            }
-                            const float test_T = fmaf(-T[k], alpha, T[k]);
-                            const unsigned long long satm = gs2m_ballot_b(test_T < 0.0001f) & candm;
-                            const float Tn = gs2m_lanes(candm & ~satm) ? test_T : T[k];
-                            const float wT = T[k] - Tn;
-                            C0[k] = fmaf(B.z, wT, C0[k]);
-                            C1[k] = fmaf(B.w, wT, C1[k]);
-                            C2[k] = fmaf(CL.x, wT, C2[k]);
-                            T[k] = Tn;
-                            dn[k] |= satm;
-                        }
-                    }
-                }
-            }
-        };
-        auto step_any = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
-            if (STEP == 1) step_h(qmf, CL, A, B);
-            else step(qmf, CL, A, B);
-        };
         // The quadrant mask is read (= the LDS wait) BEFORE the next instance's reads are issued, so the
         // wait never covers a read that was just issued (the compiler's waitcnt is lgkmcnt(0) in this loop).
         const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
@@ -383,16 +343,16 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             B1 = spb[j + 1];
             K1 = spc[j + 1];
             GS2M_SCHED_BARRIER();
-            step_any(qm0, K0, A0, B0);
+            step(qm0, K0, A0, B0);
             const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
             GS2M_SCHED_BARRIER();
             A0 = spa[j + 2];
             B0 = spb[j + 2];
             K0 = spc[j + 2];
             GS2M_SCHED_BARRIER();
-            step_any(qm1, K1, A1, B1);
+            step(qm1, K1, A1, B1);
         }
-        if (j < nb) step_any(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
+        if (j < nb) step(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
     }
     gs2m_wait_dma();   // never leave with a DMA write to this workgroup's LDS in flight
     const size_t plane = (size_t)H * W;

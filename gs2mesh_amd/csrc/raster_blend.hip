@@ -23,20 +23,6 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
         else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
         return 0;
     }
-    // development variants (A/B on the GPU box; not part of the documented option values)
-#define GS2M_BLEND_DEV(V, WPB, OCC, STEP)                                                                                              \
-    if (variant == V) {                                                                                                                \
-        const dim3 g2((tiles + WPB - 1) / WPB, nv), b2(64 * WPB);                                                                      \
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<WPB, 2, OCC, STEP>), g2, b2, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank); \
-        else GS2M_LAUNCH((k_blend_wave4e<WPB, 1, OCC, STEP>), g2, b2, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank); \
-        return 0;                                                                                                                      \
-    }
-    GS2M_BLEND_DEV(41, 4, 7, 1)
-    GS2M_BLEND_DEV(42, 2, 7, 0)
-    GS2M_BLEND_DEV(43, 1, 7, 0)
-    GS2M_BLEND_DEV(44, 2, 7, 1)
-    GS2M_BLEND_DEV(45, 4, 6, 1)
-    GS2M_BLEND_DEV(46, 8, 7, 0)
     if (variant == 0 && tile_rows == 1) {
         GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
         return 0;
