@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--reduce", default="reduce_scatter", choices=["allreduce", "reduce_scatter"])
     ap.add_argument("--tile-rows", type=int, default=int(os.environ.get("GS2M_BENCH_TILE_ROWS", "2")), choices=[1, 2],
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "4")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "6")),
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
     ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "32")),
                     help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way)")
@@ -306,7 +306,7 @@ def main():
             ent = tr.get(args.config, {}).get(dom)
             if ent and ent.get("cull") == args.cull and ent.get("blend_variant", 4) == args.blend:
                 traffic = ent["hbm_bytes_per_launch"]
-                traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 1')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 2')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                   f"passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')}; "
                                   "committed profile, not measured in this run")
                 if ent.get("valu_insts_per_launch"):
@@ -315,8 +315,18 @@ def main():
                     rate = ent["valu_insts_per_launch"] / (stages[dom]["avg_us"] * 1e-6)
                     valu = dict(insts_per_launch=ent["valu_insts_per_launch"], achieved_Ginst_s=round(rate / 1e9, 1),
                                 peak_Ginst_s=1228.8, frac=round(rate / 1228.8e9, 4),
-                                measured_scalar_fma_ceiling_Ginst_s=805.0,
-                                note="MI355X_MICROARCH.md: scalar v_fma_f32 measured 103 TF = 805 G wave64 inst/s")
+                                measured_plain_fp32_Ginst_s=1010.0,
+                                note="tools/ubench/valu_rates.hip on this chip, 7 waves/SIMD: plain fp32 VALU op 2.4 cycles per "
+                                     "wave64 instruction per SIMD (1010 G inst/s), v_exp_f32 8.1, v_cmp / v_cndmask through a lane "
+                                     "mask ~4, v_pk_fma_f32 7.0")
+                    if ent.get("valu_trans_per_launch"):
+                        # lower bound of the VALU issue time of this instruction mix: transcendental ops at 8.1 cycles,
+                        # everything else priced as a plain op (the lane-mask compares / selects cost more)
+                        tr_n = ent["valu_trans_per_launch"]
+                        cyc = 8.1 * tr_n + 2.4 * (ent["valu_insts_per_launch"] - tr_n)
+                        valu["trans_insts_per_launch"] = tr_n
+                        valu["issue_bound_us_at_2p4GHz"] = round(cyc / 1024 / 2.4e3, 1)
+                        valu["frac_of_issue_bound"] = round(valu["issue_bound_us_at_2p4GHz"] / stages[dom]["avg_us"], 3)
         except Exception:
             traffic = None
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",

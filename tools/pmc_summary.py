@@ -36,6 +36,8 @@ for k, cs in summary.items():
         traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                               fetch_kib=cs["FETCH_SIZE"], write_kib=cs["WRITE_SIZE"],
                               valu_insts_per_launch=int(cs["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in cs else None,
+                              valu_trans_per_launch=int(cs["SQ_INSTS_VALU_TRANS_F32"]) if "SQ_INSTS_VALU_TRANS_F32" in cs else None,
+                              date=f"round {tag[1]}" if tag[:1] == "r" and tag[1:2].isdigit() else tag,
                               cull=bench.get("config", {}).get("exact_tile_cull", 1), source=f"profiles/{tag}_pmc.json")
 tp = os.path.join(dst, "pmc_traffic.json")
 allt = json.load(open(tp)) if os.path.exists(tp) else {}

@@ -16,5 +16,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 16 > /dev/null 2> $OUT/pmc_$c.err
 done
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_SQ -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 16 > /dev/null 2> $OUT/pmc_SQ.err
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_SQ2 -- python $R/bench.py --no-cpu-baseline --inflight 1 --steps 16 > /dev/null 2> $OUT/pmc_SQ2.err
 find $OUT -name "*.csv" | head -20
 tail -c 400 $OUT/bench.json
