@@ -76,7 +76,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     R.set_option(_lib.OPT_EXACT_TILE_CULL, int(args.cull))
     R.set_option(_lib.OPT_TILE_ROWS, int(args.tile_rows))
     R.set_option(_lib.OPT_BLEND_VARIANT, int(args.blend))
-    if args.spatial_order:
+    if args.spatial_order > 0 or (args.spatial_order < 0 and cfg.P >= 1_000_000):
         R.pack_model(gd)
     else:
         R.pack_sh(gd)
@@ -132,8 +132,9 @@ def main():
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
     ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "32")),
                     help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way)")
-    ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "1")),
-                    help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same results); 0 = SH packing only")
+    ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
+                    help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
+                         "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
     ap.add_argument("--min-repeats", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -189,7 +190,8 @@ def main():
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
                               exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows,
-                              fuse_batch=args.fuse_batch, spatial_order=bool(args.spatial_order))
+                              fuse_batch=args.fuse_batch, spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)))
+    spatial_order_used = int(pipe.spatial_order)
     R = pipe.rasterizers[0]
     color, rgb8 = pipe.color[0], pipe.rgb8[0]
 
@@ -448,7 +450,7 @@ def main():
             config=dict(workload=f"{args.config}: {cfg.P} synth_v1 Gaussians (SH deg 3), {K} stereo pairs/GPU at "
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
-                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=int(args.spatial_order), pairs_in_flight=args.inflight,
+                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight,
                         tsdf_fuse_batch=args.fuse_batch,
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
             timing=dict(repeats=len(dts), timed_region_s=round(sum(dts), 4), statistic="median over repeats of the K-step job",

@@ -65,6 +65,7 @@ struct gs2m_raster {
     size_t pk_cap3 = 0, pk_cap3s = 0, pk_cap4 = 0, pk_cap1 = 0, order_cap = 0, rank_cap = 0;
     const float* model_src[4] = {nullptr, nullptr, nullptr, nullptr};  // xyz, scales, rotations, opacities packed from
     bool model_packed = false;
+    bool hint_valid = false;         // h_status holds the class counts of an earlier pass of the same geometry
     bool last_packed = false;        // the last pass ran on the packed copy (parity taps map positions back to ids)
     const int* run_rank = nullptr;   // rank table of the pass being launched (null: keys carry record positions)
     size_t mask_cap = 0;
@@ -335,7 +336,20 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "scatter")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SORT);
-        gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists);
+        // class-grid hint: what the previous call on this handle (same image size and binning) found, as far as its status
+        // copy has landed in the pinned mirror; -1 = no information (first call, other geometry)
+        int hint[3] = {-1, -1, -1};
+        if (r->hint_valid && r->last_tiles == tiles && r->last_nv == nv) {
+            for (int c = 0; c < 3; ++c) {
+                unsigned m = 0;
+                for (int v = 0; v < nv; ++v) {
+                    const unsigned x = r->h_status[1 + status_slot + v].n_class[c];
+                    m = x > m ? x : m;
+                }
+                hint[c] = m > 0x3fffffffu ? -1 : (int)m;
+            }
+        }
+        gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists, hint);
     }
     if (dbg_check(r, st, "sort_tiles")) return 1;
     {
@@ -346,6 +360,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;
+    r->hint_valid = true;
     r->last_packed = g.ids != nullptr;
     r->last_nv = nv;
     r->last_tiles = tiles;

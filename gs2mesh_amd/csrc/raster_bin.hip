@@ -11,12 +11,25 @@ void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, u
 }
 size_t gs2m_sort_lists_words(int nv, int tiles) { return (size_t)nv * GS2M_SORT_CLASSES * (tiles + 1); }
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
-                            const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists) {
+                            const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint) {
     // <= 512 instances: one wave per tile; larger lists are walked from the work lists k_tile_scan wrote, by grids
-    // sized for residency (4 / 2 / 2 workgroups per CU by their LDS), not one mostly idle workgroup per tile
+    // sized for residency (4 / 2 / 2 workgroups per CU by their LDS), not one mostly idle workgroup per tile.
+    // class_hint (may be null) = lists per size class the PREVIOUS call on this handle found (read back with its status,
+    // possibly stale): the class kernels walk their lists grid-stride, so any grid >= 1 is correct -- the hint only keeps a
+    // class that is (almost) empty from launching hundreds of workgroups of 40-80 KiB LDS that wait for CU space just to
+    // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
     GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap);
-    const int g0 = tiles < 1024 ? tiles : 1024, g1 = tiles < 512 ? tiles : 512;
-    GS2M_LAUNCH((k_sort_tiles_bucket<4096, 256, 0>), dim3(g0, nv), dim3(256), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    GS2M_LAUNCH((k_sort_tiles_bucket<8192, 512, 1>), dim3(g1, nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    GS2M_LAUNCH(k_sort_tiles, dim3(g1, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
+    const int full[3] = {tiles < 1024 ? tiles : 1024, tiles < 512 ? tiles : 512, tiles < 512 ? tiles : 512};
+    int g[3];
+    for (int c = 0; c < 3; ++c) {
+        g[c] = full[c];
+        if (class_hint && class_hint[c] >= 0) {
+            const int want = class_hint[c] + class_hint[c] / 2 + 16;  // 1.5 x the last count + a floor of 16 workgroups
+            g[c] = want < full[c] ? want : full[c];
+        }
+        if (g[c] < 1) g[c] = 1;
+    }
+    GS2M_LAUNCH((k_sort_tiles_bucket<4096, 256, 0>), dim3(g[0], nv), dim3(256), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH((k_sort_tiles_bucket<8192, 512, 1>), dim3(g[1], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH(k_sort_tiles, dim3(g[2], nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
 }

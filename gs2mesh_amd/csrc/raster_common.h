@@ -64,4 +64,6 @@ GS2M_DEVICE unsigned gs2m_xcd_contiguous(unsigned bid, unsigned nwg) {
 struct ViewStatus {
     unsigned num_rendered;  // instances this view produced
     unsigned overflow;      // 1 if num_rendered > arena capacity (results invalid)
+    unsigned n_class[3];    // lists of the view in the three size classes of the per-tile sort (> 512, > 4096, > 8192 instances)
+    unsigned pad;
 };

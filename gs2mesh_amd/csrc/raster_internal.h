@@ -35,7 +35,7 @@ void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, u
                            ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists);
 size_t gs2m_sort_lists_words(int nv, int tiles);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
-                            const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists);
+                            const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint);
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
                       unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank);

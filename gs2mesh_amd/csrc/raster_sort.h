@@ -106,7 +106,10 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
         start[i] = run;
         run += cnt[i];
     }
-    if (tid < GS2M_SORT_CLASSES) lists[tid * (tiles + 1)] = n_class[tid];   // complete: every thread passed the scan's barriers
+    if (tid < GS2M_SORT_CLASSES) {   // complete: every thread passed the scan's barriers
+        lists[tid * (tiles + 1)] = n_class[tid];
+        status[v].n_class[tid] = n_class[tid];   // read back with the status: sizes the next call's class grids (a hint)
+    }
     if (tid == 1023) {
         const unsigned total = part[1023];
         start[tiles] = total;
