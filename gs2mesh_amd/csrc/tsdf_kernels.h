@@ -416,16 +416,21 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                 c2[j] = bc[2 * GS2M_TSDF_VOX + vi0 + 16 * j];
             }
         }
-        unsigned long long todo = fm;
-        while (todo != 0ull) {
-            const int fi = __ffsll(todo) - 1;   // frames in ascending order
-            todo &= todo - 1ull;
+        // Software pipeline over the frames of the block: the projection of frame n + 1 and its depth gathers are issued
+        // before frame n is applied, so a wave always has the next frame's memory round trip in flight (the kernel is bound
+        // by gather latency: 63 % of the wave cycles wait at 4 waves per SIMD, PMC).  Frames are still APPLIED in ascending
+        // order with the same arithmetic: bit-identical to the frame-by-frame path.
+        struct Probe {
+            int fi;
+            int pix[4], uu[4], vv[4];
+            float zc[4], d[4];
+        };
+        auto probe = [&](const int fi, Probe& P) __attribute__((always_inline)) {
             const TsdfBatchFrame& bf = frames[fi];
             const TsdfFrame& f = bf.f;
             const float* __restrict__ depth = bf.depth;
-            const unsigned char* __restrict__ color = bf.color;
             const unsigned char* __restrict__ mask = bf.mask;
-            const int last_pix = f.W * f.H - 1;
+            P.fi = fi;
             // UniformTSDFVolume::IntegrateWithDepthToCameraDistanceMultiplier: camera-space centre of voxel (x, y, 0) ...
             float pc0 = f.E[0] * p0 + f.E[1] * p1 + f.E[2] * p2 + f.E[3] * 1.f;
             float pc1 = f.E[4] * p0 + f.E[5] * p1 + f.E[6] * p2 + f.E[7] * 1.f;
@@ -436,20 +441,18 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                 pc1 += f.Es12;
                 pc2 += f.Es22;
             }
-            int pix[4], uu[4], vv[4];
-            float zc[4], d[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                pix[j] = -1;
-                uu[j] = vv[j] = 0;
-                zc[j] = pc2;
+                P.pix[j] = -1;
+                P.uu[j] = P.vv[j] = 0;
+                P.zc[j] = pc2;
                 if (!(pc2 <= 0)) {
                     const float u_f = pc0 * f.fx_f / pc2 + f.cx_f + 0.5f;
                     const float v_f = pc1 * f.fy_f / pc2 + f.cy_f + 0.5f;
                     if (u_f >= 0.0001f && u_f < f.safe_w && v_f >= 0.0001f && v_f < f.safe_h) {
-                        uu[j] = (int)u_f;
-                        vv[j] = (int)v_f;
-                        pix[j] = vv[j] * f.W + uu[j];
+                        P.uu[j] = (int)u_f;
+                        P.vv[j] = (int)v_f;
+                        P.pix[j] = P.vv[j] * f.W + P.uu[j];
                     }
                 }
                 pc0 += f.Es02;
@@ -457,17 +460,20 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                 pc2 += f.Es22;
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {   // depth gathers, back to back
-                d[j] = 0.0f;
-                if (pix[j] >= 0) {
-                    float dd = depth[pix[j]];
-                    if (f.use_mask && mask[pix[j]] == 0) dd = dd * 0.0f;
-                    if (f.use_min && dd < f.min_depth_f) dd = 0.0f;
-                    if (f.depth_scale_f != 1.0f) dd /= f.depth_scale_f;
-                    if (dd >= f.depth_trunc_up_f) dd = 0.0f;
-                    d[j] = dd;
+            for (int j = 0; j < 4; ++j) {   // depth gathers, back to back (consumed by apply() one frame later)
+                P.d[j] = 0.0f;
+                if (P.pix[j] >= 0) {
+                    float dd = depth[P.pix[j]];
+                    if (f.use_mask && mask[P.pix[j]] == 0) dd = dd * 0.0f;
+                    P.d[j] = dd;
                 }
             }
+        };
+        auto apply = [&](Probe& P) __attribute__((always_inline)) {
+            const TsdfBatchFrame& bf = frames[P.fi];
+            const TsdfFrame& f = bf.f;
+            const unsigned char* __restrict__ color = bf.color;
+            const int last_pix = f.W * f.H - 1;
             unsigned rgbp[4];
             bool upd[4];
             float tnew[4];
@@ -476,19 +482,25 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                 upd[j] = false;
                 tnew[j] = 0.0f;
                 rgbp[j] = 0u;
-                if (pix[j] >= 0 && d[j] > 0.0f) {
+                float dd = P.d[j];
+                if (P.pix[j] >= 0) {
+                    if (f.use_min && dd < f.min_depth_f) dd = 0.0f;
+                    if (f.depth_scale_f != 1.0f) dd /= f.depth_scale_f;
+                    if (dd >= f.depth_trunc_up_f) dd = 0.0f;
+                }
+                if (P.pix[j] >= 0 && dd > 0.0f) {
                     // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated on the fly and only here
-                    const float xx = (uu[j] - f.cx_f) * f.fx_inv_f;
-                    const float yy = (vv[j] - f.cy_f) * f.fy_inv_f;
+                    const float xx = (P.uu[j] - f.cx_f) * f.fx_inv_f;
+                    const float yy = (P.vv[j] - f.cy_f) * f.fy_inv_f;
                     const float mult = sqrtf(xx * xx + yy * yy + 1.0f);
-                    const float sdf = (d[j] - zc[j]) * mult;
+                    const float sdf = (dd - P.zc[j]) * mult;
                     if (sdf > -f.sdf_trunc_f) {
                         upd[j] = true;
                         tnew[j] = fminf(1.0f, sdf * f.sdf_trunc_inv_f);
                         if (V.has_color) {
-                            const unsigned char* c = color + 3 * (size_t)pix[j];
-                            rgbp[j] = pix[j] < last_pix ? gs2m_load_u32_unaligned(c)
-                                                        : ((unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16));
+                            const unsigned char* c = color + 3 * (size_t)P.pix[j];
+                            rgbp[j] = P.pix[j] < last_pix ? gs2m_load_u32_unaligned(c)
+                                                          : ((unsigned)c[0] | ((unsigned)c[1] << 8) | ((unsigned)c[2] << 16));
                         }
                     }
                 }
@@ -503,6 +515,26 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                     w[j] = w[j] + 1.0f;
                 }
             }
+        };
+        unsigned long long todo = fm;
+        Probe A, B;
+        if (todo != 0ull) {
+            probe(__ffsll(todo) - 1, A);   // frames in ascending order
+            todo &= todo - 1ull;
+            while (todo != 0ull) {
+                probe(__ffsll(todo) - 1, B);
+                todo &= todo - 1ull;
+                apply(A);
+                if (todo == 0ull) {
+                    A = B;
+                    break;
+                }
+                probe(__ffsll(todo) - 1, A);
+                todo &= todo - 1ull;
+                apply(B);
+                if (todo == 0ull) break;
+            }
+            apply(A);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
