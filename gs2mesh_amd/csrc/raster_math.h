@@ -105,8 +105,11 @@ GS2M_DEVICE void cov2d_ewa(const float* vm, float tx_in, float ty_in, float tz, 
 // sh[k*3 + c]; returns max(0, SH + 0.5).  dir must already be normalised.
 #define GS2M_SH_C0 0.28209479177387814f
 #define GS2M_SH_C1 0.4886025119029199f
+// STRIDE = distance between the coefficients of one channel: 3 for a [16][3] row (sh[3 k + c]), 1 for the 16
+// coefficients of channel c gathered into an array (c = 0).  Same expression, same order, either way.
+template <int STRIDE = 3>
 GS2M_DEVICE float sh_channel(int deg, const float* sh, int c, float x, float y, float z) {
-#define SHK(k) sh[3 * (k) + c]
+#define SHK(k) sh[STRIDE * (k) + c]
     float result = GS2M_SH_C0 * SHK(0);
     if (deg > 0) {
         result = result - GS2M_SH_C1 * y * SHK(1) + GS2M_SH_C1 * z * SHK(2) - GS2M_SH_C1 * x * SHK(3);

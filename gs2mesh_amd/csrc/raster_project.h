@@ -114,14 +114,28 @@ GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
 
 // Projection + colour, one thread per Gaussian -- a streaming kernel (no LDS, no loop): activations, Sigma once
 // for all views of the batch, EWA projection, SH colour, the (cull-tightened) tile rect -> GeomRec.
-template <int NV>
-GS2M_KERNEL void __launch_bounds__(256)
+#define GS2M_PROJECT_THREADS 256
+template <int NV, bool DMA_SH>
+GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
 k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
           int exact_cull) {
     const int ncoef = (g.D + 1) * (g.D + 1);
+    // Packed SH copy: the 192-B row of every Gaussian of the wave goes straight from HBM into LDS (global_load_lds, 12 x 1 KiB
+    // per wave), issued BEFORE the parameter loads and the projection: one memory round trip per thread instead of two in
+    // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.
+    // The colour pass then reads the 16 coefficients of one channel at a time back from LDS.
+    __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
+    constexpr bool dma_sh = DMA_SH;   // the launcher picks it (gs2m_launch_project): packed, spatially ordered model
     {
-        const int gi = (int)(blockIdx.x * 256u + threadIdx.x);
+        const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
         const bool valid = gi < g.P;
+        const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
+        if (dma_sh && valid) {
+            const float4* s4 = reinterpret_cast<const float4*>(g.shs_packed) + (size_t)(gi >> 6) * (12 * 64) + (gi & 63);
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (k * 4 < ncoef * 3) gs2m_global_load_lds16(s4 + k * 64, &s_sh[wave_id][k][0]);
+        }
         ProjView pv[NV];
         float op = 0.0f, thr = 0.0f;
 #pragma unroll
@@ -162,7 +176,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                 any = any || pv[v].ok;
             }
             float sh[48];
-            const bool need_sh = any && (g.colors_precomp == nullptr);
+            const bool need_sh = any && (g.colors_precomp == nullptr) && !dma_sh;
             if (need_sh) {
                 if (g.shs_packed) {
                     // wave-transposed copy (k_pack_sh): float4 k of 64 consecutive Gaussians is 1 KiB contiguous
@@ -207,6 +221,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                 }
             }
             if (exact_cull) thr = cull_threshold(op);
+            if (dma_sh) gs2m_wait_dma();   // this lane's row has landed (a lane only reads its own column: no barrier)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 GeomRec* rec = recs + (size_t)v * g.P + gi;
@@ -233,9 +248,28 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                     dx = dx / len;
                     dy = dy / len;
                     dz = dz / len;
-                    cr = sh_channel(g.D, sh, 0, dx, dy, dz);
-                    cg = sh_channel(g.D, sh, 1, dx, dy, dz);
-                    cb = sh_channel(g.D, sh, 2, dx, dy, dz);
+                    if (dma_sh) {
+                        // element e = 3 k + c of the row sits in float4 e / 4, component e % 4 of this lane's column
+                        const float* row = reinterpret_cast<const float*>(&s_sh[wave_id][0][lane_id]);
+                        float col[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float coef[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                const int e = 3 * k + c;
+                                coef[k] = k < ncoef ? row[(e >> 2) * (64 * 4) + (e & 3)] : 0.0f;
+                            }
+                            col[c] = sh_channel<1>(g.D, coef, 0, dx, dy, dz);
+                        }
+                        cr = col[0];
+                        cg = col[1];
+                        cb = col[2];
+                    } else {
+                        cr = sh_channel(g.D, sh, 0, dx, dy, dz);
+                        cg = sh_channel(g.D, sh, 1, dx, dy, dz);
+                        cb = sh_channel(g.D, sh, 2, dx, dy, dz);
+                    }
                 }
                 // GS2M_OPT_EXACT_TILE_CULL (image-preserving extension): shrink the reference's AABB-of-
                 // the-3-sigma-circle rect to the bounding box of the alpha >= 1/255 ellipse,
