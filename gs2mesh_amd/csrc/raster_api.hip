@@ -34,6 +34,7 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
         }                                                                                     \
     } while (0)
 
+#define GS2M_SORT_CLASSES_API 3   // = GS2M_SORT_CLASSES (raster_sort.h)
 #define GS2M_MAX_STATUS 64  // views per gs2m_render_views call whose status is kept
 
 struct gs2m_raster {
@@ -355,7 +356,8 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     {
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
         if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
-                              g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr))
+                              g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
+                              r->d_sort_lists + (size_t)nv * GS2M_SORT_CLASSES_API * (tiles + 1)))
             return 1;
     }
     if (dbg_check(r, st, "blend")) return 1;

@@ -9,7 +9,7 @@ void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, u
                            ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {
     GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, status, sticky, cap, sort_lists);
 }
-size_t gs2m_sort_lists_words(int nv, int tiles) { return (size_t)nv * GS2M_SORT_CLASSES * (tiles + 1); }
+size_t gs2m_sort_lists_words(int nv, int tiles) { return (size_t)nv * (GS2M_SORT_CLASSES * (tiles + 1) + tiles); }  // class lists + schedule
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint) {
     // <= 512 instances: one wave per tile; larger lists are walked from the work lists k_tile_scan wrote, by grids

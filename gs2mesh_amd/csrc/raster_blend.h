@@ -146,7 +146,8 @@ template <int WPB, int LROWS, int OCC>
 GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank) {
+               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
+               const unsigned* __restrict__ order) {
     // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
     // log2 o, r, g}, c = {b, quadrant mask | general << 8 (bits)}; 2 pad slots: the software-pipelined reads run 2
     // instances ahead.  5.6 KiB of LDS per wave with the DMA landing zone: 7 waves per SIMD fit the 160 KiB.
@@ -161,11 +162,23 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const int tiles = gx * cam.gy;                              // tiles composited by waves
     const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);    // instance lists
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
-    const unsigned grp = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
-    const int tile = gs2m_uniform((int)(grp * (unsigned)WPB) + wave);
-    if (tile >= tiles) return;
-    const int tx = tile % gx, ty = tile / gx;
+    int tx, ty;
+    if (order) {
+        // longest list first (k_tile_scan's schedule): wave i of the launch takes half (i % LROWS) of list order[i / LROWS]
+        const int i = gs2m_uniform((int)(bid * (unsigned)WPB) + wave);
+        if (i >= ltiles * LROWS) return;
+        const int lt = (int)order[(size_t)v * ltiles + i / LROWS];
+        tx = lt % gx;
+        ty = (lt / gx) * LROWS + i % LROWS;
+        if (ty >= cam.gy) return;
+    } else {
+        const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
+        const unsigned grp = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
+        const int tile = gs2m_uniform((int)(grp * (unsigned)WPB) + wave);
+        if (tile >= tiles) return;
+        tx = tile % gx;
+        ty = tile / gx;
+    }
     const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
     float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
     GS2M_KEEP_F32(pxf0);

@@ -9,7 +9,7 @@
 //   0: the reference's structure (256-thread workgroup per tile, 1 pixel per lane; 16 x 16 lists only)
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P, unsigned cap,
-                      float* out_color, unsigned char* out_rgb8, const int* rank) {
+                      float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order) {
     const int tiles = gx * gy;
     const dim3 grid((tiles + 3) / 4, nv), block(256);
     if (variant == 7) {
@@ -19,8 +19,12 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
     }
 
     if (variant == 4) {
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
-        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
+        static const int lpt = getenv("GS2M_BLEND_LPT") ? atoi(getenv("GS2M_BLEND_LPT")) : 1;  // tuning knob: 0 = XCD-contiguous tile ranges
+        const unsigned* ord = lpt ? order : nullptr;
+        const int ltiles = gx * ((gy + tile_rows - 1) / tile_rows);
+        const dim3 g2(ord ? (unsigned)(ltiles * tile_rows + 3) / 4u : grid.x, nv);
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
         return 0;
     }
     if (variant == 0 && tile_rows == 1) {

@@ -69,8 +69,10 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
 GS2M_KERNEL void __launch_bounds__(1024)
 k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles,
             ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap, unsigned* __restrict__ sort_lists) {
-    __shared__ unsigned part[1024];
+    __shared__ unsigned part[16];    // wave totals of the scan
     __shared__ unsigned n_class[GS2M_SORT_CLASSES];
+    __shared__ unsigned w_pos[64];   // longest-list-first order of the lists (compositing schedule): 64 weight buckets
+    __shared__ unsigned w_max;       // longest list of the view
     const int tid = (int)threadIdx.x;
     const int v = (int)blockIdx.x;
     const unsigned* cnt = tile_count + (size_t)v * tiles;
@@ -82,36 +84,71 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     // walk them with a small grid instead of launching a workgroup per tile that mostly has nothing to do)
     unsigned* lists = sort_lists + (size_t)v * GS2M_SORT_CLASSES * (tiles + 1);
     if (tid < GS2M_SORT_CLASSES) n_class[tid] = 0u;
+    if (tid < 64) w_pos[tid] = 0u;
+    if (tid == 64) w_max = 0u;
     __syncthreads();
-    unsigned s = 0;
+    unsigned s = 0, cmax = 0;
     for (int i = lo; i < hi; ++i) {
         const unsigned c = cnt[i];
         s += c;
+        cmax = c > cmax ? c : cmax;
         if (c > GS2M_SORT_WAVE) {
             const int cls = c <= 4096u ? 0 : (c <= GS2M_SORT_BUCKET_CAP ? 1 : 2);
             lists[cls * (tiles + 1) + 1 + atomicAdd(&n_class[cls], 1u)] = (unsigned)i;
         }
     }
-    part[tid] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned add = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += add;
-        __syncthreads();
+    if (cmax) atomicMax(&w_max, cmax);
+    // inclusive scan over the 1024 partials: a shuffle scan inside every wave, then the 16 wave totals
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = gs2m_shfl_up(incl, d);
+        if (lane >= d) incl += y;
     }
-    unsigned run = part[tid] - s;  // exclusive
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    unsigned before = 0u, total_all = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const unsigned x = part[w];
+        before += w < wave ? x : 0u;
+        total_all += x;
+    }
+    unsigned run = before + incl - s;  // exclusive
     for (int i = lo; i < hi; ++i) {
         start[i] = run;
         run += cnt[i];
+    }
+    // compositing schedule: lists by descending length (64 buckets up to the longest list; the order inside a bucket does not matter).
+    // A compositing wave lives ~100 us; dispatched longest first, the waves that end the kernel are the shortest ones.
+    unsigned* order = sort_lists + (size_t)gridDim.x * GS2M_SORT_CLASSES * (tiles + 1) + (size_t)v * tiles;
+    int wsh = 0;                                                  // bucket width 2^wsh: the longest list falls into the top bucket
+    while ((w_max >> wsh) > 63u) ++wsh;
+    auto wbucket = [&](unsigned c) -> unsigned { return 63u - (c >> wsh); };
+    for (int i = lo; i < hi; ++i) atomicAdd(&w_pos[wbucket(cnt[i])], 1u);
+    __syncthreads();
+    if (tid < 64) {   // exclusive prefix over the 64 buckets: one wave, six shuffle steps
+        const unsigned c = w_pos[tid];
+        unsigned incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = gs2m_shfl_up(incl, d);
+            if (tid >= d) incl += y;
+        }
+        w_pos[tid] = incl - c;
+    }
+    __syncthreads();
+    for (int i = lo; i < hi; ++i) {
+        const unsigned c = cnt[i];
+        order[atomicAdd(&w_pos[wbucket(c)], 1u)] = (unsigned)i;
     }
     if (tid < GS2M_SORT_CLASSES) {   // complete: every thread passed the scan's barriers
         lists[tid * (tiles + 1)] = n_class[tid];
         status[v].n_class[tid] = n_class[tid];   // read back with the status: sizes the next call's class grids (a hint)
     }
     if (tid == 1023) {
-        const unsigned total = part[1023];
+        const unsigned total = total_all;
         start[tiles] = total;
         status[v].num_rendered = total;
         status[v].overflow = total > cap ? 1u : 0u;
