@@ -370,6 +370,7 @@ extern "C" int gs2m_tsdf_integrate_batch(gs2m_tsdf* t, int n_frames, const float
         HIPCHK(hipMemcpyAsync(t->d_bframes, hb, sizeof(TsdfBatchFrame) * nf, hipMemcpyHostToDevice, st));
         HIPCHK(hipEventRecord(t->ring_done[slot], st));
         HIPCHK(hipMemsetAsync(t->V.counters + 1, 0, sizeof(unsigned), st));  // touched_count = 0
+        HIPCHK(hipMemsetAsync(t->V.counters + 3, 0, sizeof(unsigned), st));  // work counter of the batch sweep
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
         if (t->timing) {
             e0 = tsdf_ev_get(t);

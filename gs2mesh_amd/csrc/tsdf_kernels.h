@@ -378,14 +378,21 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
     __shared__ float s_p0[16], s_p1[16];
     const int tid = (int)threadIdx.x;
     const int zq = tid >> 8, x = (tid >> 4) & 15, y = tid & 15;
+    __shared__ unsigned s_it;
     const unsigned n_touched = V.counters[1];
     const TsdfFrame& f0 = frames[0].f;   // volume constants (voxel length, truncation) are the same in every frame
-    for (unsigned it = blockIdx.x; it < n_touched; it += gridDim.x) {
+    for (;;) {
+        // blocks are handed out dynamically (counters[3], zeroed before the launch): a block costs as many frame passes as
+        // frames touched it (1 ... the batch size), so a static round-robin leaves the workgroups 1.5x apart at the end
+        __syncthreads();  // previous block's readers of s_p0 / s_p1 / s_it (and of fmask) are done
+        if (tid == 0) s_it = atomicAdd(&V.counters[3], 1u);
+        __syncthreads();
+        const unsigned it = s_it;
+        if (it >= n_touched) break;
         const unsigned h = V.touched[it];
         const unsigned long long key = V.hash_keys[h];
         const int slot = V.hash_vals[h];
         const unsigned long long fm = V.fmask[h];
-        __syncthreads();  // previous block's readers of s_p0 / s_p1 (and of fmask) are done
         if (slot < 0) {   // pool overflow (flagged); uniform across the workgroup
             if (tid == 0) V.fmask[h] = 0ull;
             continue;
