@@ -325,7 +325,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     if (dbg_check(r, st, "hist_colscan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
-        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
+        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, gx, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
     }
     if (dbg_check(r, st, "tile_scan")) return 1;
     {

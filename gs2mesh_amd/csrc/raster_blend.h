@@ -164,12 +164,22 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     int tx, ty;
     if (order) {
-        // longest list first (k_tile_scan's schedule): wave i of the launch takes half (i % LROWS) of list order[i / LROWS]
-        const int i = gs2m_uniform((int)(bid * (unsigned)WPB) + wave);
-        if (i >= ltiles * LROWS) return;
-        const int lt = (int)order[(size_t)v * ltiles + i / LROWS];
-        tx = lt % gx;
-        ty = (lt / gx) * LROWS + i % LROWS;
+        // k_tile_scan's schedule: chunks of GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring lists ranked by descending weight; rank p is
+        // the (p / 8)-th chunk of XCD p % 8.  Wave slot j of XCD x (= bid % 8) takes half (j % LROWS) of list (j / LROWS) %
+        // CHUNK of that XCD's (j / (CHUNK * LROWS))-th chunk.
+        const int xcd = (int)(bid % 8u);
+        const int j = gs2m_uniform((int)(bid / 8u) * WPB + wave);
+        const int lrows = ltiles / gx, cpr = (gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW;
+        const int nch = cpr * ((lrows + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
+        const int rank_c = (j / (GS2M_SCHED_CHUNK * LROWS)) * 8 + xcd;
+        if (rank_c >= nch) return;
+        const int c = (int)order[(size_t)v * ltiles + rank_c];
+        const int k = (j / LROWS) % GS2M_SCHED_CHUNK;                 // list of the chunk
+        const int crow = c / cpr, lx = (c - crow * cpr) * GS2M_SCHED_CW + k % GS2M_SCHED_CW;
+        const int ly = crow * GS2M_SCHED_CH + k / GS2M_SCHED_CW;
+        if (lx >= gx || ly >= lrows) return;
+        tx = lx;
+        ty = ly * LROWS + j % LROWS;
         if (ty >= cam.gy) return;
     } else {
         const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;

@@ -22,7 +22,9 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
         static const int lpt = getenv("GS2M_BLEND_LPT") ? atoi(getenv("GS2M_BLEND_LPT")) : 1;  // tuning knob: 0 = XCD-contiguous tile ranges
         const unsigned* ord = lpt ? order : nullptr;
         const int ltiles = gx * ((gy + tile_rows - 1) / tile_rows);
-        const dim3 g2(ord ? (unsigned)(ltiles * tile_rows + 3) / 4u : grid.x, nv);
+        // schedule: ceil(chunks / 8) chunks per XCD, GS2M_SCHED_CHUNK lists per chunk, tile_rows waves per list, 4 waves per workgroup
+        const int nch = ((gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW) * ((ltiles / gx + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
+        const dim3 g2(ord ? 8u * ((unsigned)(((nch + 7) / 8) * GS2M_SCHED_CHUNK * tile_rows + 3) / 4u) : grid.x, nv);
         if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
         else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
         return 0;

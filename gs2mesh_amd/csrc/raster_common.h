@@ -5,6 +5,14 @@
 #define GS2M_TILE 16        // DGR/cuda_rasterizer/config.h:16-17 (BLOCK_X = BLOCK_Y = 16)
 #define GS2M_MAX_VIEWS 2    // views fused per launch (a stereo pair)
 #define GS2M_SORT_LDS 4096  // keys sorted per workgroup in LDS (32 KiB)
+// chunk of the compositing schedule (k_tile_scan -> blend): GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring lists
+#ifndef GS2M_SCHED_CW
+#define GS2M_SCHED_CW 4
+#endif
+#ifndef GS2M_SCHED_CH
+#define GS2M_SCHED_CH 2
+#endif
+#define GS2M_SCHED_CHUNK (GS2M_SCHED_CW * GS2M_SCHED_CH)
 
 // Per-view uniforms (the per-view fields of GaussianRasterizationSettings,
 // DGR/diff_gaussian_rasterization/__init__.py:157-169, + derived focal / tile grid,

@@ -67,12 +67,12 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
 // Exclusive scan of tile_count over tiles: one 1024-thread workgroup per view.
 // tile_start[v][0..tiles]; status[v] = {N, N > cap}; sticky = {max N, any N > cap} since the last status query.
 GS2M_KERNEL void __launch_bounds__(1024)
-k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles,
+k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles, int gx,
             ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap, unsigned* __restrict__ sort_lists) {
     __shared__ unsigned part[16];    // wave totals of the scan
     __shared__ unsigned n_class[GS2M_SORT_CLASSES];
-    __shared__ unsigned w_pos[64];   // longest-list-first order of the lists (compositing schedule): 64 weight buckets
-    __shared__ unsigned w_max;       // longest list of the view
+    __shared__ unsigned w_pos[64];   // compositing schedule: 64 weight buckets of the list chunks
+    __shared__ unsigned w_max;       // heaviest chunk of the view
     const int tid = (int)threadIdx.x;
     const int v = (int)blockIdx.x;
     const unsigned* cnt = tile_count + (size_t)v * tiles;
@@ -87,17 +87,15 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     if (tid < 64) w_pos[tid] = 0u;
     if (tid == 64) w_max = 0u;
     __syncthreads();
-    unsigned s = 0, cmax = 0;
+    unsigned s = 0;
     for (int i = lo; i < hi; ++i) {
         const unsigned c = cnt[i];
         s += c;
-        cmax = c > cmax ? c : cmax;
         if (c > GS2M_SORT_WAVE) {
             const int cls = c <= 4096u ? 0 : (c <= GS2M_SORT_BUCKET_CAP ? 1 : 2);
             lists[cls * (tiles + 1) + 1 + atomicAdd(&n_class[cls], 1u)] = (unsigned)i;
         }
     }
-    if (cmax) atomicMax(&w_max, cmax);
     // inclusive scan over the 1024 partials: a shuffle scan inside every wave, then the 16 wave totals
     const int lane = tid & 63, wave = tid >> 6;
     unsigned incl = s;
@@ -120,29 +118,56 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
         start[i] = run;
         run += cnt[i];
     }
-    // compositing schedule: lists by descending length (64 buckets up to the longest list; the order inside a bucket does not matter).
-    // A compositing wave lives ~100 us; dispatched longest first, the waves that end the kernel are the shortest ones.
+    // Compositing schedule.  A compositing wave lives ~100 us and a launch has only ~2 generations of them: dispatched in
+    // image order the kernel ends on whatever long lists happen to come last, and an XCD that owns a dense part of the image
+    // finishes long after the others.  The lists are grouped into CHUNKS of GS2M_SCHED_CW x GS2M_SCHED_CH neighbours (they
+    // share Gaussians: one L2), the chunks are ranked by descending weight (64 buckets up to the heaviest) and dealt to the
+    // XCDs round-robin: rank p goes to XCD p % 8 as its (p / 8)-th chunk (block b runs on XCD b % 8 and blocks are
+    // dispatched in order) -- every XCD gets the same share of heavy chunks and ends on its lightest ones.
     unsigned* order = sort_lists + (size_t)gridDim.x * GS2M_SORT_CLASSES * (tiles + 1) + (size_t)v * tiles;
-    int wsh = 0;                                                  // bucket width 2^wsh: the longest list falls into the top bucket
+    const int lrows = tiles / gx;                                               // rows of lists
+    const int cpr = (gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW;                   // chunks per chunk row
+    const int nch = cpr * ((lrows + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);       // chunks
+    auto chunk_weight = [&](int c) -> unsigned {
+        const int crow = c / cpr, x0 = (c - crow * cpr) * GS2M_SCHED_CW, y0 = crow * GS2M_SCHED_CH;
+        unsigned w = 0u;
+        for (int k = 0; k < GS2M_SCHED_CHUNK; ++k) {
+            const int lx = x0 + k % GS2M_SCHED_CW, ly = y0 + k / GS2M_SCHED_CW;
+            if (lx < gx && ly < lrows) w += cnt[ly * gx + lx];
+        }
+        return w;
+    };
+    unsigned cw[2] = {0u, 0u};   // a thread owns chunks tid and tid + 1024 (nch <= 2048: larger grids fall back to rank = id)
+    const bool sched = nch <= 2048;
+    if (sched) {
+        for (int k = 0; k < 2; ++k)
+            if (tid + 1024 * k < nch) {
+                cw[k] = chunk_weight(tid + 1024 * k);
+                atomicMax(&w_max, cw[k]);
+            }
+    }
+    __syncthreads();
+    int wsh = 0;                                                  // bucket width 2^wsh: the heaviest chunk falls into the top bucket
     while ((w_max >> wsh) > 63u) ++wsh;
-    auto wbucket = [&](unsigned c) -> unsigned { return 63u - (c >> wsh); };
-    for (int i = lo; i < hi; ++i) atomicAdd(&w_pos[wbucket(cnt[i])], 1u);
+    if (sched)
+        for (int k = 0; k < 2; ++k)
+            if (tid + 1024 * k < nch) atomicAdd(&w_pos[63u - (cw[k] >> wsh)], 1u);
     __syncthreads();
     if (tid < 64) {   // exclusive prefix over the 64 buckets: one wave, six shuffle steps
         const unsigned c = w_pos[tid];
-        unsigned incl = c;
+        unsigned incl2 = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const unsigned y = gs2m_shfl_up(incl, d);
-            if (tid >= d) incl += y;
+            const unsigned y = gs2m_shfl_up(incl2, d);
+            if (tid >= d) incl2 += y;
         }
-        w_pos[tid] = incl - c;
+        w_pos[tid] = incl2 - c;
     }
     __syncthreads();
-    for (int i = lo; i < hi; ++i) {
-        const unsigned c = cnt[i];
-        order[atomicAdd(&w_pos[wbucket(c)], 1u)] = (unsigned)i;
-    }
+    for (int k = 0; k < 2; ++k)
+        if (tid + 1024 * k < nch) order[sched ? atomicAdd(&w_pos[63u - (cw[k] >> wsh)], 1u) : (unsigned)(tid + 1024 * k)] = (unsigned)(tid + 1024 * k);
+    if (!sched)
+        for (int c = tid + 2048; c < nch; c += 1024) order[c] = (unsigned)c;
     if (tid < GS2M_SORT_CLASSES) {   // complete: every thread passed the scan's barriers
         lists[tid * (tiles + 1)] = n_class[tid];
         status[v].n_class[tid] = n_class[tid];   // read back with the status: sizes the next call's class grids (a hint)
