@@ -130,8 +130,10 @@ def main():
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "6")),
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
-    ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "32")),
-                    help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way)")
+    ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "0")),
+                    help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way); "
+                         "0 (default) = the K views of a job in equal sweeps of at most 32 views, at least two (the last sweep "
+                         "runs after the last render: K = 49 -> 25 + 24)")
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
@@ -162,6 +164,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     K, Wm = args.steps, args.warmup
+    if args.fuse_batch <= 0:
+        n_sweeps = max(2, -(-K // 32))
+        args.fuse_batch = max(1, -(-K // n_sweeps))
     cfg = synthetic.CONFIGS[args.config]
     Wd, Ht = cfg.width, cfg.height
     cx, cy = Wd / 2.0, Ht / 2.0
