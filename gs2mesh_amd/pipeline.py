@@ -67,8 +67,9 @@ class RenderFusePipeline:
         self.fuse_batch = max(1, min(int(fuse_batch), 64))
         self._pending = []
         # two sets of image buffers: batch b + 1 is collected while batch b is still being integrated
+        # (the u8 pair of a pending view is rendered straight into its buffer: no copy out of the slot)
         nb = self.fuse_batch if self.fuse_batch > 1 else 0
-        self._bimg = [[torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)] for _ in range(2)]
+        self._bpair = [[torch.empty((2, self.H, self.W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)] for _ in range(2)]
         self._bcopied = [[torch.cuda.Event() for _ in range(nb)] for _ in range(2)]
         self._batch_done = [None, None]
         self._bset = 0
@@ -107,10 +108,11 @@ class RenderFusePipeline:
         self._n += 1
         r = self.rasterizers[j]
         if self.inflight == 1:
-            r.render_views(self.g, cams, bg=self.bg, out_color=self.color[0], out_rgb8=self.rgb8[0], sync=False)
             if depth is not None and self.fuse_batch > 1:
                 k = len(self._pending)
-                self._bimg[self._bset][k].copy_(self.rgb8[0][0], non_blocking=True)
+                self.rgb8[0] = self._bpair[self._bset][k]     # rendered straight into the pending view's buffer
+            r.render_views(self.g, cams, bg=self.bg, out_color=self.color[0], out_rgb8=self.rgb8[0], sync=False)
+            if depth is not None and self.fuse_batch > 1:
                 self._pending.append((k, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
                 if len(self._pending) == self.fuse_batch:
                     self._flush_batch()
@@ -126,13 +128,17 @@ class RenderFusePipeline:
         rs.wait_stream(cur)
         with torch.cuda.stream(rs):
             rs.wait_event(self._fused[j])          # the view that last used this slot's images is integrated
-            r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j], sync=False)
-            self._rendered[j].record(rs)
-            if depth is not None and self.fuse_batch > 1:
+            batched = depth is not None and self.fuse_batch > 1
+            if batched:
+                # the u8 pair goes straight into the pending view's buffer (no copy out of the slot): the batch that last
+                # read this buffer set (two batches ago) must be done
                 k = len(self._pending)
                 if self._batch_done[self._bset] is not None:
-                    rs.wait_event(self._batch_done[self._bset])   # the batch that last read this buffer set (two batches ago)
-                self._bimg[self._bset][k].copy_(self.rgb8[j][0], non_blocking=True)
+                    rs.wait_event(self._batch_done[self._bset])
+                self.rgb8[j] = self._bpair[self._bset][k]
+            r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j], sync=False)
+            self._rendered[j].record(rs)
+            if batched:
                 self._bcopied[self._bset][k].record(rs)
         if depth is not None and self.fuse_batch > 1:
             for t in (depth, mask):
@@ -165,7 +171,7 @@ class RenderFusePipeline:
             raise ValueError("fuse_batch: the views of a batch must share depth_scale / depth_trunc / min_depth")
         bset = self._bset
         self._bset ^= 1
-        images = [RGBDImage(self._bimg[bset][k], d, depth_scale=p0[4], depth_trunc=p0[5]) for k, d, *_ in pend]
+        images = [RGBDImage(self._bpair[bset][k][0], d, depth_scale=p0[4], depth_trunc=p0[5]) for k, d, *_ in pend]
         masks = [p[3] for p in pend]
         args = (images, self.intrinsic, [p[2] for p in pend])
         kw = dict(masks=masks if any(m is not None for m in masks) else None, min_depth=p0[6])
