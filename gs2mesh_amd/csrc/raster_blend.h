@@ -119,8 +119,11 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
 //   * the reference's power > 0 test and alpha cap (forward.cu:336-343) only run for the instances where they can matter
 //     (opacity > 0.98, or a conic within 1e-3 of singular), flagged while staging: 9 vector ops per contributing
 //     (instance, quadrant) -- exp, T' = fma(-T, alpha, T), compare, select, w = T - T', 3 colour FMAs, move;
-//   * workgroup -> tile-group mapping is XCD-aware (block b runs on XCD b%8: each XCD gets a contiguous run of tiles, so
-//     neighbouring tiles, which share Gaussians, hit the same L2).
+//   * wave -> tile mapping = k_tile_scan's schedule (`order`): chunks of 4 x 2 neighbouring lists (they share Gaussians:
+//     one L2) ranked by descending weight and dealt to the XCDs round-robin (block b runs on XCD b % 8, blocks are
+//     dispatched in order) -- a wave lives ~100 us and a launch has ~2 generations of them, so the kernel used to end on
+//     whatever long lists came last and on the XCD that owned the densest part of the image (C2 238 -> 218 us, C3 320 ->
+//     277 us).  Without `order` (GS2M_BLEND_LPT=0): one contiguous run of tiles per XCD.
 // Decisions are the reference's (same thresholds, same order); roundings of ~1 ulp in q (|q| <= 8) -> relative 1e-6 in alpha.
 // LROWS = reference tiles per instance list (GS2M_OPT_TILE_ROWS): with 2 the binning stages handle ~30 % fewer
 // (Gaussian, tile) instances; two waves walk the same 16 x 32 list, each compositing its own 16 x 16 half (instances that
@@ -131,7 +134,7 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
 // launch, 41 % of the wave cycles issuing / 27 % issue stalls / 32 % waits.  tools/ubench/valu_rates.hip prices the VALU
 // mix at 7 waves per SIMD: plain fp32 op 2.4 cycles per wave64 instruction per SIMD, v_exp_f32 8.1, v_cmp + v_cndmask
 // through a lane mask ~4 each, v_pk_fma_f32 7 (no gain over two v_fma) -> the mix of this loop costs >= 166 us at
-// 2.4 GHz; the kernel runs at ~0.7 of that bound, the rest is the scalar / branch traffic of the skips.
+// 2.4 GHz; the kernel runs at ~0.76 of that bound, the rest is the scalar / branch traffic of the skips.
 // Rejected after A/B on the GPU (same image, slower): exponents + compares of all four quadrants hoisted in front of
 // the branches (+17 %: 2.8 more VALU ops per instance), accepted lanes by execution mask instead of v_cndmask (+3 %:
 // one VALU op less, two scalar ops and a branch more), column terms only for the columns an instance reaches (+6 %),
