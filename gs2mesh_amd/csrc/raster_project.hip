@@ -24,7 +24,8 @@ void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUnif
     // SH rows through LDS (k_project<.., true>): with the spatially ordered packed model (large models, where (almost) every
     // Gaussian is visible: C3 148 -> 136 us); a model that only has the packed SH copy keeps the register path, which reads
     // no row of a culled Gaussian and runs 16 instead of 12 waves per CU (C2: 28 vs 30 us)
-    const bool dma = g.shs_packed != nullptr && g.colors_precomp == nullptr && g.ids != nullptr;
+    static const int dma_knob = getenv("GS2M_PROJECT_DMA") ? atoi(getenv("GS2M_PROJECT_DMA")) : 1;  // tuning knob
+    const bool dma = dma_knob && g.shs_packed != nullptr && g.colors_precomp == nullptr && g.ids != nullptr;
     if (nv == 2 && dma) GS2M_LAUNCH((k_project<2, true>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
     else if (nv == 2) GS2M_LAUNCH((k_project<2, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
     else if (dma) GS2M_LAUNCH((k_project<1, true>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
