@@ -207,3 +207,23 @@ def ref_left(g, cam, cfg):
     return oracle.rasterize_forward(g["xyz"], o, cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
                                     cfg.width, cfg.height, cam.tanfovx, cam.tanfovy, np.zeros(3, np.float32), shs=shs,
                                     scales=s, rotations=q)[0]
+
+
+def test_morton_order_is_a_stable_spatial_permutation():
+    """rasterizer.morton_order: a permutation, identical for the numpy and the torch implementation, stable for equal
+    codes, and spatially coherent (consecutive positions are close together compared with the stored order)."""
+    import torch
+    from gs2mesh_amd.rasterizer import morton_order
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    xyz[100:110] = xyz[5]                      # equal codes: ids must stay ascending
+    o_np = morton_order(xyz)
+    o_t = morton_order(torch.from_numpy(xyz)).numpy()
+    assert o_np.dtype == np.int32 and sorted(o_np.tolist()) == list(range(5000))
+    np.testing.assert_array_equal(o_np, o_t)
+    pos = {int(g): i for i, g in enumerate(o_np)}
+    same = sorted([5] + list(range(100, 110)), key=lambda g: pos[g])
+    assert same == sorted(same)                # stable
+    step_sorted = np.linalg.norm(np.diff(xyz[o_np], axis=0), axis=1).mean()
+    step_stored = np.linalg.norm(np.diff(xyz, axis=0), axis=1).mean()
+    assert step_sorted < 0.25 * step_stored
