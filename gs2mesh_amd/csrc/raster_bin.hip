@@ -3,7 +3,7 @@
 #include "raster_internal.h"
 
 void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count) {
-    GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(256), 0, st, hist, n_wg, tiles, tile_count);
+    GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(64 * GS2M_COLSCAN_SEGS), 0, st, hist, n_wg, tiles, tile_count);
 }
 void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles, int gx,
                            ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {

@@ -13,18 +13,20 @@
 #define GS2M_SORT_BUCKET_CAP 8192
 
 // hist[v][wg][t]: per-workgroup counts -> exclusive prefix over workgroups (in place);
-// tile_count[v][t] = column total.  A 256-thread workgroup owns 64 consecutive tiles (lane) x 4
-// segments of the workgroup axis (wave): pass 1 sums each segment with back-to-back independent
-// loads (coalesced: consecutive lanes = consecutive tiles), the 4 segment sums are exchanged through
-// LDS, pass 2 re-reads the segment (L2-resident) and writes the running prefix.
-GS2M_KERNEL void __launch_bounds__(256)
+// tile_count[v][t] = column total.  A 1024-thread workgroup owns 64 consecutive tiles (lane) x GS2M_COLSCAN_SEGS
+// segments of the workgroup axis (wave): pass 1 sums each segment with back-to-back independent loads (coalesced:
+// consecutive lanes = consecutive tiles), the segment sums are exchanged through LDS, pass 2 re-reads the segment
+// (L2-resident) and writes the running prefix.  16 segments: a thread's dependent chain is ~15 rows for the usual
+// ~256-row matrix (4 segments of 256-thread workgroups left the kernel latency-bound at 120 workgroups).
+#define GS2M_COLSCAN_SEGS 16
+GS2M_KERNEL void __launch_bounds__(64 * GS2M_COLSCAN_SEGS)
 k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count) {
-    __shared__ unsigned seg_sum[4][64];
+    __shared__ unsigned seg_sum[GS2M_COLSCAN_SEGS][64];
     const int lane = (int)(threadIdx.x & 63u), seg = (int)(threadIdx.x >> 6);
     const int t = (int)blockIdx.x * 64 + lane;
     const int v = (int)blockIdx.y;
-    const int per = (n_wg + 3) / 4;
-    const int w0 = seg * per;
+    const int per = (n_wg + GS2M_COLSCAN_SEGS - 1) / GS2M_COLSCAN_SEGS;
+    const int w0 = seg * per < n_wg ? seg * per : n_wg;
     const int w1 = w0 + per < n_wg ? w0 + per : n_wg;
     unsigned* col = hist + (size_t)v * n_wg * tiles + t;
     unsigned s = 0;
@@ -42,8 +44,13 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
     seg_sum[seg][lane] = s;
     __syncthreads();
     if (t < tiles) {
-        unsigned run = 0;
-        for (int k = 0; k < seg; ++k) run += seg_sum[k][lane];
+        unsigned run = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < GS2M_COLSCAN_SEGS; ++k) {
+            const unsigned x = seg_sum[k][lane];
+            run += k < seg ? x : 0u;
+            total += x;
+        }
         int w = w0;
         for (; w + 8 <= w1; w += 8) {
             unsigned x[8];
@@ -60,7 +67,7 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
             col[(size_t)w * tiles] = run;
             run += x;
         }
-        if (seg == 3) tile_count[(size_t)v * tiles + t] = run;
+        if (seg == 0) tile_count[(size_t)v * tiles + t] = total;
     }
 }
 
