@@ -137,6 +137,13 @@ def main():
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
+    ap.add_argument("--blend-cus", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND_CUS", "0")),
+                    help="CU partition (gs2mesh_amd/streams.py): compositing launches on streams masked to this many CUs "
+                         "(a multiple of 32 below the CU count; 0 = no partition)")
+    ap.add_argument("--blend-streams", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND_STREAMS", "2")))
+    ap.add_argument("--bin-cus", default=os.environ.get("GS2M_BENCH_BIN_CUS", "all"), choices=["all", "rest", "blend", "own"],
+                    help="with --blend-cus: binning chains on unmasked streams (all) or on the CUs the compositing leaves (rest)")
+    ap.add_argument("--fuse-cus", default=os.environ.get("GS2M_BENCH_FUSE_CUS", "all"), choices=["all", "rest", "blend", "own"])
     ap.add_argument("--min-repeats", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -195,8 +202,10 @@ def main():
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
                               exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows,
-                              fuse_batch=args.fuse_batch, spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)))
+                              fuse_batch=args.fuse_batch, spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)),
+                              blend_cus=args.blend_cus, blend_streams=args.blend_streams, bin_cus=args.bin_cus, fuse_cus=args.fuse_cus)
     spatial_order_used = int(pipe.spatial_order)
+    pipe_blend_cus = int(pipe.blend_cus)
     R = pipe.rasterizers[0]
     color, rgb8 = pipe.color[0], pipe.rgb8[0]
 
@@ -255,8 +264,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(Wm, Wm + K):
             step(i)
+        pipe.drain()                              # integrates the last (partial) TSDF batch, then waits for the pipeline's streams
         if world > 1:
-            pipe.drain()                          # host waits for the fuse stream only (no device-wide sync)
             t_red0 = time.perf_counter()
             red = reduce_volume(vol, mode=args.reduce)
             torch.cuda.synchronize()
@@ -273,6 +282,24 @@ def main():
             break
     dt = statistics.median(dts)
     t_red = statistics.median(reds) if reds else None
+
+    # ---- one more (untimed) repeat with a timing event after every pair: steady-state step time vs pipeline fill / drain
+    vol.reset()
+    barrier()
+    pipe.trace_events = []
+    for i in range(Wm, Wm + K):
+        step(i)
+    pipe.drain()
+    barrier()
+    evs, pipe.trace_events = pipe.trace_events, None
+    pipe.finish()
+    steady = None
+    lo_i = min(args.inflight, K - 2)
+    if len(evs) == K and K - 1 - lo_i >= 1:
+        t_ss = evs[lo_i].elapsed_time(evs[K - 1]) / (K - 1 - lo_i)      # ms per step between the first full pipeline and the last pair
+        steady = dict(steady_state_ms_per_step=round(t_ss, 4), fill_drain_ms=round(1e3 * dt - t_ss * K, 4),
+                      note=f"hipEvents after every pair's compositing: (t[{K - 1}] - t[{lo_i}]) / {K - 1 - lo_i}; "
+                           "fill_drain = job time - K x steady state (pipeline fill, last TSDF sweep, final sync)")
 
     # ---- instrumented pass (hipEvents around every kernel launch, on the work stream) ---------
     vol.reset()
@@ -456,8 +483,10 @@ def main():
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
                         exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight,
-                        tsdf_fuse_batch=args.fuse_batch,
+                        tsdf_fuse_batch=args.fuse_batch, cu_partition=dict(blend_cus=pipe_blend_cus, blend_streams=args.blend_streams,
+                                                                           bin_cus=args.bin_cus, fuse_cus=args.fuse_cus),
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
+            steady_state=steady,
             timing=dict(repeats=len(dts), timed_region_s=round(sum(dts), 4), statistic="median over repeats of the K-step job",
                         ms_per_step_min=round(1e3 * min(dts) / K, 4), ms_per_step_max=round(1e3 * max(dts) / K, 4)),
             num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis,

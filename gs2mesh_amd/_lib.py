@@ -31,9 +31,11 @@ class Gaussians(C.Structure):
                 ("xyz", vp), ("scales", vp), ("rotations", vp), ("opacities", vp), ("shs", vp), ("shs_rest", vp)]
 
 
+ABI_VERSION = 300   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
 OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
+OPT_BLEND_WG_PER_CU = 6
 OPT_DEBUG_SYNC = 3
 OPT_STAGE_TIMING = 4
 RASTER_STAGES = ("project", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend", "count_tiles")
@@ -42,6 +44,9 @@ TSDF_STAGES = ("tsdf_touch", "tsdf_integrate")
 _PROTOS = {
     "gs2m_version": (i32, []),
     "gs2m_last_error": (C.c_char_p, []),
+    "gs2m_stream_create": (i32, [C.POINTER(vp), i32, C.POINTER(C.c_uint32), i32]),
+    "gs2m_stream_destroy": (i32, [vp]),
+    "gs2m_raster_set_blend_stream": (i32, [vp, vp]),
     "gs2m_raster_create": (i32, [C.POINTER(vp), i32]),
     "gs2m_raster_destroy": (i32, [vp]),
     "gs2m_raster_set_option": (i32, [vp, i32, i32]),
@@ -53,6 +58,7 @@ _PROTOS = {
                                 vp]),
     "gs2m_raster_pack_sh": (i32, [vp, C.POINTER(Gaussians), vp]),
     "gs2m_raster_pack_model": (i32, [vp, C.POINTER(Gaussians), vp, vp]),
+    "gs2m_raster_pack_invalidate": (i32, [vp]),
     "gs2m_raster_status": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
     "gs2m_raster_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
     "gs2m_raster_download_geometry": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
@@ -111,7 +117,11 @@ def get() -> C.CDLL:
             import torch  # noqa: F401
         except Exception:  # pragma: no cover - torch is the memory/stream plumbing; the C ABI itself does not need it
             pass
-        _LIB = bind(C.CDLL(LIB_PATH))
+        lib = bind(C.CDLL(LIB_PATH))
+        if lib.gs2m_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} is ABI version {lib.gs2m_version()}, this binding needs {ABI_VERSION}: "
+                               "rebuild it (python -m gs2mesh_amd.build)")
+        _LIB = lib
     return _LIB
 
 

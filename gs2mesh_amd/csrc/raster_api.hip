@@ -39,7 +39,7 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1;
+    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_blend_wg_per_cu = 0;
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -88,6 +88,10 @@ struct gs2m_raster {
     // last call
     int last_P = 0, last_nv = 0, last_tiles = 0, last_views_total = 0;
     unsigned last_cap = 0;
+    // gs2m_raster_set_blend_stream: the compositing launch goes to this stream (e.g. one created with a CU mask), ordered
+    // against the call's stream by the two events below; null = everything on the call's stream
+    hipStream_t blend_stream = nullptr;
+    hipEvent_t ev_binned = nullptr, ev_blended = nullptr;
 };
 
 template <typename T>
@@ -150,6 +154,8 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : r->ev_free) (void)hipEventDestroy(e);
+    if (r->ev_binned) (void)hipEventDestroy(r->ev_binned);
+    if (r->ev_blended) (void)hipEventDestroy(r->ev_blended);
     delete r;
     return 0;
 }
@@ -175,10 +181,58 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             }
             r->opt_tile_rows = value;
             return 0;
+        case GS2M_OPT_BLEND_WG_PER_CU:
+            if (value < 0 || value > 8) {
+                gs2m_set_error("GS2M_OPT_BLEND_WG_PER_CU must be 0 (no cap) .. 8");
+                return 1;
+            }
+            r->opt_blend_wg_per_cu = value;
+            return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
         case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
     }
+}
+
+extern "C" int gs2m_stream_create(gs2m_stream* out, int device, const uint32_t* cu_mask, int n_words) {
+    if (!out) {
+        gs2m_set_error("gs2m_stream_create: out is NULL");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(device));
+    hipStream_t s = nullptr;
+    if (cu_mask && n_words > 0) {
+        bool any = false;
+        for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0u;
+        if (!any) {
+            gs2m_set_error("gs2m_stream_create: empty CU mask");
+            return 1;
+        }
+        HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    *out = (gs2m_stream)s;
+    return 0;
+}
+
+extern "C" int gs2m_stream_destroy(gs2m_stream s) {
+    if (s) HIPCHK(hipStreamDestroy((hipStream_t)s));
+    return 0;
+}
+
+extern "C" int gs2m_raster_set_blend_stream(gs2m_raster* r, gs2m_stream s) {
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(r->device));
+    if (s && !r->ev_binned) {
+        HIPCHK(hipEventCreateWithFlags(&r->ev_binned, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&r->ev_blended, hipEventDisableTiming));
+    }
+    r->blend_stream = (hipStream_t)s;
+    return 0;
 }
 
 // tiles of the binning grid: 16 x (16 * rows) pixels
@@ -353,12 +407,24 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
         gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists, hint);
     }
     if (dbg_check(r, st, "sort_tiles")) return 1;
+    // compositing on its own stream (gs2m_raster_set_blend_stream): binned -> [blend stream] -> blended -> back on `st`, so
+    // that for the caller everything is still ordered on `st`
+    hipStream_t bs = st;
+    if (r->blend_stream && r->blend_stream != st) {
+        bs = r->blend_stream;
+        HIPCHK(hipEventRecord(r->ev_binned, st));
+        HIPCHK(hipStreamWaitEvent(bs, r->ev_binned, 0));
+    }
     {
-        StageTimer tm(r, st, GS2M_STAGE_BLEND);
-        if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
+        StageTimer tm(r, bs, GS2M_STAGE_BLEND);
+        if (gs2m_launch_blend(bs, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
                               g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
-                              r->d_sort_lists + (size_t)nv * GS2M_SORT_CLASSES_API * (tiles + 1)))
+                              r->d_sort_lists + (size_t)nv * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_wg_per_cu))
             return 1;
+    }
+    if (bs != st) {
+        HIPCHK(hipEventRecord(r->ev_blended, bs));
+        HIPCHK(hipStreamWaitEvent(st, r->ev_blended, 0));
     }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;
@@ -607,6 +673,18 @@ static int pack_common(gs2m_raster* r, const gs2m_gaussians* gs, const int32_t* 
         r->model_src[3] = gs->opacities;
         r->model_packed = true;
     }
+    return 0;
+}
+
+extern "C" int gs2m_raster_pack_invalidate(gs2m_raster* r) {
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    r->pack_src = nullptr;
+    r->pack_src_rest = nullptr;
+    r->pack_P = 0;
+    r->model_packed = false;
     return 0;
 }
 

@@ -38,7 +38,8 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
                             const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint);
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
-                      unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order);
+                      unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order,
+                      int wg_per_cu);
 
 // error plumbing (common_api.hip)
 void gs2m_set_error(const char* fmt, ...);

@@ -28,7 +28,8 @@ class RenderFusePipeline:
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None,
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0,
                  exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
-                 lib=None, fuse_batch: int = 1, spatial_order="auto"):
+                 lib=None, fuse_batch: int = 1, spatial_order="auto", blend_cus: int = 0, blend_streams: int = 2,
+                 bin_cus: str = "all", fuse_cus: str = "all", blend_wg_per_cu: int = 0, blend_stream_plain: bool = False):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
@@ -45,22 +46,53 @@ class RenderFusePipeline:
         self.device = int(device)
         self.bg = bg
         dev = torch.device(f"cuda:{device}")
-        self.rasterizers, self.color, self.rgb8 = [], [], []
+        self.rasterizers, self.color, self.rgb8, self._own8 = [], [], [], []
         for j in range(self.inflight):
             r = Rasterizer(device, lib=lib)
             r.set_option(_lib.OPT_EXACT_TILE_CULL, int(exact_tile_cull))
             r.set_option(_lib.OPT_TILE_ROWS, int(tile_rows))   # 2 = 16 x 32 binning tiles (same image, fewer instances)
             if blend_variant is not None:
                 r.set_option(_lib.OPT_BLEND_VARIANT, int(blend_variant))
+            if blend_wg_per_cu:
+                r.set_option(_lib.OPT_BLEND_WG_PER_CU, int(blend_wg_per_cu))
             self.rasterizers.append(r)
             self.color.append(torch.empty((2, 3, self.H, self.W), dtype=torch.float32, device=dev))
-            self.rgb8.append(torch.empty((2, self.H, self.W, 3), dtype=torch.uint8, device=dev))
+            # rgb8[j] = where slot j's latest u8 pair lives (the slot's own buffer, or the pending view's batch buffer)
+            self._own8.append(torch.empty((2, self.H, self.W, 3), dtype=torch.uint8, device=dev))
+            self.rgb8.append(self._own8[j])
+        self._masked = []
+        self.blend_cus = 0
         if self.inflight == 1:
             # serial mode: everything on the caller's current stream
             self.render_streams, self.fuse_stream = [None], None
         else:
-            self.render_streams = [torch.cuda.Stream(device=dev) for _ in range(self.inflight)]
-            self.fuse_stream = torch.cuda.Stream(device=dev)
+            # CU partition (gs2mesh_amd/streams.py): with blend_cus = N (a multiple of 32, < the CU count) the compositing
+            # launches go to `blend_streams` streams masked to CUs [0, N); "rest" puts the binning chains / the TSDF sweeps
+            # on streams masked to the other CUs, "all" leaves them unmasked (they may also use what the compositing
+            # leaves free), fuse_cus = "blend" masks the TSDF stream like the compositing.
+            from .streams import acquire
+            total = torch.cuda.get_device_properties(dev).multi_processor_count
+            self.blend_cus = int(blend_cus) if blend_cus and 0 < int(blend_cus) < total else 0
+            rest = (self.blend_cus, total - self.blend_cus)
+
+            def make(kind):
+                if kind == "all" or (not self.blend_cus and kind != "own"):
+                    return torch.cuda.Stream(device=dev)
+                # "own": every CU, but a stream of its own kind: HIP multiplexes ordinary streams onto GPU_MAX_HW_QUEUES (4)
+                # hardware queues, and a cross-stream wait parked in a shared hardware queue blocks every stream mapped
+                # to it; a CU-masked stream always gets a hardware queue of its own
+                m = acquire(device, {"rest": rest, "own": (0, total)}.get(kind, (0, self.blend_cus)), total, lib=lib)
+                self._masked.append(m)
+                return m.torch
+
+            self.render_streams = [make(bin_cus) for _ in range(self.inflight)]
+            self.fuse_stream = make(fuse_cus)
+            if self.blend_cus or blend_stream_plain:
+                bl = [acquire(device, (0, self.blend_cus) if self.blend_cus else None, total, lib=lib)
+                      for _ in range(max(1, int(blend_streams)))]
+                self._masked += bl
+                for j, r in enumerate(self.rasterizers):
+                    r.set_blend_stream(bl[j % len(bl)].handle)
         # fuse_batch > 1: the views are integrated `fuse_batch` at a time by the voxel-stationary batch kernel
         # (gs2m_tsdf_integrate_batch: same result as view by view, one voxel-state read + write per batch).  The left
         # image of every pending view is kept in its own buffer (a slot's image is re-rendered before the batch runs).
@@ -76,6 +108,7 @@ class RenderFusePipeline:
         self._rendered = [torch.cuda.Event() for _ in range(self.inflight)]
         self._fused = [torch.cuda.Event() for _ in range(self.inflight)]
         self._n = 0
+        self.trace_events = None   # a list: submit() appends a timing event recorded after every pair (bench.py's steady-state probe)
 
     # -- set-up ------------------------------------------------------------------------------------
     def prepare(self, cams, headroom: float = 1.3):
@@ -108,6 +141,8 @@ class RenderFusePipeline:
         self._n += 1
         r = self.rasterizers[j]
         if self.inflight == 1:
+            # a fuse-less render (or view-by-view fusion) writes the slot's OWN buffer, never a pending view's batch buffer
+            self.rgb8[0] = self._own8[0]
             if depth is not None and self.fuse_batch > 1:
                 k = len(self._pending)
                 self.rgb8[0] = self._bpair[self._bset][k]     # rendered straight into the pending view's buffer
@@ -129,6 +164,7 @@ class RenderFusePipeline:
         with torch.cuda.stream(rs):
             rs.wait_event(self._fused[j])          # the view that last used this slot's images is integrated
             batched = depth is not None and self.fuse_batch > 1
+            self.rgb8[j] = self._own8[j]   # fuse-less / view-by-view: the slot's own buffer (ordered by _fused[j] above)
             if batched:
                 # the u8 pair goes straight into the pending view's buffer (no copy out of the slot): the batch that last
                 # read this buffer set (two batches ago) must be done
@@ -140,6 +176,10 @@ class RenderFusePipeline:
             self._rendered[j].record(rs)
             if batched:
                 self._bcopied[self._bset][k].record(rs)
+            if self.trace_events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(rs)
+                self.trace_events.append(ev)
         if depth is not None and self.fuse_batch > 1:
             for t in (depth, mask):
                 if torch.is_tensor(t) and t.is_cuda:
@@ -217,6 +257,22 @@ class RenderFusePipeline:
                 raise RuntimeError(f"instance arena overflow inside the pipelined loop (slot {j}: views "
                                    f"{j}, {j + self.inflight}, ... of the {self._n} submitted; need {req} instances "
                                    f"per view)")
+
+    def close(self):
+        """Drain and release the masked streams (the handles' compositing goes back to the call's stream)."""
+        if getattr(self, "_masked", None):
+            self.drain()
+            for r in self.rasterizers:
+                r.set_blend_stream(None)
+            for m in self._masked:
+                m.close()
+            self._masked = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_stage_timing(self, enable: bool):
         for r in self.rasterizers:

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define GS2M_VERSION 100 /* 0.1.0 */
+#define GS2M_VERSION 300 /* 0.3.0: round-3 ABI (sum-form exchange buffers, sticky overflow word, masked streams);
+                            the Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
 
@@ -42,6 +43,17 @@ typedef void* gs2m_stream; /* hipStream_t */
 int gs2m_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* gs2m_last_error(void);
+
+/*
+ * Streams with a compute-unit mask (hipExtStreamCreateWithCUMask): work enqueued on such a stream only runs on the CUs
+ * whose bit is set.  cu_mask[n_words] (HOST): bit i of the array = CU i in the driver's enumeration, which interleaves
+ * the 8 XCDs (bit i belongs to XCD i % 8, then round-robin over that XCD's shader engines): the low N bits, N a
+ * multiple of 32, are an XCD- and SE-symmetric set of N CUs.  cu_mask == NULL: a plain non-blocking stream.  New: the
+ * reference launches everything on the null stream (DGR/rasterize_points.cu); here the VALU-bound compositing grid is
+ * kept off a few CUs so that the latency-bound binning / TSDF kernels of the next views always find a free CU.
+ */
+int gs2m_stream_create(gs2m_stream* out, int device, const uint32_t* cu_mask /* host */, int n_words);
+int gs2m_stream_destroy(gs2m_stream s);
 
 /* ------------------------------------------------------------------------------------ */
 /* rasteriser                                                                           */
@@ -64,6 +76,10 @@ enum {
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4,    /* 1 = bracket every stage launch with hipEvents on the
                                      work stream (read with gs2m_raster_stage_times)      */
+    GS2M_OPT_BLEND_WG_PER_CU = 6, /* cap on the compositing workgroups (4 waves each) resident per CU, 1..6; 0 = no cap (7).
+                                     The compositing grid otherwise refills every slot a retiring workgroup frees, and the
+                                     1024-thread binning / TSDF workgroups of the NEXT views (other streams) only get placed
+                                     in its tail; with a cap every CU keeps wave slots and LDS free for them.  Same image. */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and
@@ -87,6 +103,11 @@ enum {
 int gs2m_raster_create(gs2m_raster** out, int device);
 int gs2m_raster_destroy(gs2m_raster* r);
 int gs2m_raster_set_option(gs2m_raster* r, int option, int value);
+
+/* Launch the compositing kernel of every later forward / render_views call on `blend_stream` instead of the call's
+ * stream (NULL = back to the call's stream).  The library orders it with two events (binning -> compositing -> back),
+ * so for the caller all work of a call is still ordered on the stream it passed. */
+int gs2m_raster_set_blend_stream(gs2m_raster* r, gs2m_stream blend_stream);
 
 /* Pre-size the arenas (optional; every forward grows them on demand).
  * P Gaussians, n_views views of W x H rendered per call, `instances` (Gaussian,tile)
@@ -198,6 +219,11 @@ int gs2m_raster_pack_sh(gs2m_raster* r, const gs2m_gaussians* g, gs2m_stream str
  */
 int gs2m_raster_pack_model(gs2m_raster* r, const gs2m_gaussians* g, const int32_t* order /* device [P] */,
                            gs2m_stream stream);
+
+/* The packed copies are matched to the caller's arrays by DEVICE POINTER (and P) only: after an in-place update of any
+ * Gaussian parameter, or when tensors may have been freed and re-allocated at the same addresses, call this (or pack
+ * again) -- later gs2m_render_views calls then read the caller's arrays until the next pack. */
+int gs2m_raster_pack_invalidate(gs2m_raster* r);
 
 /* Synchronises `stream` (pass the stream the handle is used on) and reports num_rendered[v] for
  * v < n_views of the LAST forward/render_views call on the handle (host array, may be NULL), and

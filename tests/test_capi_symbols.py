@@ -28,7 +28,8 @@ def test_hip_library_builds_and_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/gs2mesh_amd.h but not exported"
     lib.gs2m_version.restype = ctypes.c_int
-    assert lib.gs2m_version() == 100
+    from gs2mesh_amd import _lib as binding
+    assert lib.gs2m_version() == binding.ABI_VERSION == 300
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path], capture_output=True, text=True)
     if out.returncode == 0 and out.stdout:
         pass  # informational only

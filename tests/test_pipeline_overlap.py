@@ -8,7 +8,7 @@ from gs2mesh_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-def _run(inflight, n_views=6, fuse_batch=1):
+def _run(inflight, n_views=6, fuse_batch=1, **pipe_kw):
     import torch
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
     from gs2mesh_amd.pipeline import RenderFusePipeline
@@ -22,7 +22,7 @@ def _run(inflight, n_views=6, fuse_batch=1):
     poses = synthetic.ring_poses(n_views, cfg.ring_radius, 0, n_views)
     intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
     vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
-    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0, fuse_batch=fuse_batch)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0, fuse_batch=fuse_batch, **pipe_kw)
     cams, depths, Es = [], [], []
     for p in poses:
         l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
@@ -39,6 +39,7 @@ def _run(inflight, n_views=6, fuse_batch=1):
         images.append((pipe.color[slot].cpu().numpy().copy(), pipe.rgb8[slot].cpu().numpy().copy()))
     pipe.finish()
     keys, tsdf, weight, rgb = vol.download()
+    pipe.close()
     order = np.lexsort(keys.T[::-1])
     return images, keys[order], tsdf[order], weight[order], rgb[order]
 
@@ -62,6 +63,61 @@ def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
     for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
         assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
     for a, b in zip(ref[1:], got[1:]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(blend_cus=224), dict(blend_cus=192, bin_cus="rest", fuse_cus="rest", blend_streams=1),
+                                dict(blend_cus=224, fuse_cus="blend", blend_streams=3)])
+def test_cu_partitioned_streams_equal_serial(kw):
+    """CU-masked streams (gs2m_stream_create / gs2m_raster_set_blend_stream): the compositing launches run on streams
+    restricted to a subset of the CUs, ordered against the binning chain by events inside the library -- same images, same
+    volume as the serial single-stream order."""
+    ref = _run(1)
+    got = _run(3, fuse_batch=2, **kw)
+    for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
+        assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
+    for a, b in zip(ref[1:], got[1:]):
+        assert np.array_equal(a, b)
+
+
+def test_fuseless_render_does_not_touch_a_pending_views_image():
+    """A submit without depth on a slot whose previous view is still pending in a TSDF batch renders into the slot's own
+    buffer, not into the pending view's batch buffer (which the later sweep still reads)."""
+    import torch
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    from gs2mesh_amd.rasterizer import camera_from
+    cfg = synthetic.CONFIGS["C1"]
+    dev = torch.device("cuda:0")
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+    gd["raw"] = True
+    W, H = cfg.width, cfg.height
+    poses = synthetic.ring_poses(6, cfg.ring_radius, 0, 6)
+    intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
+    out = []
+    for extra in (False, True):
+        vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
+        pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=2, device=0, fuse_batch=4)
+        subs = []
+        for p in poses:
+            l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
+            E = np.eye(4)
+            E[:3] = p
+            subs.append(([camera_from(l), camera_from(r)],
+                         synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2, H / 2, cfg.sphere_radius, dev), E))
+        pipe.prepare(subs[0][0])
+        for i, (c, d, E) in enumerate(subs[:4]):
+            pipe.submit(c, d, E, depth_trunc=cfg.baseline * 20, min_depth=cfg.baseline * 4)
+            if extra and i < 3:
+                # fuse-less renders of OTHER views on both slots while views 0..i are pending
+                pipe.submit(subs[5][0])
+                pipe.submit(subs[4][0])
+        pipe.finish()
+        keys, tsdf, weight, rgb = vol.download()
+        order = np.lexsort(keys.T[::-1])
+        out.append((keys[order], tsdf[order], weight[order], rgb[order]))
+    for a, b in zip(*out):
         assert np.array_equal(a, b)
 
 
