@@ -395,9 +395,13 @@ def main():
         # activations), against the CPU oracle (the reference's own kernels when oracle/_ref is prebuilt)
         from oracle import parity
         rr = R.render_views(gd, cams[Wm], out_color=color, out_rgb8=rgb8, want_radii=True)
-        par = parity.pair_parity(g, cams_np[Wm], Wd, Ht, color.cpu().numpy(), rgb8.cpu().numpy(), rr["radii"].cpu().numpy())
+        par = parity.pair_parity(g, cams_np[Wm], Wd, Ht, color.cpu().numpy(), rgb8.cpu().numpy(), rr["radii"].cpu().numpy(),
+                                 flips=True)
         par["what"] = (f"first timed {args.config} pair (both eyes, worst case), fp32 image on [0,1] vs the CPU oracle; "
-                       "radii: fused exp/normalize/sigmoid vs numpy's")
+                       "radii: fused exp/normalize/sigmoid vs numpy's; flip_pixels = pixels where a decision of renderCUDA "
+                       "(power > 0, alpha < 1/255, T(1-alpha) < 1e-4) sits within 1e-5 of its threshold in the oracle's own "
+                       "replay; max_abs_clean = max |delta| on all other pixels (bar 2e-4); unexplained_pixels = pixels beyond "
+                       "the bound of the contributions that can flip")
         N_ref = par.get("oracle_num_rendered")
         if isinstance(N_ref, list):
             _, B_pair_ref = alg_bytes(cfg, p_vis, p_vis_union, [float(x) for x in N_ref])

@@ -21,9 +21,8 @@ ARCH = "gfx950"
 SOURCES = [
     ("raster_project.hip", ["-ffp-contract=off"]),
     ("raster_bin.hip", []),
-    # packed-f32 SLP costs register copies in the compositing loop; MFMA results straight into VGPRs (the compositing
-    # reads them with VALU ops: AGPR destinations would cost a v_accvgpr_read per exponent and 32 more registers)
-    ("raster_blend.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
+    # packed-f32 SLP costs register copies in the compositing loop
+    ("raster_blend.hip", ["-fno-slp-vectorize"]),
     ("raster_api.hip", []),
     ("tsdf_kernels.hip", ["-ffp-contract=off"]),
     ("tsdf_api.hip", []),

@@ -25,6 +25,9 @@ GS2M_DEVICE unsigned long long gs2m_ballot(int pred) { return __ballot(pred); }
 // inverse: a wave-uniform 64-bit mask used as a per-lane predicate (no instruction: the mask IS the v_cndmask operand)
 GS2M_DEVICE unsigned long long gs2m_ballot_b(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 GS2M_DEVICE bool gs2m_lanes(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// "does any ACTIVE lane satisfy pred?" inside divergent code (ballot under the execution mask).  Only ever used to skip
+// work no lane needs: taking the branch when the answer is no must be harmless (the CPU emulator always answers yes).
+GS2M_DEVICE bool gs2m_any_active_lane(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
 GS2M_DEVICE int gs2m_lane() { return (int)(threadIdx.x & 63u); }
 GS2M_DEVICE int gs2m_popc64(unsigned long long m) { return __popcll(m); }
 template <typename T>
@@ -66,32 +69,12 @@ GS2M_DEVICE float gs2m_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); } 
 GS2M_DEVICE float gs2m_fast_log2(float x) { return __log2f(x); }
 // keep a loop-invariant float in its VGPR (stops the compiler re-materialising int->float converts in hot loops)
 #define GS2M_KEEP_F32(x) asm volatile("" : "+v"(x))
+// a wave-uniform int the compiler must treat as an opaque scalar register (stops re-association of mask tests)
+#define GS2M_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
 // instruction-scheduling fence (nothing moves across it)
 // keeps a rarely taken, wave-uniform branch a BRANCH (stops the compiler turning it into selects executed every time)
 #define GS2M_NO_IF_CONVERT() asm volatile("" ::: "memory")
 #define GS2M_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-
-// ---- matrix cores (CDNA4) ---------------------------------------------------------------------
-// v_mfma_f32_32x32x16_bf16: D[32x32] += A[32x16] * B[16x32].  Operands as raw registers: lane l supplies 8 bf16 of
-// row (A) / column (B) l & 31, K-slot group l >> 5 (packed two per dword, element e in dword e/2, low half first);
-// D register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l & 31 (MI355X guide, "Fragment layout").
-typedef __attribute__((ext_vector_type(8))) __bf16 gs2m_bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float gs2m_f32x16;
-GS2M_DEVICE gs2m_f32x16 gs2m_mfma_32x32x16_bf16(uint4 a, uint4 b, gs2m_f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gs2m_bf16x8_t, a), __builtin_bit_cast(gs2m_bf16x8_t, b), c, 0, 0, 0);
-}
-// v_permlane32_swap_b32: lanes 32-63 of `a` trade places with lanes 0-31 of `b`:  a' = [a.lo | b.lo],  b' = [a.hi | b.hi]
-GS2M_DEVICE void gs2m_permlane32_swap(unsigned& a, unsigned& b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
-}
-GS2M_DEVICE void gs2m_permlane32_swap(float& a, float& b) {
-    unsigned x = __float_as_uint(a), y = __float_as_uint(b);
-    gs2m_permlane32_swap(x, y);
-    a = __uint_as_float(x);
-    b = __uint_as_float(y);
-}
 
 // ---- LDS-DMA gather: lane l's 16 bytes at `g` land at lds_base[l] without passing through a VGPR
 // (global_load_lds_dwordx4; completion is tracked by vmcnt: gs2m_wait_dma before the LDS is read)

@@ -168,8 +168,8 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
     switch (option) {
         case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
         case GS2M_OPT_BLEND_VARIANT:
-            if (value != 0 && value != 4 && value != 7) {
-                gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0, 4 or 7");
+            if (value != 0 && value != 4) {
+                gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0 or 4");
                 return 1;
             }
             r->opt_blend = value;

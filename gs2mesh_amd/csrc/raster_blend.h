@@ -145,7 +145,7 @@ struct BlendInst {
     float2 c;
 };
 
-template <int WPB, int LROWS, int OCC>
+template <int WPB, int LROWS, int OCC, int MODE = 0>
 GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
@@ -200,12 +200,21 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     GS2M_KEEP_F32(pyf1);
     float T[4], C0[4], C1[4], C2[4];
     unsigned long long dn[4];  // finished (or outside-the-image) pixels of quadrant k: lane mask in scalar registers
+    // MODE 1: no lane masks in scalar registers -- the scalar unit issues ONE instruction per cycle for the four SIMDs of a
+    // CU (tools/ubench/salu_rates.hip) and the mask bookkeeping of MODE 0 (7 scalar instructions + 3 branches per
+    // contributing quadrant) made the kernel scalar-issue-bound.  A finished pixel raises its own threshold to +inf, the
+    // candidate test is one v_cmp against that threshold and the accumulate path runs under the execution mask.
+    float thr[4];
+    const float QMIN_ = -7.99435343685885793770f;
+    // threshold of a finished pixel: q <= log2(opacity) <= 0 for every accepted contribution (an inline constant, no register)
+    const float THR_DONE = 1.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int x = px0 + 8 * (k & 1), y = py0 + 8 * (k >> 1);
         T[k] = 1.0f;
         C0[k] = C1[k] = C2[k] = 0.0f;
         dn[k] = gs2m_ballot_b(!(x < W && y < H));
+        thr[k] = (x < W && y < H) ? QMIN_ : THR_DONE;
     }
     const float qx0 = (float)(tx * GS2M_TILE), qy0 = (float)(ty * GS2M_TILE);
     const int ltile = (ty / LROWS) * gx + tx;
@@ -244,11 +253,13 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     while (base < r1) {
         unsigned lq = 0u;  // quadrants that still have unfinished pixels
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lq |= (dn[k] != ~0ull ? 1u : 0u) << k;
+        for (int k = 0; k < 4; ++k)
+            lq |= ((MODE == 1 ? gs2m_ballot_b(thr[k] < 0.0f) != 0ull : dn[k] != ~0ull) ? 1u : 0u) << k;
         if (lq == 0u) break;
         gs2m_wait_dma();       // this batch's records have landed in s_raw
         gs2m_wave_sync();      // ... and the previous batch's staged instances have been read by every lane
         int nb_staged = 0;
+        bool batch_general = false;   // any staged instance of this batch needs the reference's power > 0 test / alpha cap
         {
             const float4 ra = s_raw[wave][0][lane], rb = s_raw[wave][1][lane], rc = s_raw[wave][2][lane];
             const bool have = base + (unsigned)lane < r1;
@@ -274,7 +285,9 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             }
             // general path (power > 0 test + alpha cap) only where it can matter: opacity near the 0.99 cap, or a conic so
             // close to singular that rounding could make the quadratic form negative
-            const bool general = !(op <= 0.98f) || !(ra.z > 0.0f && rb.x > 0.0f && det >= 1.0e-3f * ra.z * rb.x);
+            // MODE 1 applies the alpha cap to every instance (one v_min) and flags only the conics that need the power > 0 test
+            const bool singular = !(ra.z > 0.0f && rb.x > 0.0f && det >= 1.0e-3f * ra.z * rb.x);
+            const bool general = MODE == 1 ? singular : (!(op <= 0.98f) || singular);
             BlendInst bi;
             bi.a = ra;
             bi.b = rb;
@@ -284,6 +297,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             bi.b.y = lo;
             bi.c.x = rc.x;
             bi.c.y = __uint_as_float(m | (general ? 0x100u : 0u));
+            batch_general = gs2m_ballot_b(general && have && m != 0u) != 0ull;
             if (LROWS > 1) {
                 // the list also serves the other half of the 16 x 32 tile: stage only the instances that reach this
                 // half (ballot compaction), so the compositing loop never iterates over the others
@@ -320,9 +334,12 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         }
         // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
         // constants are in flight while instance j is composited (no LDS wait on the critical path).
-        auto step = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
-            const int qm = qmf & (int)lq;
-            if (qm != 0) {
+        auto step_body = [&](auto gen_tag, const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+            constexpr int GTAG = (int)decltype(gen_tag)::value;   // 0 / 1: compile-time, 2: the instance's flag (bit 8 of qmf)
+            constexpr bool GENERAL = GTAG == 1;
+            int qm = qmf & (int)lq;
+            GS2M_OPAQUE_SGPR(qm);   // one s_and per instance, then s_bitcmp per quadrant (not an s_and + s_cmp per quadrant)
+            {
                 const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
                 const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
                 const float nbdx[2] = {-(A.w * dx0), -(A.w * dx1)};
@@ -332,11 +349,38 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                         const float dy = A.y - ((k >> 1) ? pyf1 : pyf0);
                         // q = e + dy (c' dy - b' dx): two FMAs
                         const float qv = fmaf(fmaf(B.x, dy, nbdx[k & 1]), dy, e[k & 1]);
+                        if (MODE == 1) {
+                            if (qv >= thr[k]) {   // per-lane: the accumulate path runs under the execution mask
+                                float alpha = fminf(0.99f, gs2m_fast_exp2(qv));   // alpha cap (forward.cu:343), every instance
+                                if (GTAG == 1 || (GTAG == 2 && (qmf & 0x100))) {   // scalar branch (rare; the test fills a hazard slot)
+                                    // the reference's power > 0 skip (forward.cu:336-337), near-singular conics only:
+                                    // a skipped lane gets alpha = 0 (T' = T, not saturating, w = 0: no contribution)
+                                    GS2M_NO_IF_CONVERT();
+                                    alpha = qv > B.y ? 0.0f : alpha;
+                                }
+                                const float test_T = fmaf(-T[k], alpha, T[k]);
+                                float Tn = test_T;
+                                // a pixel saturates once, a quadrant is evaluated thousands of times: the saturation
+                                // bookkeeping sits behind a wave-uniform branch (no scalar ALU op: s_cbranch_vccz)
+                                if (gs2m_any_active_lane(test_T < 0.0001f)) {
+                                    GS2M_NO_IF_CONVERT();
+                                    const bool sat = test_T < 0.0001f;
+                                    thr[k] = sat ? THR_DONE : thr[k];      // finished: never a candidate again
+                                    Tn = sat ? T[k] : test_T;              // T stays the last accepted transmittance
+                                }
+                                const float wT = T[k] - Tn;
+                                C0[k] = fmaf(B.z, wT, C0[k]);
+                                C1[k] = fmaf(B.w, wT, C1[k]);
+                                C2[k] = fmaf(CL.x, wT, C2[k]);
+                                T[k] = Tn;
+                            }
+                            continue;
+                        }
                         const unsigned long long prem = gs2m_ballot_b(qv >= QMIN) & ~dn[k];   // v_cmp + s_andn2
                         if (prem != 0ull) {
                             float alpha = gs2m_fast_exp2(qv);
                             unsigned long long candm = prem;
-                            if (qmf & 0x100) {                                 // scalar branch: general path (rare)
+                            if (GTAG == 1 || (GTAG == 2 && (qmf & 0x100))) {  // scalar branch: general path (rare)
                                 GS2M_NO_IF_CONVERT();
                                 candm = prem & ~gs2m_ballot_b(qv > B.y);       // power > 0: skipped (forward.cu:336-337)
                                 alpha = fminf(0.99f, alpha);
@@ -355,30 +399,42 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 }
             }
         };
-        // The quadrant mask is read (= the LDS wait) BEFORE the next instance's reads are issued, so the
-        // wait never covers a read that was just issued (the compiler's waitcnt is lgkmcnt(0) in this loop).
-        const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
-        const float2* spc = &s_c[wave][0];
-        float4 A0 = spa[0], B0 = spb[0], A1, B1;
-        float2 K0 = spc[0], K1;
-        int j = 0;
-        for (; j + 1 < nb; j += 2) {
-            const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
-            GS2M_SCHED_BARRIER();
-            A1 = spa[j + 1];
-            B1 = spb[j + 1];
-            K1 = spc[j + 1];
-            GS2M_SCHED_BARRIER();
-            step(qm0, K0, A0, B0);
-            const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
-            GS2M_SCHED_BARRIER();
-            A0 = spa[j + 2];
-            B0 = spb[j + 2];
-            K0 = spc[j + 2];
-            GS2M_SCHED_BARRIER();
-            step(qm1, K1, A1, B1);
-        }
-        if (j < nb) step(gs2m_uniform((int)__float_as_uint(K0.y)), K0, A0, B0);
+        // The reference's power > 0 test and alpha cap are valid for every instance but only matter for the flagged ones
+        // (opacity near the cap, near-singular conic): a batch with a flagged instance runs the general copy of the loop,
+        // every other batch the short one -- one scalar branch per 64 instances instead of one per contributing quadrant.
+        // Software-pipelined broadcast reads, unrolled by two with ping-pong registers.  The quadrant mask is read (= the
+        // LDS wait) BEFORE the next instance's reads are issued, so the wait never covers a read that was just issued.
+        auto run_loop = [&](auto gen_tag) __attribute__((always_inline)) {
+            const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
+            const float2* spc = &s_c[wave][0];
+            float4 A0 = spa[0], B0 = spb[0], A1, B1;
+            float2 K0 = spc[0], K1;
+            int j = 0;
+            for (; j + 1 < nb; j += 2) {
+                const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
+                GS2M_SCHED_BARRIER();
+                A1 = spa[j + 1];
+                B1 = spb[j + 1];
+                K1 = spc[j + 1];
+                GS2M_SCHED_BARRIER();
+                if (qm0 & (int)lq) step_body(gen_tag, qm0, K0, A0, B0);
+                const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
+                GS2M_SCHED_BARRIER();
+                A0 = spa[j + 2];
+                B0 = spb[j + 2];
+                K0 = spc[j + 2];
+                GS2M_SCHED_BARRIER();
+                if (qm1 & (int)lq) step_body(gen_tag, qm1, K1, A1, B1);
+            }
+            if (j < nb) {
+                const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
+                if (qm0 & (int)lq) step_body(gen_tag, qm0, K0, A0, B0);
+            }
+        };
+        // one copy of the loop: the instance's flag (bit 8 of the mask word) selects the general path inside the body
+        // (a second copy of the loop for flagged batches costs ~12 registers: spills at 7 waves per SIMD)
+        (void)batch_general;
+        run_loop(std::integral_constant<int, 2>{});
     }
     gs2m_wait_dma();   // never leave with a DMA write to this workgroup's LDS in flight
     const size_t plane = (size_t)H * W;

@@ -1,11 +1,10 @@
 // raster_blend.hip -- compositing stage (default FMA contraction; VALU-bound inner loop).
 #include <cstdlib>
 #include "raster_blend.h"
-#include "raster_blend_mfma.h"
 #include "raster_internal.h"
 
 // gy = rows of the 16 x 16 reference grid; tile_rows = 16 x 16 tiles per instance list (GS2M_OPT_TILE_ROWS)
-//   variant 7: exponents on the matrix cores (k_blend_mfma), 4: all-VALU wave-per-tile kernel (k_blend_wave4e),
+//   variant 4: wave-per-tile kernel (k_blend_wave4e),
 //   0: the reference's structure (256-thread workgroup per tile, 1 pixel per lane; 16 x 16 lists only)
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P, unsigned cap,
@@ -18,12 +17,6 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
     size_t pad = 0;
     if (wg_per_cu > 0 && wg_per_cu < 7) pad = ((size_t)(160 * 1024) / (size_t)wg_per_cu - 22848) & ~(size_t)255;
     const dim3 grid((tiles + 3) / 4, nv), block(256);
-    if (variant == 7) {
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_mfma<4, 2, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
-        else GS2M_LAUNCH((k_blend_mfma<4, 1, 0>), grid, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
-        return 0;
-    }
-
     if (variant == 4) {
         static const int lpt = getenv("GS2M_BLEND_LPT") ? atoi(getenv("GS2M_BLEND_LPT")) : 1;  // tuning knob: 0 = XCD-contiguous tile ranges
         const unsigned* ord = lpt ? order : nullptr;
@@ -31,6 +24,17 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
         // schedule: ceil(chunks / 8) chunks per XCD, GS2M_SCHED_CHUNK lists per chunk, tile_rows waves per list, 4 waves per workgroup
         const int nch = ((gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW) * ((ltiles / gx + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
         const dim3 g2(ord ? 8u * ((unsigned)(((nch + 7) / 8) * GS2M_SCHED_CHUNK * tile_rows + 3) / 4u) : grid.x, nv);
+        static const int mode = getenv("GS2M_BLEND_MODE") ? atoi(getenv("GS2M_BLEND_MODE")) : 0;   // development A/B knob
+        if (mode == 2) {   // MODE 1 at 6 waves per SIMD (80 VGPRs)
+            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 6, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 6, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+            return 0;
+        }
+        if (mode == 1) {
+            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+            return 0;
+        }
         if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
         else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
         return 0;
@@ -39,6 +43,6 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
         GS2M_LAUNCH(k_blend_tile256, dim3(gx, gy, nv), dim3(256), 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank);
         return 0;
     }
-    gs2m_set_error("blend variant %d is not available with GS2M_OPT_TILE_ROWS %d (variants: 0 [rows 1 only], 4, 7)", variant, tile_rows);
+    gs2m_set_error("blend variant %d is not available with GS2M_OPT_TILE_ROWS %d (variants: 0 [rows 1 only], 4)", variant, tile_rows);
     return 1;
 }

@@ -73,6 +73,46 @@ def synth_v1(P, seed, log_s_mu):
                 opacity=opacity)
 
 
+def trained_like(P, seed, log_s_mu, focal=2900.0, ring_radius=3.5):
+    """Gaussians with the statistics of a TRAINED splat that ``synth_v1`` lacks (same layout): strongly anisotropic
+    scales (10-100 : 1, surface-aligned discs and needles), 30 % of the opacities saturated at sigmoid >= 0.985 (the
+    reference's 0.99 alpha cap, forward.cu:343), a mass of near-transparent ones, 0.1 % background splats whose screen
+    radius exceeds 300 px (hundreds of tiles each: the > 64-tile walk of the binning), most centres on a surface shell,
+    duplicated centres (exact depth ties in every view) and SH rest coefficients large enough to clamp colours at 0."""
+    rng = np.random.default_rng(seed)
+    n_shell = int(0.7 * P)
+    d = rng.normal(size=(n_shell, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    shell = d * (0.6 + rng.normal(0.0, 0.01, size=(n_shell, 1)))
+    xyz = np.concatenate([shell, rng.uniform(-1.0, 1.0, size=(P - n_shell, 3))]).astype(np.float32)
+    n_dup = max(2, P // 50)                                   # exact depth ties: copies of other centres
+    dst = rng.choice(P, n_dup, replace=False)
+    xyz[dst] = xyz[rng.choice(P, n_dup)]
+    scaling = rng.normal(log_s_mu, 0.5, size=(P, 3))
+    thin = rng.integers(1, 3, size=P)                         # 1 thin axis = disc, 2 = needle
+    ratio = np.log(rng.uniform(10.0, 100.0, size=P))
+    for a in range(3):
+        scaling[:, a] -= np.where((a < thin), ratio, 0.0)
+    perm = np.argsort(rng.random((P, 3)), axis=1)             # which axes are the thin ones
+    scaling = np.take_along_axis(scaling, perm, axis=1)
+    n_big = max(1, P // 1000)                                 # background splats: radius = 3 sigma f / z > 300 px
+    big = rng.choice(P, n_big, replace=False)
+    sigma = rng.uniform(1.0, 2.0, size=n_big) * 300.0 * ring_radius / (3.0 * focal)
+    scaling[big, 0] = np.log(sigma)
+    scaling[big, 1] = np.log(sigma * rng.uniform(0.3, 1.0, size=n_big))
+    scaling[big, 2] = np.log(sigma * 0.01)
+    u = rng.random(P)
+    o = np.where(u < 0.30, rng.uniform(0.985, 0.9997, size=P),
+                 np.where(u < 0.60, rng.uniform(0.004, 0.1, size=P), rng.uniform(0.1, 0.98, size=P)))
+    o[big] = rng.uniform(0.02, 0.3, size=n_big)
+    opacity = np.log(o / (1.0 - o)).astype(np.float32).reshape(P, 1)
+    rotation = rng.normal(0.0, 1.0, size=(P, 4)).astype(np.float32)
+    f_dc = RGB2SH(rng.uniform(0.0, 1.0, size=(P, 1, 3))).astype(np.float32)
+    f_rest = rng.normal(0.0, 0.15, size=(P, 15, 3)).astype(np.float32)
+    return dict(xyz=xyz, features_dc=f_dc, features_rest=f_rest, scaling=scaling.astype(np.float32), rotation=rotation,
+                opacity=opacity)
+
+
 def ring_pose(azimuth, radius=3.5):
     """COLMAP world->camera [R|t] of a camera on a horizontal ring looking at the origin,
     up = -y (COLMAP: +x right, +y down, +z forward)."""

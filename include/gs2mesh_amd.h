@@ -67,11 +67,11 @@ enum {
                                      (DGR/cuda_rasterizer/auxiliary.h:46-56), 1 = also drop
                                      (Gaussian,tile) instances whose alpha < 1/255 on the
                                      whole tile (image unchanged, num_rendered smaller)   */
-    GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 7 = one wave per 16x16 tile, exponents of the
-                                     (pixel, instance) pairs computed on the matrix cores (bf16x3 split,
-                                     fp32 accumulate); 4 = the same wave-per-tile layout, all VALU;
+    GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 4 (default) = one wave per 16x16 tile, 4 pixels per lane;
                                      0 = the reference's structure (16x16 tile per 256-thread workgroup,
-                                     1 px/lane; GS2M_OPT_TILE_ROWS 1 only).  Same image (to rounding). */
+                                     1 px/lane; GS2M_OPT_TILE_ROWS 1 only).  Same image (to rounding).
+                                     (7, exponents on the matrix cores, was removed in round 3: slower than 4
+                                     and wrong on strongly anisotropic splats -- DESIGN.md 3.) */
     GS2M_OPT_DEBUG_SYNC = 3,      /* 1 = synchronise + check after every launch (the
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4,    /* 1 = bracket every stage launch with hipEvents on the

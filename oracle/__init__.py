@@ -81,6 +81,8 @@ def raster_lib():
         lib.oracle_rasterize_forward.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp,
                                                  vp, C.c_float, vp, vp, vp, vp, vp, C.c_float, C.c_float,
                                                  C.c_int, vp, vp]
+        lib.oracle_render_flip_bounds.restype = None
+        lib.oracle_render_flip_bounds.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp]
         lib.oracle_tile_may_contribute.restype = C.c_int
         lib.oracle_tile_may_contribute.argtypes = [C.c_float] * 6 + [C.c_int, C.c_int]
         _raster = lib
@@ -186,6 +188,25 @@ def render(W, H, ranges, point_list, means2D, features, conic_opacity, bg):
                       _ptr(np.ascontiguousarray(conic_opacity, np.float32)),
                       _ptr(np.ascontiguousarray(bg, np.float32)), _ptr(out), _ptr(final_T), _ptr(n_contrib))
     return out, final_T, n_contrib
+
+
+def render_flip_bounds(W, H, ranges, point_list, means2D, conic_opacity, cmax, rel_eps=1e-5):
+    """Replay of renderCUDA's three threshold decisions (power > 0, alpha < 1/255, T(1-alpha) < 1e-4): per pixel, the
+    number of decisions taken within ``rel_eps`` of their threshold and a bound on the change of the pixel if an
+    implementation with different last-ulp rounding takes the other side (oracle_render_flip_bounds).
+    -> dict(n_alpha[H,W], n_T[H,W], n_power[H,W] u16, bound[H,W] f32, cond[H,W] f32 = the reference's own rounding noise
+    on ill-conditioned evaluations: 2 alpha T cmax x 2^-22 x the largest term of `power`, where that exceeds rel_eps)."""
+    lib = raster_lib()
+    out = dict(n_alpha=np.zeros((H, W), np.uint16), n_T=np.zeros((H, W), np.uint16), n_power=np.zeros((H, W), np.uint16),
+               bound=np.zeros((H, W), np.float32), cond=np.zeros((H, W), np.float32))
+    pl = np.ascontiguousarray(point_list, np.uint32)
+    if pl.size == 0:
+        pl = np.zeros(1, np.uint32)
+    lib.oracle_render_flip_bounds(int(W), int(H), _ptr(np.ascontiguousarray(ranges, np.uint32)), _ptr(pl),
+                                  _ptr(np.ascontiguousarray(means2D, np.float32)),
+                                  _ptr(np.ascontiguousarray(conic_opacity, np.float32)), float(rel_eps), float(cmax),
+                                  _ptr(out["n_alpha"]), _ptr(out["n_T"]), _ptr(out["n_power"]), _ptr(out["bound"]), _ptr(out["cond"]))
+    return out
 
 
 def rasterize_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, bg,

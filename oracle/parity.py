@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import activate, rasterize_forward, ref_available, ref_forward
+from . import activate, bin_instances, preprocess, rasterize_forward, ref_available, ref_forward, render_flip_bounds
 
 
 def quantize_u8(img_chw: np.ndarray) -> np.ndarray:
@@ -33,6 +33,40 @@ def image_parity(img: np.ndarray, ref: np.ndarray, rgb8: np.ndarray | None = Non
     return out
 
 
+CLEAN_BAR = 2e-4     # max |delta| of the fp32 image where no threshold decision can flip
+
+
+def flip_attribution(g: dict, cam, W: int, H: int, img: np.ndarray, ref: np.ndarray, bg=(0.0, 0.0, 0.0),
+                     rel_eps: float = 1e-5) -> dict:
+    """Turns "max |delta| is one threshold flip" into a checked statement.  From the oracle's own projection and
+    instance lists (the reference's, bit for bit) `render_flip_bounds` finds every (pixel, instance) decision of
+    renderCUDA taken within ``rel_eps`` of its threshold and bounds the change a flip can cause.  Returns the split
+    figures; ``ok`` = max |delta| <= CLEAN_BAR on pixels without a candidate AND |delta| <= CLEAN_BAR + bound elsewhere,
+    where bound = flips + the reference's own rounding noise on ill-conditioned evaluations (`cond`, see the C source)."""
+    s, q, o = activate(g["scaling"], g["rotation"], g["opacity"])
+    shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+    geom = preprocess(g["xyz"], s, q, o, shs, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                      cam.tanfovx, cam.tanfovy)
+    pl, ranges = bin_instances(geom, W, H)
+    cmax = float(max(1.0, float(geom["rgb"].max(initial=0.0)), float(np.max(bg))))
+    fb = render_flip_bounds(W, H, ranges, pl, geom["means2D"], geom["conic_opacity"], cmax, rel_eps)
+    d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64)).max(axis=0)     # [H,W], worst channel
+    cand = (fb["bound"] > 0) | (fb["cond"] > CLEAN_BAR / 4)
+    clean_max = float(d[~cand].max()) if (~cand).any() else 0.0
+    excess = d - (CLEAN_BAR + 1.01 * (fb["bound"].astype(np.float64) + fb["cond"].astype(np.float64)))
+    excess_nocond = d - (CLEAN_BAR + 1.01 * fb["bound"].astype(np.float64))
+    worst = np.argsort(excess.ravel())[::-1][:4]
+    detail = [dict(y=int(i // W), x=int(i % W), delta=float(d.ravel()[i]), bound=float(fb["bound"].ravel()[i]),
+                   cond=float(fb["cond"].ravel()[i])) for i in worst if excess.ravel()[i] > 0]
+    return dict(flip_pixels=int(cand.sum()), ill_conditioned_pixels=int((fb["cond"] > CLEAN_BAR / 4).sum()),
+                unexplained_without_conditioning=int((excess_nocond > 0).sum()), worst_unexplained=detail, flip_pixels_alpha=int((fb["n_alpha"] > 0).sum()),
+                flip_pixels_T=int((fb["n_T"] > 0).sum()), flip_pixels_power=int((fb["n_power"] > 0).sum()),
+                max_abs_clean=clean_max, max_abs_flip=float(d[cand].max()) if cand.any() else 0.0,
+                pixels_over_clean_bar=int((d > CLEAN_BAR).sum()), unexplained_pixels=int((excess > 0).sum()),
+                worst_excess=float(excess.max()), rel_eps=rel_eps, clean_bar=CLEAN_BAR,
+                ok=bool(clean_max <= CLEAN_BAR and (excess <= 0).all()))
+
+
 def oracle_eye(g: dict, cam, W: int, H: int, bg=(0.0, 0.0, 0.0), prefer_reference: bool = True) -> dict:
     """Render one eye of pre-activation Gaussians ``g`` (numpy, GaussianModel layout) on the CPU: with the
     reference's own kernels (oracle/_ref, when prebuilt) or with the restated oracle (bit-identical, slower).
@@ -51,7 +85,7 @@ def oracle_eye(g: dict, cam, W: int, H: int, bg=(0.0, 0.0, 0.0), prefer_referenc
 
 
 def pair_parity(g: dict, cams, W: int, H: int, color: np.ndarray, rgb8: np.ndarray | None = None,
-                radii: np.ndarray | None = None, bg=(0.0, 0.0, 0.0)) -> dict:
+                radii: np.ndarray | None = None, bg=(0.0, 0.0, 0.0), flips: bool = False) -> dict:
     """Parity of one rendered stereo pair.  ``cams`` = (left, right) graphics.Camera, ``color`` [2,3,H,W],
     ``rgb8`` [2,H,W,3] or None, ``radii`` [2,P] or None.  Worst case over the two eyes for every figure."""
     eyes = []
@@ -60,6 +94,14 @@ def pair_parity(g: dict, cams, W: int, H: int, color: np.ndarray, rgb8: np.ndarr
         e = image_parity(color[v], o["color"], None if rgb8 is None else rgb8[v])
         if radii is not None:
             e["radii_mismatches"] = int((np.asarray(radii[v]) != o["radii"]).sum())
+        if flips:
+            fa = flip_attribution(g, cam, W, H, color[v], o["color"], bg)
+            for k in ("flip_pixels", "ill_conditioned_pixels", "max_abs_clean", "max_abs_flip", "unexplained_pixels",
+                      "unexplained_without_conditioning", "pixels_over_clean_bar"):
+                e[k] = fa[k]
+            if fa["worst_unexplained"]:
+                e["worst_unexplained"] = str(fa["worst_unexplained"])
+            e["flips_ok"] = int(fa["ok"])
         e["oracle"] = o["kind"]
         e["oracle_num_rendered"] = o["num_rendered"]
         eyes.append(e)
@@ -68,8 +110,10 @@ def pair_parity(g: dict, cams, W: int, H: int, color: np.ndarray, rgb8: np.ndarr
         for k, val in e.items():
             if k == "psnr_db":
                 worst[k] = min(worst[k], val)
-            elif k in ("oracle", "n_values"):
+            elif k in ("oracle", "n_values", "worst_unexplained"):
                 continue
+            elif k == "flips_ok":
+                worst[k] = min(worst[k], val)
             elif k == "oracle_num_rendered":
                 worst[k] = [eyes[0][k], val]
             else:

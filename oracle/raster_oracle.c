@@ -436,6 +436,82 @@ void oracle_render(int W, int H, const uint32_t* ranges, const uint32_t* point_l
  * Optional taps (may be NULL): radii[P], and the geometry buffers.  Returns num_rendered.
  * P == 0 writes nothing (the caller zero-fills out_color: rasterize_points.cu:68,81).
  */
+/* ---------------------------------------------------------------------------------------------
+ * Flip attribution (test infrastructure of the parity tests; no counterpart in the reference).
+ * renderCUDA (forward.cu:330-362) takes three per-(pixel, instance) DECISIONS on fp32 values:
+ *     power > 0 -> skip,    alpha < 1/255 -> skip,    T(1 - alpha) < 1e-4 -> stop.
+ * An implementation whose exp / products differ from libm's in the last ulps takes the other side of a
+ * decision when the value sits within its rounding error of the threshold; the image then changes by the
+ * size of the dropped / added contribution, not by a rounding error.  This pass replays the reference
+ * loop and, per pixel, counts the decisions taken within `rel_eps` of their threshold and bounds the
+ * change a flip of each can cause:
+ *     alpha / power candidate:  2 * alpha * T * cmax   (its own contribution + the (1 - alpha) factor on
+ *                                                        everything behind it, which sums to <= T * cmax)
+ *     T candidate:              T * cmax               (everything behind the stop, background included)
+ * cmax = largest colour value that can multiply a weight (features and background).  A parity test can
+ * then assert the rounding-level bar on the pixels with bound == 0 and |delta| <= bound elsewhere.
+ * Conditioning: `power` is a sum of three products that cancel along the ridge of a long thin splat (terms
+ * ~1e5 for a result ~1 at 300 px from the centre of a background splat): ANY fp32 evaluation order, the
+ * reference's included, is then only good to ~4 ulps of the largest term (pscale), i.e. alpha to a relative
+ * kappa * pscale with kappa = 2^-22.  cond[pixel] sums 2 * alpha * T * cmax * kappa * pscale over the
+ * evaluations where that exceeds rel_eps: the part of |delta| that is the reference's own rounding noise.
+ * ------------------------------------------------------------------------------------------- */
+void oracle_render_flip_bounds(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                               const float* means2D, const float* conic_opacity, float rel_eps, float cmax,
+                               uint16_t* n_alpha, uint16_t* n_T, uint16_t* n_power, float* bound, float* cond) {
+    const int gx = (W + BLOCK_X - 1) / BLOCK_X;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int py = 0; py < H; ++py) {
+        for (int px = 0; px < W; ++px) {
+            const int tile = (py / BLOCK_Y) * gx + (px / BLOCK_X);
+            const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+            const float pixf[2] = {(float)px, (float)py};
+            float T = 1.0f;
+            unsigned ca = 0, cT = 0, cp = 0;
+            double b = 0.0, cnd = 0.0;
+            for (uint32_t k = r0; k < r1; ++k) {
+                const uint32_t g = point_list[k];
+                float dx = means2D[2 * g] - pixf[0];
+                float dy = means2D[2 * g + 1] - pixf[1];
+                const float* co = conic_opacity + 4 * (size_t)g;
+                float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                /* |power| within the rounding of its three products of the sign change */
+                const float pscale = 0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy);
+                /* relative band of alpha in THIS evaluation: rel_eps, or the reference's own rounding noise on an ill-conditioned
+                 * sum (an absolute error kappa * pscale of power = that relative error of alpha) */
+                const float rel_c = pscale * (1.0f / 4194304.0f);   /* kappa = 2^-22 */
+                const float eps_i = rel_c > rel_eps ? (rel_c < 0.5f ? rel_c : 0.5f) : rel_eps;
+                const int near_p = pscale > 0.0f && fabsf(power) <= rel_eps * pscale;   /* dx = dy = 0: exactly 0 for everyone */
+                if (near_p) {
+                    cp++;
+                    b += 2.0 * (double)fminf(0.99f, co[3]) * T * cmax;
+                }
+                if (power > 0.0f) continue;
+                float alpha = fminf(0.99f, co[3] * expf(power));
+                if (fabsf(alpha - 1.0f / 255.0f) <= eps_i * (1.0f / 255.0f)) {
+                    ca++;
+                    b += 2.0 * (double)alpha * T * cmax;
+                }
+                if (alpha < 1.0f / 255.0f) continue;
+                if (rel_c > rel_eps) cnd += 2.0 * (double)alpha * T * cmax * eps_i;
+                float test_T = T * (1 - alpha);
+                if (fabsf(test_T - 0.0001f) <= rel_eps * 0.0001f * 100.0f) { /* T carries the rounding of every (1 - alpha) before it */
+                    cT++;
+                    b += (double)T * cmax;
+                }
+                if (test_T < 0.0001f) break;
+                T = test_T;
+            }
+            const size_t pix_id = (size_t)W * py + px;
+            n_alpha[pix_id] = (uint16_t)(ca > 65535u ? 65535u : ca);
+            n_T[pix_id] = (uint16_t)(cT > 65535u ? 65535u : cT);
+            n_power[pix_id] = (uint16_t)(cp > 65535u ? 65535u : cp);
+            bound[pix_id] = (float)b;
+            if (cond) cond[pix_id] = (float)cnd;
+        }
+    }
+}
+
 int64_t oracle_rasterize_forward(int P, int D, int M, const float* background, int W, int H,
                                  const float* means3D, const float* shs,
                                  const float* colors_precomp, const float* opacities,

@@ -82,6 +82,7 @@ static inline void __threadfence_block() {}
 static inline int gs2m_syncthreads_count(int pred) { return ::emu::sync_count(pred); }
 static inline unsigned long long gs2m_ballot(int pred) { return ::emu::ballot(pred); }
 static inline unsigned long long gs2m_ballot_b(bool pred) { return ::emu::ballot(pred ? 1 : 0); }
+static inline bool gs2m_any_active_lane(bool) { return true; }   // divergent code: not a collective here (see hip/platform.h)
 static inline bool gs2m_lanes(unsigned long long mask) { return (mask >> ::emu::lane()) & 1ull; }
 static inline void gs2m_wave_sync() { (void)::emu::ballot(0); }
 static inline int gs2m_uniform(int v) { return v; }
@@ -114,50 +115,10 @@ static inline float gs2m_fast_exp2(float x) { return exp2f(x); }
 static inline float gs2m_fast_log2(float x) { return log2f(x); }
 #define GS2M_KEEP_F32(x) ((void)0)
 #define GS2M_NO_IF_CONVERT() ((void)0)
+#define GS2M_OPAQUE_SGPR(x) ((void)0)
 #define GS2M_SCHED_BARRIER() ((void)0)
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 static inline int __ffsll(unsigned long long m) { return __builtin_ffsll((long long)m); }
-
-// ---- matrix cores / half-wave swap (emulated as wave collectives) ---------------------------
-struct gs2m_f32x16 {
-    float v[16];
-    float& operator[](int i) { return v[i]; }
-    const float& operator[](int i) const { return v[i]; }
-};
-static inline float emu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
-static inline gs2m_f32x16 gs2m_mfma_32x32x16_bf16(uint4 a, uint4 b, gs2m_f32x16 c) {
-    struct { uint4 a, b; } mine = {a, b}, all[64];
-    ::emu::wave_gather(&mine, sizeof(mine), all);
-    const int l = ::emu::lane();
-    gs2m_f32x16 d = c;
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
-        float acc = c.v[r];
-        for (int g = 0; g < 2; ++g) {
-            unsigned short ea[8], eb[8];
-            memcpy(ea, &all[row + 32 * g].a, 16);
-            memcpy(eb, &all[col + 32 * g].b, 16);
-            for (int e = 0; e < 8; ++e) acc += emu_bf16_to_f32(ea[e]) * emu_bf16_to_f32(eb[e]);
-        }
-        d.v[r] = acc;
-    }
-    return d;
-}
-static inline void gs2m_permlane32_swap(unsigned& a, unsigned& b) {
-    struct { unsigned a, b; } mine = {a, b}, all[64];
-    ::emu::wave_gather(&mine, sizeof(mine), all);
-    const int l = ::emu::lane();
-    if (l < 32) b = all[l + 32].a;   // a' = [a.lo | b.lo], b' = [a.hi | b.hi]
-    else a = all[l - 32].b;
-}
-static inline void gs2m_permlane32_swap(float& a, float& b) {
-    unsigned x, y;
-    memcpy(&x, &a, 4);
-    memcpy(&y, &b, 4);
-    gs2m_permlane32_swap(x, y);
-    memcpy(&a, &x, 4);
-    memcpy(&b, &y, 4);
-}
 
 static inline void gs2m_global_load_lds16(const void* g, void* lds_base) { memcpy((char*)lds_base + 16 * ::emu::lane(), g, 16); }
 static inline void gs2m_wait_dma() {}

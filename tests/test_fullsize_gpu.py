@@ -41,7 +41,7 @@ def test_c2_stereo_pair_vs_oracle_and_invariants():
     assert np.array_equal(c["color"].cpu().numpy(), img)
     assert max(c["num_rendered"]) < 0.8 * max(n_ref_mode)
     # every compositing kernel variant agrees to rounding
-    for variant in (0, 4, 7):
+    for variant in (0, 4):
         R.set_option(_lib.OPT_BLEND_VARIANT, variant)
         d = R.render_views(gd, pair)["color"].cpu().numpy()
         diff = np.abs(d - img)
@@ -141,15 +141,10 @@ BENCH_PARITY_BOUNDS = {
     # mean 3.0e-8, PSNR 130.8 dB, 1.6e-6, 26 pixels, 1 radius
     ("C2", 4): dict(max_abs=5e-3, mean_abs=1e-7, psnr_db=111.0, frac_gt_1e5=1.6e-5, u8_flipped_pixels=140, radii_mismatches=2),
     ("C3", 4): dict(max_abs=8e-4, mean_abs=6e-8, psnr_db=127.0, frac_gt_1e5=3.2e-6, u8_flipped_pixels=52, radii_mismatches=2),
-    # exponents on the matrix cores (blend 7: bf16x3 split, fp32 accumulate -> ~1e-7 of the largest polynomial term instead
-    # of ~1e-7 of q).  Measured r2b: C2 max 2.0e-3, mean 4.8e-8, PSNR 115.8 dB, 6.9e-6, 71 pixels;  C3 (sharp 1.3-px
-    # Gaussians: larger terms) max 1.35e-3, mean 5.3e-8, PSNR 121.8 dB, 6.5e-6, 44 pixels
-    ("C2", 7): dict(max_abs=5e-3, mean_abs=1e-7, psnr_db=111.0, frac_gt_1e5=1.6e-5, u8_flipped_pixels=142, radii_mismatches=2),
-    ("C3", 7): dict(max_abs=2.7e-3, mean_abs=1.1e-7, psnr_db=118.5, frac_gt_1e5=1.3e-5, u8_flipped_pixels=88, radii_mismatches=2),
 }
 
 
-@pytest.mark.parametrize("blend", [7, 4])
+@pytest.mark.parametrize("blend", [4])
 @pytest.mark.parametrize("cfg_name", ["C2", "C3"])
 def test_bench_configuration_full_size_vs_oracle(cfg_name, blend):
     """RenderFusePipeline(inflight=4) + 16x32 binning tiles + exact tile cull + packed SH + fused raw activations
@@ -183,13 +178,17 @@ def test_bench_configuration_full_size_vs_oracle(cfg_name, blend):
     for slot, i in sorted(kept.items())[:2]:                      # two of the four views still held by the slots
         color = pipe.color[slot].cpu().numpy()
         rgb8 = pipe.rgb8[slot].cpu().numpy()
-        m = parity.pair_parity(g, cams[i], W, H, color, rgb8, radii0 if i == 0 else None)
+        m = parity.pair_parity(g, cams[i], W, H, color, rgb8, radii0 if i == 0 else None, flips=(blend == 4))
         m["view"] = i
         if worst is None:
             worst = m
         else:
-            for k in ("max_abs", "mean_abs", "frac_gt_1e5", "frac_gt_1e4", "u8_flipped_pixels", "u8_flipped_values", "u8_max_lsb"):
-                worst[k] = max(worst[k], m[k])
+            for k in ("max_abs", "mean_abs", "frac_gt_1e5", "frac_gt_1e4", "u8_flipped_pixels", "u8_flipped_values", "u8_max_lsb",
+                      "flip_pixels", "max_abs_clean", "max_abs_flip", "unexplained_pixels", "pixels_over_clean_bar"):
+                if k in m:
+                    worst[k] = max(worst[k], m[k])
+            if "flips_ok" in m:
+                worst["flips_ok"] = min(worst["flips_ok"], m["flips_ok"])
             worst["psnr_db"] = min(worst["psnr_db"], m["psnr_db"])
     # radii of the prepare() render of view 0 (fused exp / normalize / sigmoid vs numpy's)
     o0 = [parity.oracle_eye(g, c, W, H) for c in cams[0]]
@@ -207,6 +206,54 @@ def test_bench_configuration_full_size_vs_oracle(cfg_name, blend):
     assert worst["frac_gt_1e5"] <= b["frac_gt_1e5"], worst
     assert worst["u8_flipped_pixels"] <= b["u8_flipped_pixels"] and worst["u8_max_lsb"] <= 1, worst
     assert worst["radii_mismatches"] <= b["radii_mismatches"], worst
+    if blend == 4:
+        # the CHECKED form of "the outliers are threshold flips" (oracle/parity.py:flip_attribution): SURVEY.md 8(c)'s
+        # max |delta| <= 2e-4 holds on every pixel where no decision of renderCUDA sits within 1e-5 of its threshold, and
+        # every other pixel stays within the bound of the contributions that can flip
+        assert worst["flips_ok"] == 1 and worst["unexplained_pixels"] == 0 and worst["max_abs_clean"] <= 2e-4, worst
+
+
+def test_trained_like_splats_full_size_vs_reference_kernels():
+    """C2-sized `synthetic.trained_like` model (anisotropy 10-100 : 1, 30 % of the opacities at the 0.99 cap, 0.1 % splats
+    wider than 300 px, depth ties) through the bench's configuration -- RenderFusePipeline, 16 x 32 binning tiles, exact
+    tile cull, fused raw activations -- against the reference's own kernels (oracle/_ref) at 1600 x 1200, with the flip
+    attribution as the image bar.  This is the path the isotropic `synth_v1` scenes do not stress: the flagged `general`
+    compositing branch and the > 64-tile wave walk of the binning."""
+    import json
+    import os
+    import torch
+    from oracle import parity
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    from gs2mesh_amd.rasterizer import camera_from
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = synthetic.CONFIGS["C2"]
+    W, H = cfg.width, cfg.height
+    g = synthetic.trained_like(cfg.P, 4242, cfg.log_s_mu, focal=cfg.focal, ring_radius=cfg.ring_radius)
+    gd = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    gd["raw"] = True
+    poses = synthetic.ring_poses(2, cfg.ring_radius, 3, cfg.n_pairs)
+    cams = [synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline) for p in poses]
+    pipe = RenderFusePipeline(gd, W, H, None, None, inflight=2, device=0, exact_tile_cull=1, tile_rows=2)
+    ccams = [[camera_from(l), camera_from(r)] for l, r in cams]
+    first = pipe.prepare(ccams[0], headroom=2.0)
+    radii0 = first["radii"].cpu().numpy()
+    assert radii0.max() > 300                                      # the background splats are there
+    slots = [pipe.submit(c) for c in ccams]
+    pipe.finish()
+    color = pipe.color[slots[1]].cpu().numpy()
+    rgb8 = pipe.rgb8[slots[1]].cpu().numpy()
+    m = parity.pair_parity(g, cams[1], W, H, color, rgb8, None, flips=True)
+    o0 = [parity.oracle_eye(g, c, W, H) for c in cams[0]]
+    m["radii_mismatches"] = int(max((radii0[v] != o0[v]["radii"]).sum() for v in range(2)))
+    m["num_rendered_reference_lists"] = [o["num_rendered"] for o in o0]
+    m["num_rendered"] = [int(x) for x in first["num_rendered"]]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "parity_C2_trained_like.json"), "w") as fh:
+        json.dump(m, fh, indent=1)
+    print("PARITY trained_like", json.dumps(m))
+    assert m["flips_ok"] == 1 and m["unexplained_pixels"] == 0 and m["max_abs_clean"] <= 2e-4, m
+    assert m["psnr_db"] >= 100.0 and m["u8_max_lsb"] <= 1 and m["radii_mismatches"] <= 4, m
 
 
 def test_c2_tile_rows_2_is_bit_identical_to_tile_rows_1():

@@ -322,7 +322,7 @@ def test_argument_validation_errors(backend):
         r.forward(*base, colors_precomp=d(np.ones((4, 3), np.float32)))
 
 
-@pytest.mark.parametrize("variant", [0, 4, 7])
+@pytest.mark.parametrize("variant", [0, 4])
 def test_blend_variants_match_the_oracle(backend, variant):
     """Every compositing kernel variant (GS2M_OPT_BLEND_VARIANT) on a ragged image, a crowded
     saturating tile stack and with exact culling on."""
@@ -513,11 +513,13 @@ def test_hip_path_against_reference_golden(backend):
 
 @pytest.mark.parametrize("env", [{"GS2M_NWG_TARGET": "2", "GS2M_MAX_WG_THREADS": "128"},
                                  {"GS2M_NWG_TARGET": "3", "GS2M_MAX_WG_THREADS": "1024"},
-                                 {"GS2M_NWG_TARGET": "64", "GS2M_MAX_WG_THREADS": "64"}])
+                                 {"GS2M_NWG_TARGET": "64", "GS2M_MAX_WG_THREADS": "64"},
+                                 {"GS2M_BLEND_MODE": "1"}])
 def test_workgroup_geometry_knobs_do_not_change_results(env):
     """k_count_tiles / k_scatter with few large workgroup chunks (several loop iterations per workgroup, partial last
     iteration) and with small workgroups: same records, instance lists and image as the reference golden.  The knobs are
-    read once per process, hence the subprocess (emulator build of the kernel sources)."""
+    read once per process, hence the subprocess (emulator build of the kernel sources).  GS2M_BLEND_MODE=1: the
+    compositing loop without lane masks in scalar registers (execution-mask form, raster_blend.h MODE 1)."""
     import os
     import subprocess
     import sys
@@ -661,3 +663,69 @@ def test_4k_image_tile_cursors_fit_the_lds(backend, rows):
     if rows == 1:
         assert r.last_num_rendered == ref_n
     assert_image_close(be.host(img), ref_img)
+
+
+@pytest.mark.parametrize("rows,cull", [(1, 0), (2, 1)])
+def test_trained_like_splats_with_flip_attribution(backend, rows, cull):
+    """`synthetic.trained_like`: anisotropy 10-100 : 1, 30 % of the opacities at the 0.99 alpha cap, background splats
+    hundreds of tiles wide, exact depth ties.  Projected record / instance lists bit-exact as for the isotropic scenes;
+    the image is held to the CHECKED statement (oracle/parity.py:flip_attribution): |delta| <= 2e-4 wherever no
+    threshold decision of renderCUDA (forward.cu:336-350) sits within 1e-5 of its threshold, and within the bound of
+    the flipped contribution elsewhere."""
+    from oracle import parity
+    W, H, f = 200, 136, 180.0
+    P = 5000
+    g = synthetic.trained_like(P, 23, math.log(0.03), focal=f)
+    s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
+    shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+    assert (o >= 0.985).mean() > 0.25 and (s.max(axis=1) / s.min(axis=1) > 10).mean() > 0.9
+    pose = synthetic.ring_pose(0.3, 3.5)
+    pose = np.concatenate([pose[0], pose[1][:, None]], axis=1)
+    cam, _ = synthetic.stereo_cameras(pose, W, H, f, f, 0.245)
+    bg = [0.2, 0.1, 0.3]
+    be = backend
+    d = be.dev
+    r = Rasterizer(0, lib=be.lib)
+    r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+    r.set_option(_lib.OPT_TILE_ROWS, rows)
+    img, radii = r.forward(d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                           d(np.asarray(bg, np.float32)), W, H, cam.tanfovx, cam.tanfovy, shs=d(shs), scales=d(s), rotations=d(q))
+    img, radii = be.host(img), be.host(radii)
+    ref_img, ref_radii, ref_n = oracle_forward(cam, g["xyz"], o, bg, shs=shs, scales=s, rotations=q)
+    np.testing.assert_array_equal(radii, ref_radii)
+    assert ref_radii.max() > 150 and (ref_radii > 0).sum() > 3000          # background splats: hundreds of tiles
+    if rows == 1 and cull == 0:
+        assert r.last_num_rendered == ref_n
+        n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        geom_ref = oracle.preprocess(g["xyz"], s, q, o, shs, cam.world_view_transform, cam.full_proj_transform,
+                                     cam.camera_center, W, H, cam.tanfovx, cam.tanfovy)
+        pl, ranges = r.download_binning(0, ref_n, n_tiles)
+        ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+        np.testing.assert_array_equal(ranges, ref_ranges)
+        np.testing.assert_array_equal(pl, ref_pl)                           # depth ties resolved in id order
+    graw = dict(g)
+    fa = parity.flip_attribution(graw, cam, W, H, img, ref_img, bg)
+    assert fa["ok"], fa
+    assert fa["max_abs_clean"] <= 2e-4, fa
+    assert_image_close(img, ref_img, frac_tol=3e-4)
+
+
+def test_flip_bounds_count_the_decisions_at_their_thresholds():
+    """oracle_render_flip_bounds on hand-made cases: an alpha exactly at 1/255, a transmittance product exactly at 1e-4,
+    and a clean pixel."""
+    W = H = 16
+    ranges = np.array([[0, 2]], np.uint32)
+    pl = np.array([0, 1], np.uint32)
+    means = np.array([[3.0, 3.0], [9.0, 9.0]], np.float32)
+    # instance 0: isotropic, opacity 1/255 at its centre pixel -> alpha == 1/255 at (3,3) only (falls off elsewhere)
+    # instance 1: opacity 0.99 at (9,9): test_T = 0.01 -> far from 1e-4
+    co = np.array([[0.5, 0.0, 0.5, 1.0 / 255.0], [0.5, 0.0, 0.5, 0.99]], np.float32)
+    fb = oracle.render_flip_bounds(W, H, ranges, pl, means, co, cmax=1.0, rel_eps=1e-5)
+    assert fb["n_alpha"][3, 3] == 1 and fb["n_alpha"].sum() == 1
+    assert fb["bound"][3, 3] > 0 and fb["bound"][9, 9] == 0 and fb["n_T"].sum() == 0
+    # a stack whose running transmittance hits 1e-4 exactly: two layers of alpha 0.99 give T = 1e-4 (within rounding)
+    pl2 = np.array([0, 1, 2], np.uint32)
+    means2 = np.array([[5.0, 5.0]] * 3, np.float32)
+    co2 = np.array([[0.5, 0.0, 0.5, 0.99]] * 3, np.float32)
+    fb2 = oracle.render_flip_bounds(W, H, np.array([[0, 3]], np.uint32), pl2, means2, co2, cmax=1.0, rel_eps=1e-5)
+    assert fb2["n_T"][5, 5] >= 1 and fb2["bound"][5, 5] >= 0.009            # T = 0.01 in front of the deciding layer
