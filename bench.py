@@ -126,6 +126,14 @@ def main():
                     help="exact tile culling (image-preserving); 0 = reference instance lists")
     ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "4")))
     ap.add_argument("--reduce", default="reduce_scatter", choices=["allreduce", "reduce_scatter"])
+    ap.add_argument("--payload", default="auto", choices=["auto", "packed", "f32"],
+                    help="N > 1: exchange payload of the TSDF reduction (packed = fp32 wsum + one int64 of integer lanes per voxel, "
+                         "12 B; f32 = five fp32 planes, 20 B; auto = packed while the ranks integrated <= 1023 frames in total)")
+    ap.add_argument("--reduce-algo", default="rccl", choices=["rccl", "direct"],
+                    help="reduce_scatter as RCCL's collective, or as one all_to_all of the 1/N slices + a local sum")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the driver's contract): --steps views per GPU; strong: --steps views IN TOTAL, sharded "
+                         "contiguously over the GPUs (BASELINE config C4: --config C4 --steps 300 --scaling strong)")
     ap.add_argument("--tile-rows", type=int, default=int(os.environ.get("GS2M_BENCH_TILE_ROWS", "2")), choices=[1, 2],
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "6")),
@@ -170,7 +178,14 @@ def main():
                                 device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    K, Wm = args.steps, args.warmup
+    K_total = args.steps * world if args.scaling == "weak" else args.steps
+    if args.scaling == "strong":
+        from gs2mesh_amd.parallel import shard_range
+        lo_k, hi_k = shard_range(args.steps, rank, world)
+        K = hi_k - lo_k                         # this rank's share of the job (contiguous views)
+    else:
+        lo_k, K = rank * args.steps, args.steps
+    Wm = args.warmup
     if args.fuse_batch <= 0:
         n_sweeps = max(2, -(-K // 32))
         args.fuse_batch = max(1, -(-K // n_sweeps))
@@ -183,7 +198,8 @@ def main():
     gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
     gd["raw"] = True
     n_local = K + Wm
-    poses = synthetic.ring_poses(n_local, cfg.ring_radius, first=rank * n_local, total=world * n_local)
+    # timed views of this rank: [lo_k, lo_k + K) of the job's K_total views; the warm-up views precede them on the ring
+    poses = synthetic.ring_poses(n_local, cfg.ring_radius, first=lo_k - Wm, total=max(K_total, 1))
     cams, cams_np, depths, Es = [], [], [], []
     for p in poses:
         l, r = synthetic.stereo_cameras(p, Wd, Ht, cfg.focal, cfg.focal, cfg.baseline)
@@ -250,7 +266,7 @@ def main():
         step(i)
     pipe.finish()                                 # drain the pipeline's streams before touching the volume
     if world > 1:
-        reduce_volume(vol, mode=args.reduce)      # warm the RCCL communicator
+        reduce_volume(vol, mode=args.reduce, payload=args.payload, algo=args.reduce_algo)      # warm the RCCL communicator + size the exchange buffers
     vol.status()
     vol.reset()
     torch.cuda.synchronize()
@@ -267,7 +283,7 @@ def main():
         pipe.drain()                              # integrates the last (partial) TSDF batch, then waits for the pipeline's streams
         if world > 1:
             t_red0 = time.perf_counter()
-            red = reduce_volume(vol, mode=args.reduce)
+            red = reduce_volume(vol, mode=args.reduce, payload=args.payload, algo=args.reduce_algo)
             torch.cuda.synchronize()
             reds.append(time.perf_counter() - t_red0)
         barrier()
@@ -376,7 +392,7 @@ def main():
                            achieved_GBps=round(B_pair / t_raster / 1e9, 1), frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4),
                            frac_of_6p29TBps=round(B_pair / t_raster / 6.29e12, 4),
                            render_only_pairs_per_s=round(1.0 / t_raster, 1))
-    tsdf = dict(mvoxel_updates_per_s_job=round(world * K * blocks_frame * 4096 / dt / 1e6, 1),
+    tsdf = dict(mvoxel_updates_per_s_job=round(K_total * blocks_frame * 4096 / dt / 1e6, 1),
                 mvoxel_updates_per_s_kernels=round(blocks_frame * 4096 / t_tsdf / 1e6, 1),
                 blocks_per_frame=round(blocks_frame, 1), updated_voxels_per_frame=round(U_frame, 1),
                 allocated_blocks=int(n_blocks), voxel_length=cfg.voxel_length, sdf_trunc=cfg.sdf_trunc,
@@ -384,7 +400,10 @@ def main():
     if red is not None:
         tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
                               union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),
-                              collectives=int(red.get("collectives", 0)))
+                              collectives=int(red.get("collectives", 0)), payload=red.get("payload"), algo=red.get("algo"),
+                              frames_total=int(red.get("frames_total", 0)),
+                              note="bytes_per_rank = packed union blocks one rank contributes (12 B / voxel packed, 20 B / voxel f32); "
+                                   "a reduce-scatter moves (N-1)/N of it over xGMI")
 
     # ---- oracle legs (rank 0, N = 1 only): parity of the first timed pair, CPU baseline --------------------------
     cpu, par = None, None
@@ -480,9 +499,9 @@ def main():
     if rank == 0:
         out = dict(
             metric="stereo-pair renders/sec + TSDF Mvoxel-updates/sec",
-            value=round(world * K / dt, 2), unit="stereo-pairs/s (rendered L+R and fused)",
-            n_gpus=world, steps=K, warmup=Wm, ms_per_step=round(1e3 * dt / K, 4), higher_is_better=True,
-            scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            value=round(K_total / dt, 2), unit="stereo-pairs/s (rendered L+R and fused)",
+            n_gpus=world, steps=args.steps, warmup=Wm, ms_per_step=round(1e3 * dt / max(K, 1), 4), higher_is_better=True,
+            scaling=args.scaling, vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=f"{args.config}: {cfg.P} synth_v1 Gaussians (SH deg 3), {K} stereo pairs/GPU at "
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,

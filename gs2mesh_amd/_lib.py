@@ -36,6 +36,8 @@ OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
 OPT_BLEND_WG_PER_CU = 6
+XFORM_SUM_F32, XFORM_RAW_F32, XFORM_SUM_PACKED = 0, 1, 2
+XFORM_PACKED_MAX_FRAMES = 1023
 OPT_DEBUG_SYNC = 3
 OPT_STAGE_TIMING = 4
 RASTER_STAGES = ("project", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend", "count_tiles")
@@ -79,6 +81,8 @@ _PROTOS = {
     "gs2m_tsdf_block_keys": (i32, [vp, i64, vp, vp]),
     "gs2m_tsdf_pack_sum": (i32, [vp, vp, i64, vp, vp]),
     "gs2m_tsdf_unpack_sum": (i32, [vp, vp, i64, vp, i32, vp]),
+    "gs2m_tsdf_pack": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "gs2m_tsdf_unpack": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
 }
 
 SYMBOLS = tuple(_PROTOS)

@@ -454,8 +454,8 @@ extern "C" int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m
         return 1;
     }
     if (n == 0) return 0;
-    HIPCHK(hipMemcpyAsync(keys, t->V.block_keys, sizeof(int) * 3 * (size_t)n, hipMemcpyDeviceToDevice,
-                          (hipStream_t)stream));
+    HIPCHK(hipSetDevice(t->device));
+    gs2m_launch_tsdf_owned_keys((hipStream_t)stream, (unsigned)n, t->V, keys);   // halo copies -> sentinel key
     return 0;
 }
 
@@ -509,27 +509,37 @@ extern "C" int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, i
     return 0;
 }
 
-extern "C" int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream) {
-    if (!t || n < 0 || (n > 0 && (!keys || !buf))) {
-        gs2m_set_error("gs2m_tsdf_pack_sum: bad argument");
+extern "C" int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, float* buf_f32, int64_t* buf_i64,
+                              gs2m_stream stream) {
+    if (!t || n < 0 || form < 0 || form > 2 || (n > 0 && (!keys || !buf_f32 || (form == 2 && !buf_i64)))) {
+        gs2m_set_error("gs2m_tsdf_pack: bad argument");
         return 1;
     }
     if (n == 0) return 0;
     HIPCHK(hipSetDevice(t->device));
-    gs2m_launch_tsdf_pack((hipStream_t)stream, (unsigned)n, t->V, keys, buf);
+    gs2m_launch_tsdf_pack((hipStream_t)stream, (unsigned)n, t->V, keys, form, buf_f32, (long long*)buf_i64);
     return 0;
+}
+
+extern "C" int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, const float* buf_f32,
+                                const int64_t* buf_i64, int halo, gs2m_stream stream) {
+    if (!t || n < 0 || form < 0 || form > 2 || (n > 0 && (!keys || !buf_f32 || (form == 2 && !buf_i64)))) {
+        gs2m_set_error("gs2m_tsdf_unpack: bad argument");
+        return 1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(hipSetDevice(t->device));
+    gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, form, buf_f32, (const long long*)buf_i64, halo);
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream) {
+    return gs2m_tsdf_pack(t, keys, n, 0, buf, nullptr, stream);
 }
 
 extern "C" int gs2m_tsdf_unpack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* buf, int halo,
                                     gs2m_stream stream) {
-    if (!t || n < 0 || (n > 0 && (!keys || !buf))) {
-        gs2m_set_error("gs2m_tsdf_unpack_sum: bad argument");
-        return 1;
-    }
-    if (n == 0) return 0;
-    HIPCHK(hipSetDevice(t->device));
-    gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, buf, halo);
-    return 0;
+    return gs2m_tsdf_unpack(t, keys, n, 0, buf, nullptr, halo, stream);
 }
 
 extern "C" int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_triangles) {

@@ -10,8 +10,10 @@ void gs2m_launch_tsdf_touch_batch(hipStream_t st, const TsdfVolume& V, const Tsd
                                   const TsdfBatchFrame* frames);
 void gs2m_launch_tsdf_integrate_batch(hipStream_t st, int n_wg, const TsdfVolume& V, const TsdfBatchFrame* frames);
 void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V);
-void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, float* buf);
-void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* buf, int halo);
+void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, float* buf, long long* ibuf);
+void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, const float* buf,
+                             const long long* ibuf, int halo);
+void gs2m_launch_tsdf_owned_keys(hipStream_t st, unsigned n, const TsdfVolume& V, int* keys);
 // marching cubes (tsdf_extract.h)
 struct McDevTables;
 size_t gs2m_mc_tables_bytes();

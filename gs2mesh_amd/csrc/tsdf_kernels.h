@@ -583,39 +583,60 @@ k_tsdf_clear_used(TsdfVolume V) {
 }
 
 // ---- multi-GPU exchange -----------------------------------------------------------------------
-// pack: one workgroup per canonical key; SUM form in ONE fp32 buffer [n][5][4096] -- planes wsum = tsdf * weight,
-// weight, sum r, sum g, sum b -- so that the host reduces everything with a single RCCL collective.  Counts and colour
-// sums are integers < 2^24 (255 x 65 793 views), hence exact in fp32 and independent of the reduction order.
+// Exchange forms (GS2M_XFORM_*, include/gs2mesh_amd.h):
+//   0 SUM_F32     one fp32 buffer [n][5][4096]: planes wsum = tsdf * weight, weight, sum r, sum g, sum b -- counts and colour
+//                 sums are integers < 2^24, exact in fp32 and independent of the reduction order (one fp32 SUM collective);
+//   1 RAW_F32     the same buffer with the planes VERBATIM (tsdf, weight, sums): for blocks that are already reduced
+//                 (halo copies: fl(fl(t * w) / w) is not always t);
+//   2 SUM_PACKED  wsum as fp32 [n][4096] + ONE int64 per voxel  w | sum r << 10 | sum g << 28 | sum b << 46  (valid while the
+//                 volume has seen <= 1023 frames: w < 2^10, colour sums <= 255 * 1023 < 2^18, no carry between the fields
+//                 under an integer SUM): 12 instead of 20 bytes per voxel on the wire.
+// pack: one workgroup per canonical key (zeros where the block is not allocated here or only a halo copy).
+#define GS2M_XF_SUM_F32 0
+#define GS2M_XF_RAW_F32 1
+#define GS2M_XF_SUM_PACKED 2
+template <int FORM>
 GS2M_KERNEL void __launch_bounds__(256)
-k_tsdf_pack(TsdfVolume V, const int* __restrict__ keys, float* __restrict__ buf) {
+k_tsdf_pack(TsdfVolume V, const int* __restrict__ keys, float* __restrict__ buf, long long* __restrict__ ibuf) {
     const int tid = (int)threadIdx.x;
     const size_t b = blockIdx.x;
     const int bx = keys[3 * b], by = keys[3 * b + 1], bz = keys[3 * b + 2];
-    const int slot = tsdf_key_in_range(bx, by, bz) ? tsdf_lookup(V, tsdf_pack_key(bx, by, bz)) : -1;
-    float* o = buf + b * 5 * GS2M_TSDF_VOX;
+    int slot = tsdf_key_in_range(bx, by, bz) ? tsdf_lookup(V, tsdf_pack_key(bx, by, bz)) : -1;
+    if (slot >= 0 && FORM != GS2M_XF_RAW_F32 && V.halo[slot]) slot = -1;   // a halo copy is another rank's block: never summed twice
+    float* o = buf + b * (FORM == GS2M_XF_SUM_PACKED ? 1 : 5) * GS2M_TSDF_VOX;
     for (int i = tid; i < GS2M_TSDF_VOX; i += 256) {
-        float w = 0.f, t = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        float w = 0.f, t = 0.f;
+        unsigned c0 = 0u, c1 = 0u, c2 = 0u;
         if (slot >= 0) {
             w = V.weight[(size_t)slot * GS2M_TSDF_VOX + i];
-            t = V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i] * w;
+            t = V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i];
+            if (FORM != GS2M_XF_RAW_F32) t = t * w;
             if (V.has_color) {
-                c0 = (float)V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i];
-                c1 = (float)V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i];
-                c2 = (float)V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i];
+                c0 = V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i];
+                c1 = V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i];
+                c2 = V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i];
             }
         }
         o[i] = t;
-        o[GS2M_TSDF_VOX + i] = w;
-        o[2 * GS2M_TSDF_VOX + i] = c0;
-        o[3 * GS2M_TSDF_VOX + i] = c1;
-        o[4 * GS2M_TSDF_VOX + i] = c2;
+        if (FORM == GS2M_XF_SUM_PACKED) {
+            ibuf[b * GS2M_TSDF_VOX + i] = (long long)((unsigned long long)(unsigned)w | ((unsigned long long)c0 << 10) |
+                                                      ((unsigned long long)c1 << 28) | ((unsigned long long)c2 << 46));
+        } else {
+            o[GS2M_TSDF_VOX + i] = w;
+            o[2 * GS2M_TSDF_VOX + i] = (float)c0;
+            o[3 * GS2M_TSDF_VOX + i] = (float)c1;
+            o[4 * GS2M_TSDF_VOX + i] = (float)c2;
+        }
     }
 }
 
-// unpack: replaces the state of the listed blocks (allocating as needed) with tsdf = wsum / weight; `halo` marks them as
-// neighbour-only blocks of another rank's part of the volume (mesh extraction reads them but starts no cube there).
+// unpack: replaces the state of the listed blocks (allocating as needed): tsdf = wsum / weight (SUM forms) or verbatim
+// (RAW); `halo` marks them as neighbour-only blocks of another rank's part of the volume (mesh extraction reads them but
+// starts no cube there; pack / block_keys skip them).
+template <int FORM>
 GS2M_KERNEL void __launch_bounds__(256)
-k_tsdf_unpack(TsdfVolume V, const int* __restrict__ keys, const float* __restrict__ buf, int halo) {
+k_tsdf_unpack(TsdfVolume V, const int* __restrict__ keys, const float* __restrict__ buf, const long long* __restrict__ ibuf,
+              int halo) {
     __shared__ int s_slot;
     const int tid = (int)threadIdx.x;
     const size_t b = blockIdx.x;
@@ -634,15 +655,40 @@ k_tsdf_unpack(TsdfVolume V, const int* __restrict__ keys, const float* __restric
     __syncthreads();
     const int slot = s_slot;
     if (slot < 0) return;
-    const float* in = buf + b * 5 * GS2M_TSDF_VOX;
+    const float* in = buf + b * (FORM == GS2M_XF_SUM_PACKED ? 1 : 5) * GS2M_TSDF_VOX;
     for (int i = tid; i < GS2M_TSDF_VOX; i += 256) {
-        const float w = in[GS2M_TSDF_VOX + i];
+        float w;
+        unsigned c0, c1, c2;
+        if (FORM == GS2M_XF_SUM_PACKED) {
+            const unsigned long long p = (unsigned long long)ibuf[b * GS2M_TSDF_VOX + i];
+            w = (float)(unsigned)(p & 0x3ffull);
+            c0 = (unsigned)((p >> 10) & 0x3ffffull);
+            c1 = (unsigned)((p >> 28) & 0x3ffffull);
+            c2 = (unsigned)(p >> 46);
+        } else {
+            w = in[GS2M_TSDF_VOX + i];
+            c0 = (unsigned)in[2 * GS2M_TSDF_VOX + i];
+            c1 = (unsigned)in[3 * GS2M_TSDF_VOX + i];
+            c2 = (unsigned)in[4 * GS2M_TSDF_VOX + i];
+        }
         V.weight[(size_t)slot * GS2M_TSDF_VOX + i] = w;
-        V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i] = w > 0.f ? in[i] / w : 0.f;
+        V.tsdf[(size_t)slot * GS2M_TSDF_VOX + i] = FORM == GS2M_XF_RAW_F32 ? in[i] : (w > 0.f ? in[i] / w : 0.f);
         if (V.has_color) {
-            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i] = (unsigned)in[2 * GS2M_TSDF_VOX + i];
-            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i] = (unsigned)in[3 * GS2M_TSDF_VOX + i];
-            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i] = (unsigned)in[4 * GS2M_TSDF_VOX + i];
+            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + i] = c0;
+            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + GS2M_TSDF_VOX + i] = c1;
+            V.rgb[(size_t)slot * 3 * GS2M_TSDF_VOX + 2 * GS2M_TSDF_VOX + i] = c2;
         }
     }
+}
+
+// block keys of the first n slots; halo copies (another rank's blocks) are reported as the out-of-range sentinel key
+GS2M_KERNEL void __launch_bounds__(256)
+k_tsdf_owned_keys(TsdfVolume V, unsigned n, int* __restrict__ keys) {
+    const unsigned s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n) return;
+    const bool h = V.halo[s] != 0;
+    const int sentinel = GS2M_TSDF_KEY_BIAS - 1;
+    keys[3 * (size_t)s] = h ? sentinel : V.block_keys[3 * (size_t)s];
+    keys[3 * (size_t)s + 1] = h ? sentinel : V.block_keys[3 * (size_t)s + 1];
+    keys[3 * (size_t)s + 2] = h ? sentinel : V.block_keys[3 * (size_t)s + 2];
 }

@@ -26,11 +26,19 @@ void gs2m_launch_tsdf_integrate_batch(hipStream_t st, int n_wg, const TsdfVolume
 void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V) {
     GS2M_LAUNCH(k_tsdf_clear_used, dim3(2048), dim3(256), 0, st, V);
 }
-void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, float* buf) {
-    GS2M_LAUNCH(k_tsdf_pack, dim3(n), dim3(256), 0, st, V, keys, buf);
+void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, float* buf, long long* ibuf) {
+    if (form == GS2M_XF_SUM_PACKED) GS2M_LAUNCH(k_tsdf_pack<GS2M_XF_SUM_PACKED>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf);
+    else if (form == GS2M_XF_RAW_F32) GS2M_LAUNCH(k_tsdf_pack<GS2M_XF_RAW_F32>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf);
+    else GS2M_LAUNCH(k_tsdf_pack<GS2M_XF_SUM_F32>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf);
 }
-void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, const float* buf, int halo) {
-    GS2M_LAUNCH(k_tsdf_unpack, dim3(n), dim3(256), 0, st, V, keys, buf, halo);
+void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, const float* buf,
+                             const long long* ibuf, int halo) {
+    if (form == GS2M_XF_SUM_PACKED) GS2M_LAUNCH(k_tsdf_unpack<GS2M_XF_SUM_PACKED>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf, halo);
+    else if (form == GS2M_XF_RAW_F32) GS2M_LAUNCH(k_tsdf_unpack<GS2M_XF_RAW_F32>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf, halo);
+    else GS2M_LAUNCH(k_tsdf_unpack<GS2M_XF_SUM_F32>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf, halo);
+}
+void gs2m_launch_tsdf_owned_keys(hipStream_t st, unsigned n, const TsdfVolume& V, int* keys) {
+    GS2M_LAUNCH(k_tsdf_owned_keys, dim3((n + 255u) / 256u), dim3(256), 0, st, V, n, keys);
 }
 
 size_t gs2m_mc_tables_bytes() { return sizeof(McDevTables); }

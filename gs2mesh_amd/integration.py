@@ -92,6 +92,8 @@ class ScalableTSDFVolume:
                                               self.max_blocks, int(device)), self._lib)
         self._h = h
         self._keep = []  # uploaded frames stay alive until the next synchronising call
+        self.frames_integrated = 0   # frames this volume's state carries (bounds every weight: the packed exchange form needs it)
+        self._xbuf = {}              # persistent, grow-only exchange buffers (gs2mesh_amd.parallel)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -106,6 +108,18 @@ class ScalableTSDFVolume:
 
     def reset(self, stream=None):
         _lib.check(self._lib.gs2m_tsdf_reset(self._h, stream or C.c_void_p(0)), self._lib)
+        self.frames_integrated = 0
+
+    def exchange_buffer(self, name, shape, dtype, device):
+        """A persistent, grow-only device buffer owned by the volume (the multi-GPU reduction re-uses its pack / receive
+        buffers across calls instead of allocating GBs per reduction); returns a view of ``shape``."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        cur = self._xbuf.get(name)
+        if cur is None or cur.dtype != dtype or cur.numel() < n or cur.device != torch.device(device):
+            self._xbuf[name] = cur = torch.empty(max(n + n // 8, 1), dtype=dtype, device=device)
+        return cur[:n].view(*shape)
 
     # ---------------------------------------------------------------------------------------
     def _to_dev(self, a, dtype):
@@ -149,6 +163,7 @@ class ScalableTSDFVolume:
             self._h, _ptr(depth), _ptr(color), _ptr(msk), W, H, intrinsic.fx, intrinsic.fy, intrinsic.cx,
             intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)), float(image.depth_scale),
             float(image.depth_trunc), float(min_depth), st), self._lib)
+        self.frames_integrated += 1
         if ours:
             self._keep.append(ours)
             if len(self._keep) > 64:
@@ -187,6 +202,7 @@ class ScalableTSDFVolume:
             self._h, n, dp, cp if has_color else None, mp if masks is not None else None, intrinsic.width, intrinsic.height,
             intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)),
             float(images[0].depth_scale), float(images[0].depth_trunc), float(min_depth), st), self._lib)
+        self.frames_integrated += n
         self._keep.append(keep)      # the frames stay alive until the next synchronising call
         if len(self._keep) > 64:
             self.status(stream)
@@ -269,6 +285,18 @@ class ScalableTSDFVolume:
             keys = torch.zeros((n, 3), dtype=torch.int32, device=f"cuda:{self.device}")
         _lib.check(self._lib.gs2m_tsdf_block_keys(self._h, n, _ptr(keys), _stream_of(keys, stream)), self._lib)
         return keys
+
+    def pack(self, keys, form, buf_f32, buf_i64=None, stream=None):
+        """``gs2m_tsdf_pack``: accumulators of the blocks ``keys`` [n,3] in exchange form ``form`` (_lib.XFORM_*)."""
+        n = int(keys.shape[0])
+        _lib.check(self._lib.gs2m_tsdf_pack(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
+                                            _stream_of(keys, stream)), self._lib)
+
+    def unpack(self, keys, form, buf_f32, buf_i64=None, halo=False, stream=None):
+        """``gs2m_tsdf_unpack``: replace the state of the blocks ``keys`` from buffers in exchange form ``form``."""
+        n = int(keys.shape[0])
+        _lib.check(self._lib.gs2m_tsdf_unpack(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
+                                              int(bool(halo)), _stream_of(keys, stream)), self._lib)
 
     def pack_sum(self, keys, buf, stream=None):
         """``gs2m_tsdf_pack_sum``: accumulators of the blocks ``keys`` [n,3] in sum form -> ``buf`` [n,5,4096] f32."""

@@ -9,13 +9,17 @@ is one sum-reduction of the TSDF accumulators at the end (``reduce_volume``):
      row carrying the rank's block count and overflow flags -- no size handshake, no per-rank ``.item()``);
      every rank builds the same canonical (sorted, unique) union; an overflow on ANY rank raises on EVERY
      rank after the collective (nobody is left waiting in one);
-  2. ``gs2m_tsdf_pack_sum`` writes the local accumulators of the union blocks in SUM form into ONE fp32
-     buffer ``[n, 5, 4096]`` (wsum = tsdf*weight, weight, sum r, sum g, sum b; the counts and colour sums are
-     integers < 2^24, exact in fp32 and independent of the reduction order);
-  3. ONE RCCL collective over that buffer: ``reduce_scatter`` (default: rank r ends owning a contiguous 1/R of
-     the canonical block list -- (R-1)/R of the bytes of an all-reduce on the wire, and xGMI is per-link
-     bound, SURVEY.md 8e) or ``all_reduce`` (every rank ends with the complete volume);
-  4. ``gs2m_tsdf_unpack_sum`` (tsdf = wsum/weight) of the owned blocks.
+  2. ``gs2m_tsdf_pack`` writes the local accumulators of the union blocks in SUM form into persistent, grow-only
+     buffers owned by the volume.  Payload "packed" (chosen when all ranks together integrated <= 1023 frames -- the
+     frame counts travel in the header of step 1, so every rank decides alike): wsum = tsdf*weight as fp32 + ONE int64
+     per voxel holding weight | sum r << 10 | sum g << 28 | sum b << 46 -- 12 bytes per voxel, integer fields exact under
+     an integer SUM.  Payload "f32" (any frame count): five fp32 planes (wsum, weight, sum r, sum g, sum b; counts and
+     colour sums are integers < 2^24, exact in fp32) -- 20 bytes per voxel;
+  3. the sum: ``reduce_scatter`` (default: rank r ends owning a contiguous 1/R of the canonical block list --
+     (R-1)/R of the bytes of an all-reduce on the wire, and xGMI is per-link bound), as RCCL's
+     reduce-scatter or ("direct") as ONE all_to_all of the 1/R slices + a local sum (every pair of GPUs has its own
+     xGMI link: each slice crosses one link once, no ring), or ``all_reduce`` (every rank ends with the whole volume);
+  4. ``gs2m_tsdf_unpack`` (tsdf = wsum/weight) of the owned blocks.
 
 After a reduce-scatter every rank extracts ITS part of the mesh (owner-side finalisation): ``exchange_halo``
 fetches the +1 neighbour blocks that belong to other ranks (one ``all_to_all``, sizes derived from the
@@ -69,86 +73,125 @@ def _as_tensor(keys):
 
 def canonical_keys(volume, group=None, always_collective: bool = False):
     """Union of the block keys of all ranks in canonical order, on the local device, + the OR of the ranks'
-    overflow flags.  One fixed-size all_gather; one host read (of the gathered header rows)."""
+    overflow flags + the number of frames all ranks integrated.  One fixed-size all_gather (persistent buffers);
+    one host read (of the gathered header rows).  Halo copies held by a volume are not its blocks (sentinel keys)."""
     keys = _as_tensor(volume.block_keys(raise_on_overflow=False))
     _, _, ov = volume.status(raise_on_overflow=False)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     collective = world > 1 or (always_collective and dist.is_initialized())
     if not collective:
-        return _lex_unique(keys), int(ov), 0
+        return _lex_unique(keys[keys[:, 0] != _SENTINEL]), int(ov), 0, int(volume.frames_integrated)
     K = int(volume.max_blocks)
     n_local = int(keys.shape[0])
-    buf = torch.full((K + 1, 3), _SENTINEL, dtype=torch.int32, device=keys.device)
+    buf = volume.exchange_buffer("keys_send", (K + 2, 3), torch.int32, keys.device)
+    buf.fill_(_SENTINEL)
     buf[:n_local] = keys
     buf[K, 0] = n_local
     buf[K, 1] = int(ov)
     buf[K, 2] = K
-    gathered = torch.empty((world * (K + 1), 3), dtype=torch.int32, device=keys.device)
+    buf[K + 1, 0] = int(volume.frames_integrated)
+    gathered = volume.exchange_buffer("keys_recv", (world * (K + 2), 3), torch.int32, keys.device)
     dist.all_gather_into_tensor(gathered, buf, group=group)
-    g = gathered.view(world, K + 1, 3)
-    head = g[:, K, :].cpu()                                   # the one host read of the exchange
-    if int(head[:, 2].min()) != K or int(head[:, 2].max()) != K:
+    g = gathered.view(world, K + 2, 3)
+    head = g[:, K:, :].cpu()                                  # the one host read of the exchange
+    if int(head[:, 0, 2].min()) != K or int(head[:, 0, 2].max()) != K:
         raise RuntimeError("reduce_volume: every rank must create its volume with the same max_blocks")
     ov_any = 0
-    for f in head[:, 1].tolist():
+    for f in head[:, 0, 1].tolist():
         ov_any |= int(f)
+    frames_total = int(head[:, 1, 0].sum())
     body = g[:, :K, :].reshape(-1, 3)
     valid = body[:, 0] != _SENTINEL
-    return _lex_unique(body[valid]), ov_any, 1
+    return _lex_unique(body[valid]), ov_any, 1, frames_total
 
 
-def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_collective: bool = False):
+def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_collective: bool = False,
+                  payload: str = "auto", algo: str = "rccl"):
     """Sum-reduce the TSDF accumulators of all ranks into `volume`.
 
     mode "reduce_scatter": rank r ends with blocks [lo_r, hi_r) of the canonical list only (use `exchange_halo`
     before extracting its part of the mesh).  mode "allreduce": every rank ends with the complete fused volume.
+    payload "packed" | "f32" | "auto" (packed when all ranks together integrated <= 1023 frames).
+    algo "rccl" (the library's reduce-scatter / all-reduce) | "direct" (reduce_scatter only: one all_to_all of the
+    1/R slices + a local sum over the R received copies).
     ``always_collective``: issue the collectives even at world size 1 (exercises the RCCL calls on one GPU).
     The caller must have drained the streams that integrate into `volume` (`RenderFusePipeline.drain`).
-    Returns dict(n_blocks_union, bytes_per_rank, keys, owned, collectives, seconds)."""
+    Returns dict(n_blocks_union, bytes_per_rank, keys, owned, collectives, seconds, payload, algo, frames_total)."""
     t0 = time.perf_counter()
+    from . import _lib
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    keys, ov_any, n_coll = canonical_keys(volume, group, always_collective)
+    if mode not in ("reduce_scatter", "allreduce") or payload not in ("auto", "packed", "f32") or algo not in ("rccl", "direct"):
+        raise ValueError((mode, payload, algo))
+    keys, ov_any, n_coll, frames_total = canonical_keys(volume, group, always_collective)
     if ov_any:
         # every rank sees the same flags after the key exchange: all of them raise, nobody waits in a collective
         what = [n for b, n in _OVERFLOW_TEXT if ov_any & b]
         raise RuntimeError("TSDF volume overflow on at least one rank: " + ", ".join(what))
+    fits = frames_total <= _lib.XFORM_PACKED_MAX_FRAMES
+    if payload == "packed" and not fits:
+        raise RuntimeError(f"packed exchange payload needs <= {_lib.XFORM_PACKED_MAX_FRAMES} frames in total, the ranks "
+                           f"integrated {frames_total} (use payload='f32' or 'auto')")
+    packed = payload == "packed" or (payload == "auto" and fits)
+    form = _lib.XFORM_SUM_PACKED if packed else _lib.XFORM_SUM_F32
     collective = world > 1 or (always_collective and dist.is_initialized())
     n = int(keys.shape[0])
     dev = keys.device
     scatter = mode == "reduce_scatter" and collective
-    if mode not in ("reduce_scatter", "allreduce"):
-        raise ValueError(mode)
     n_pad = (n + world - 1) // world * world if scatter else n
     kpad = keys
     if n_pad != n:
         # pad with a key nobody owns (far outside any scene): packs to zeros, never unpacked
         filler = torch.full((n_pad - n, 3), _SENTINEL, dtype=torch.int32, device=dev)
         kpad = torch.cat([keys, filler], dim=0).contiguous()
-    buf = torch.empty((n_pad, 5, 4096), dtype=torch.float32, device=dev)
+    planes = 1 if packed else 5
+    fbuf = volume.exchange_buffer("send_f32", (n_pad, planes, 4096), torch.float32, dev)
+    ibuf = volume.exchange_buffer("send_i64", (n_pad, 4096), torch.int64, dev) if packed else None
     if n_pad:
-        volume.pack_sum(kpad, buf)
-    nbytes = n_pad * 5 * 4096 * 4
+        volume.pack(kpad, form, fbuf, ibuf)
+    nbytes = n_pad * 4096 * (12 if packed else 20)
     lo, hi = 0, n
     if collective and n_pad:
         if scatter:
             per = n_pad // world
-            out = torch.empty((per, 5, 4096), dtype=torch.float32, device=dev)
-            dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=group)
-            buf = out
+            fout = volume.exchange_buffer("recv_f32", (per, planes, 4096), torch.float32, dev)
+            iout = volume.exchange_buffer("recv_i64", (per, 4096), torch.int64, dev) if packed else None
+            if algo == "direct":
+                # slice p of every rank's buffer goes straight to rank p (one all_to_all per dtype), which sums its R copies
+                fall = volume.exchange_buffer("a2a_f32", (world, per, planes, 4096), torch.float32, dev)
+                dist.all_to_all_single(fall.view(-1), fbuf.view(-1), group=group)
+                torch.sum(fall, dim=0, out=fout)
+                n_coll += 1
+                if packed:
+                    iall = volume.exchange_buffer("a2a_i64", (world, per, 4096), torch.int64, dev)
+                    dist.all_to_all_single(iall.view(-1), ibuf.view(-1), group=group)
+                    torch.sum(iall, dim=0, out=iout)
+                    n_coll += 1
+            else:
+                dist.reduce_scatter_tensor(fout, fbuf, op=dist.ReduceOp.SUM, group=group)
+                n_coll += 1
+                if packed:
+                    dist.reduce_scatter_tensor(iout, ibuf, op=dist.ReduceOp.SUM, group=group)
+                    n_coll += 1
+            fbuf, ibuf = fout, iout
             lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
             kpad = kpad[rank * per: (rank + 1) * per]
         else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        n_coll += 1
+            dist.all_reduce(fbuf, op=dist.ReduceOp.SUM, group=group)
+            n_coll += 1
+            if packed:
+                dist.all_reduce(ibuf, op=dist.ReduceOp.SUM, group=group)
+                n_coll += 1
     # replace the local state by the reduced blocks (reset only clears the slots in use)
     volume.reset()
     cnt = max(0, hi - lo)
     if cnt:
-        volume.unpack_sum(kpad[:cnt].contiguous(), buf[:cnt])
+        volume.unpack(kpad[:cnt].contiguous(), form, fbuf[:cnt], ibuf[:cnt] if packed else None)
     volume.status()
+    volume.frames_integrated = frames_total          # every weight of the reduced state is bounded by the total
     return dict(n_blocks_union=n, bytes_per_rank=nbytes, keys=keys, owned=(lo, hi), collectives=n_coll, mode=mode,
-                per=(n_pad // world if scatter else n), seconds=time.perf_counter() - t0)
+                per=(n_pad // world if scatter else n), seconds=time.perf_counter() - t0,
+                payload=("packed" if packed else "f32"), algo=(algo if scatter else "rccl"), frames_total=frames_total)
 
 
 def _neighbour_index(packed_sorted: torch.Tensor, keys: torch.Tensor, d):
@@ -189,14 +232,17 @@ def exchange_halo(volume, info, group=None):
     recv_counts = [int(x.numel()) for x in recv_idx]
     s_all = torch.cat(send_idx) if sum(send_counts) else torch.zeros(0, dtype=torch.long, device=dev)
     r_all = torch.cat(recv_idx) if sum(recv_counts) else torch.zeros(0, dtype=torch.long, device=dev)
-    sbuf = torch.empty((max(int(s_all.numel()), 1), 5, 4096), dtype=torch.float32, device=dev)
+    from . import _lib
+    # the blocks are already reduced: they travel VERBATIM (tsdf, weight, colour sums), so that a seam voxel has the same
+    # bits on both sides (tsdf * w / w is not always tsdf)
+    sbuf = volume.exchange_buffer("halo_send", (max(int(s_all.numel()), 1), 5, 4096), torch.float32, dev)
     if s_all.numel():
-        volume.pack_sum(keys[s_all].contiguous(), sbuf[: s_all.numel()])
-    rbuf = torch.empty((max(int(r_all.numel()), 1), 5, 4096), dtype=torch.float32, device=dev)
+        volume.pack(keys[s_all].contiguous(), _lib.XFORM_RAW_F32, sbuf[: s_all.numel()])
+    rbuf = volume.exchange_buffer("halo_recv", (max(int(r_all.numel()), 1), 5, 4096), torch.float32, dev)
     dist.all_to_all_single(rbuf[: r_all.numel()].reshape(-1), sbuf[: s_all.numel()].reshape(-1),
                            output_split_sizes=[c * 5 * 4096 for c in recv_counts],
                            input_split_sizes=[c * 5 * 4096 for c in send_counts], group=group)
     if r_all.numel():
-        volume.unpack_sum(keys[r_all].contiguous(), rbuf[: r_all.numel()], halo=True)
+        volume.unpack(keys[r_all].contiguous(), _lib.XFORM_RAW_F32, rbuf[: r_all.numel()], halo=True)
     volume.status()
     return int(r_all.numel())

@@ -320,7 +320,9 @@ int gs2m_tsdf_status(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_blocks,
 int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, int32_t* keys,
                        float* tsdf, float* weight, uint32_t* rgb_sum);
 
-/* Block keys of all allocated blocks to a DEVICE buffer keys[n,3] (i32), in slot order. */
+/* Block keys of the first n allocated blocks to a DEVICE buffer keys[n,3] (i32), in slot order.  Halo copies (blocks of
+ * another rank brought in by gs2m_tsdf_unpack(..., halo = 1)) are reported as the out-of-range sentinel key
+ * (2^20 - 1 in every component): they are not this volume's to exchange. */
 int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m_stream stream);
 
 /*
@@ -335,6 +337,21 @@ int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m_stream str
 int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream);
 int gs2m_tsdf_unpack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* buf, int halo,
                          gs2m_stream stream);
+
+/* The same with a choice of exchange form (pack_sum / unpack_sum = form GS2M_XFORM_SUM_F32):
+ *   GS2M_XFORM_SUM_F32     buf_f32[n,5,4096] in SUM form as above (one fp32 SUM collective), buf_i64 unused;
+ *   GS2M_XFORM_RAW_F32     buf_f32[n,5,4096] with the planes verbatim {tsdf, weight, sum r, sum g, sum b}: for copies of blocks
+ *                          that are already reduced (halo exchange) -- no tsdf * w / w round trip, seam voxels bit-identical;
+ *   GS2M_XFORM_SUM_PACKED  buf_f32[n,4096] = wsum, buf_i64[n,4096] = weight | sum r << 10 | sum g << 28 | sum b << 46: an fp32 SUM
+ *                          and an int64 SUM collective, 12 instead of 20 bytes per voxel.  Only valid while the volumes being
+ *                          summed have integrated <= 1023 frames IN TOTAL (weight < 2^10, colour sums < 2^18: no carry between
+ *                          the fields); the caller checks that bound (gs2mesh_amd.parallel does, and falls back to SUM_F32).
+ * Halo copies held by the volume are packed as zeros in the SUM forms (they are another rank's blocks). */
+enum { GS2M_XFORM_SUM_F32 = 0, GS2M_XFORM_RAW_F32 = 1, GS2M_XFORM_SUM_PACKED = 2 };
+int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, float* buf_f32, int64_t* buf_i64,
+                   gs2m_stream stream);
+int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, const float* buf_f32,
+                     const int64_t* buf_i64, int halo, gs2m_stream stream);
 
 /*
  * Replaces volume.extract_triangle_mesh() (tsdf_utils.py:108; Open3D ScalableTSDFVolume::

@@ -22,15 +22,27 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     be = make("emu")
-    frs, K = frames(5, 128, 96, 140.0)
+    # mode = "<reduce mode>[+mesh][:payload[:algo[:n_frames]]]"
+    parts = mode.split(":")
+    mode = parts[0]
+    payload = parts[1] if len(parts) > 1 else "auto"
+    algo = parts[2] if len(parts) > 2 else "rccl"
+    n_frames = int(parts[3]) if len(parts) > 3 else 5
+    frs, K = frames(n_frames, 128, 96, 140.0)
     W, H, fx, fy, cx, cy = K
     lo, hi = shard_range(len(frs), rank, world)
     vol = ScalableTSDFVolume(2.0 / 96, 0.1, max_blocks=2048, lib=be.lib)
     intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
     for d, c, E in frs[lo:hi]:
         vol.integrate(RGBDImage(c, d), intr, E)
+    again = mode.endswith("+again")
+    mode = mode.replace("+again", "")
     mesh_mode = mode.endswith("+mesh")
-    info = reduce_volume(vol, mode=mode.replace("+mesh", ""))
+    info = reduce_volume(vol, mode=mode.replace("+mesh", ""), payload=payload, algo=algo)
+    assert info["payload"] == ("f32" if payload == "f32" else "packed") and info["frames_total"] == n_frames
+    assert vol.frames_integrated == n_frames
+    # a second reduction must be able to re-use the persistent exchange buffers (same objects, no growth)
+    ids = {k: v.data_ptr() for k, v in vol._xbuf.items()}
     extra = {}
     if mesh_mode:
         # owner-side finalisation: halo blocks from the other ranks, then this rank's part of the mesh
@@ -39,7 +51,14 @@ def main():
         m = vol.extract_triangle_mesh()
         extra["tri_xyz"] = m.vertices[m.triangles] if len(m.triangles) else np.zeros((0, 3, 3))
         extra["owned_keys"] = owned_keys
-        assert info["collectives"] == 2
+        assert info["collectives"] == (2 if info["payload"] == "f32" else 3)
+        assert all(vol._xbuf[k].data_ptr() == p for k, p in ids.items())
+    if again:
+        # second reduction on volumes that now hold halo copies of the other rank's blocks
+        info2 = reduce_volume(vol, mode="reduce_scatter", payload=payload, algo=algo)
+        k2, t2, w2, c2 = vol.download()
+        extra.update(keys2=k2, weight2=w2, rgb2=c2)
+        assert info2["n_blocks_union"] == info["n_blocks_union"]
     keys, tsdf, weight, rgb = vol.download()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, tsdf=tsdf, weight=weight, rgb=rgb,
              union=info["n_blocks_union"], owned=np.array(info["owned"]), **extra)

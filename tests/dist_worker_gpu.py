@@ -40,8 +40,13 @@ def main():
     lo, hi = shard_range(len(poses), rank, world)
     fuse(vol, poses[lo:hi])
     torch.cuda.synchronize()
-    info = reduce_volume(vol, mode=mode, always_collective=True)
-    assert info["collectives"] == 2
+    # mode = "<reduce mode>[:payload[:algo]]"
+    parts = mode.split(":")
+    mode = parts[0]
+    payload = parts[1] if len(parts) > 1 else "auto"
+    algo = parts[2] if len(parts) > 2 else "rccl"
+    info = reduce_volume(vol, mode=mode, always_collective=True, payload=payload, algo=algo)
+    assert info["collectives"] == (2 if info["payload"] == "f32" else 3)
     tri = np.zeros((0, 3, 3))
     if mode == "reduce_scatter":
         exchange_halo(vol, info)

@@ -48,12 +48,12 @@ def run_world(tmp_path, world, mode):
         assert rendezvous and attempt < 2, "\n".join(o[-3000:] for o in outs)
 
 
-def single_process_reference(with_mesh=False):
+def single_process_reference(with_mesh=False, n_frames=5):
     from backends import make
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
     from test_tsdf_parity import frames
     be = make("emu")
-    frs, K = frames(5, 128, 96, 140.0)
+    frs, K = frames(n_frames, 128, 96, 140.0)
     W, H, fx, fy, cx, cy = K
     vol = ScalableTSDFVolume(2.0 / 96, 0.1, max_blocks=2048, lib=be.lib)
     for d, c, E in frs:
@@ -64,9 +64,14 @@ def single_process_reference(with_mesh=False):
     return vol.download()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "reduce_scatter"), (3, "allreduce")])
+@pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "reduce_scatter"), (3, "allreduce"),
+                                        (2, "reduce_scatter:f32"), (3, "reduce_scatter:packed:direct"),
+                                        (2, "reduce_scatter:f32:direct"), (2, "allreduce:f32")])
 def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
+    """Every payload (packed int64 lanes / five fp32 planes) and both reduce-scatter algorithms (the library's, or one
+    all_to_all of the 1/R slices + a local sum) give the single-process volume: weights and colour sums bit-exact."""
     run_world(tmp_path, world, mode)
+    mode = mode.split(":")[0]
     kf, tf, wf, cf = single_process_reference()
     ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
     seen = set()
@@ -83,6 +88,51 @@ def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
         np.testing.assert_array_equal(z["weight"], wf[idx])
         np.testing.assert_array_equal(z["rgb"], cf[idx])
         np.testing.assert_allclose(z["tsdf"], tf[idx], atol=1e-5, rtol=0)
+    assert seen == set(ref)
+
+
+def test_eight_ranks_reduce_scatter_direct_and_owner_side_mesh(tmp_path):
+    """The target rank count: 8 ranks x 2 frames, packed payload, direct reduce-scatter, owner-side extraction with
+    halo blocks -- ownership split, padding of the canonical list to a multiple of 8, halo need / send lists at R = 8."""
+    world, n_frames = 8, 16
+    run_world(tmp_path, world, f"reduce_scatter+mesh:packed:direct:{n_frames}")
+    (kf, tf, wf, cf), tri_ref = single_process_reference(with_mesh=True, n_frames=n_frames)
+    ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
+    parts, owned_all = [], set()
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert int(z["union"]) == len(ref)
+        owned = list(map(tuple, z["owned_keys"].tolist()))
+        assert not (set(owned) & owned_all)
+        owned_all |= set(owned)
+        parts.append(z["tri_xyz"])
+        # halo copies arrive VERBATIM: bit-identical to the owner's reduced voxels
+        keys = list(map(tuple, z["keys"].tolist()))
+        idx = np.array([ref[k] for k in keys], dtype=int)
+        np.testing.assert_array_equal(z["weight"], wf[idx])
+        np.testing.assert_array_equal(z["rgb"], cf[idx])
+    assert owned_all == set(ref)
+    got = np.concatenate(parts, axis=0)
+    assert got.shape == tri_ref.shape and len(got) > 1000
+    key = lambda t: t[np.lexsort(np.round(np.concatenate([t.mean(axis=1), t[:, 0]], axis=1) * 1e5).astype(np.int64).T[::-1])]
+    np.testing.assert_allclose(key(got), key(tri_ref), atol=2e-6, rtol=0)
+
+
+def test_halo_copies_are_not_exchanged_twice(tmp_path):
+    """A volume that holds halo copies (after exchange_halo) reports them as sentinel keys and packs them as zeros: a
+    second reduction does not count another rank's blocks twice."""
+    run_world(tmp_path, 2, "reduce_scatter+mesh+again")
+    kf, tf, wf, cf = single_process_reference()
+    ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
+    seen = set()
+    for rank in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        keys = list(map(tuple, z["keys2"].tolist()))
+        assert not (set(keys) & seen)
+        seen |= set(keys)
+        idx = np.array([ref[k] for k in keys], dtype=int)
+        np.testing.assert_array_equal(z["weight2"], wf[idx])          # weights NOT doubled by the halo copies
+        np.testing.assert_array_equal(z["rgb2"], cf[idx])
     assert seen == set(ref)
 
 

@@ -176,7 +176,8 @@ def _run_rccl(world, mode, tmp_path):
     assert all(p.returncode == 0 for p in procs) and "RCCL_OK" in outs[0], "\n".join(o[-3000:] for o in outs)
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
+@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter", "reduce_scatter:f32", "reduce_scatter:packed:direct",
+                                  "allreduce:f32"])
 def test_reduce_volume_over_rccl_single_rank(mode, tmp_path):
     """The RCCL calls of parallel.reduce_volume (fixed-size all_gather of the keys + flags, ONE all_reduce / reduce_scatter
     of the packed fp32 accumulators, the all_to_all of the halo exchange) on device tensors, world size 1 (one GPU on the
@@ -184,7 +185,7 @@ def test_reduce_volume_over_rccl_single_rank(mode, tmp_path):
     _run_rccl(1, mode, tmp_path)
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter"])
+@pytest.mark.parametrize("mode", ["allreduce", "reduce_scatter", "reduce_scatter:packed:direct"])
 def test_reduce_volume_over_rccl_two_ranks(mode, tmp_path):
     """The same on two GPUs when the box has them: views sharded over 2 ranks, RCCL over xGMI, the union of the ranks'
     volumes / partial meshes equals the single-GPU result (counts and colour sums exact, tsdf within 2e-6)."""
