@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import activate, bin_instances, preprocess, rasterize_forward, ref_available, ref_forward, render_flip_bounds
+from . import activate, bin_instances, preprocess, rasterize_forward, ref_available, ref_forward, render, render_flip_bounds
 
 
 def quantize_u8(img_chw: np.ndarray) -> np.ndarray:
@@ -36,18 +36,11 @@ def image_parity(img: np.ndarray, ref: np.ndarray, rgb8: np.ndarray | None = Non
 CLEAN_BAR = 2e-4     # max |delta| of the fp32 image where no threshold decision can flip
 
 
-def flip_attribution(g: dict, cam, W: int, H: int, img: np.ndarray, ref: np.ndarray, bg=(0.0, 0.0, 0.0),
-                     rel_eps: float = 1e-5) -> dict:
-    """Turns "max |delta| is one threshold flip" into a checked statement.  From the oracle's own projection and
-    instance lists (the reference's, bit for bit) `render_flip_bounds` finds every (pixel, instance) decision of
-    renderCUDA taken within ``rel_eps`` of its threshold and bounds the change a flip can cause.  Returns the split
-    figures; ``ok`` = max |delta| <= CLEAN_BAR on pixels without a candidate AND |delta| <= CLEAN_BAR + bound elsewhere,
-    where bound = flips + the reference's own rounding noise on ill-conditioned evaluations (`cond`, see the C source)."""
-    s, q, o = activate(g["scaling"], g["rotation"], g["opacity"])
-    shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
-    geom = preprocess(g["xyz"], s, q, o, shs, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
-                      cam.tanfovx, cam.tanfovy)
+def _attribute(geom: dict, W: int, H: int, img: np.ndarray, ref: np.ndarray | None, bg, rel_eps: float) -> dict:
     pl, ranges = bin_instances(geom, W, H)
+    bgv = np.asarray(bg, np.float32)
+    if ref is None:
+        ref = render(W, H, ranges, pl, geom["means2D"], geom["rgb"], geom["conic_opacity"], bgv)[0]
     cmax = float(max(1.0, float(geom["rgb"].max(initial=0.0)), float(np.max(bg))))
     fb = render_flip_bounds(W, H, ranges, pl, geom["means2D"], geom["conic_opacity"], cmax, rel_eps)
     d = np.abs(np.asarray(img, np.float64) - np.asarray(ref, np.float64)).max(axis=0)     # [H,W], worst channel
@@ -59,12 +52,49 @@ def flip_attribution(g: dict, cam, W: int, H: int, img: np.ndarray, ref: np.ndar
     detail = [dict(y=int(i // W), x=int(i % W), delta=float(d.ravel()[i]), bound=float(fb["bound"].ravel()[i]),
                    cond=float(fb["cond"].ravel()[i])) for i in worst if excess.ravel()[i] > 0]
     return dict(flip_pixels=int(cand.sum()), ill_conditioned_pixels=int((fb["cond"] > CLEAN_BAR / 4).sum()),
-                unexplained_without_conditioning=int((excess_nocond > 0).sum()), worst_unexplained=detail, flip_pixels_alpha=int((fb["n_alpha"] > 0).sum()),
+                unexplained_without_conditioning=int((excess_nocond > 0).sum()), worst_unexplained=detail,
+                flip_pixels_alpha=int((fb["n_alpha"] > 0).sum()),
                 flip_pixels_T=int((fb["n_T"] > 0).sum()), flip_pixels_power=int((fb["n_power"] > 0).sum()),
                 max_abs_clean=clean_max, max_abs_flip=float(d[cand].max()) if cand.any() else 0.0,
                 pixels_over_clean_bar=int((d > CLEAN_BAR).sum()), unexplained_pixels=int((excess > 0).sum()),
                 worst_excess=float(excess.max()), rel_eps=rel_eps, clean_bar=CLEAN_BAR,
                 ok=bool(clean_max <= CLEAN_BAR and (excess <= 0).all()))
+
+
+def flip_attribution(g: dict, cam, W: int, H: int, img: np.ndarray, ref: np.ndarray, bg=(0.0, 0.0, 0.0),
+                     rel_eps: float = 1e-5) -> dict:
+    """Turns "max |delta| is one threshold flip" into a checked statement.  From the oracle's own projection and
+    instance lists (the reference's, bit for bit) `render_flip_bounds` finds every (pixel, instance) decision of
+    renderCUDA taken within ``rel_eps`` of its threshold and bounds the change a flip can cause.  Returns the split
+    figures; ``ok`` = max |delta| <= CLEAN_BAR on pixels without a candidate AND |delta| <= CLEAN_BAR + bound elsewhere,
+    where bound = flips + the reference's own rounding noise on ill-conditioned evaluations (`cond`, see the C source).
+    Meaningful when the implementation under test projected the SAME record (activated inputs: bit-exact); for the
+    fused raw-parameter path use `compositing_attribution`."""
+    s, q, o = activate(g["scaling"], g["rotation"], g["opacity"])
+    shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+    geom = preprocess(g["xyz"], s, q, o, shs, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                      cam.tanfovx, cam.tanfovy)
+    return _attribute(geom, W, H, img, ref, bg, rel_eps)
+
+
+def compositing_attribution(record: dict, radii: np.ndarray, W: int, H: int, img: np.ndarray, bg=(0.0, 0.0, 0.0),
+                            rel_eps: float = 1e-5) -> dict:
+    """The same statement for the COMPOSITING stage alone: the oracle bins and composites the record the implementation
+    itself projected (``record`` = Rasterizer.download_geometry: means2D, depths, conic_opacity, rgb; ``radii`` from the
+    render) with the reference's rules, so both sides start from identical inputs.  Needed on the fused raw-parameter path:
+    exp / sigmoid / normalize differ from numpy's in the last ulp, and the inverse of a 100 : 1 anisotropic covariance
+    amplifies that to ~1e-4 of `power` -- a projection-side difference the reference would show against itself with another
+    libm, and far outside the 1e-5 band of a compositing flip."""
+    geom = dict(radii=np.ascontiguousarray(radii, np.int32), means2D=np.ascontiguousarray(record["means2D"], np.float32),
+                depths=np.ascontiguousarray(record["depths"], np.float32),
+                conic_opacity=np.ascontiguousarray(record["conic_opacity"], np.float32),
+                rgb=np.ascontiguousarray(record["rgb"], np.float32))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    # capacity of the instance list: an upper bound of getRect's tile count (auxiliary.h:46-56) per Gaussian
+    r = geom["radii"].astype(np.int64)
+    span = 2 * r // 16 + 2
+    geom["tiles_touched"] = np.where(r > 0, np.minimum(span, gx) * np.minimum(span, gy), 0).astype(np.uint32)
+    return _attribute(geom, W, H, img, None, bg, rel_eps)
 
 
 def oracle_eye(g: dict, cam, W: int, H: int, bg=(0.0, 0.0, 0.0), prefer_reference: bool = True) -> dict:
