@@ -140,8 +140,7 @@ def main():
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
     ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "0")),
                     help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way); "
-                         "0 (default) = the K views of a job in equal sweeps of at most 32 views, at least two (the last sweep "
-                         "runs after the last render: K = 49 -> 25 + 24)")
+                         "0 (default) = the K views of a job in equal sweeps of at most 32 views, at least two")
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
@@ -186,7 +185,11 @@ def main():
     else:
         lo_k, K = rank * args.steps, args.steps
     Wm = args.warmup
+    fuse_plan = None
     if args.fuse_batch <= 0:
+        # the K views of a job in equal sweeps of at most 32 views, at least two.  (Measured in round 3: sweeps of decreasing
+        # size -- 10, 5, 3, 2 for K = 20, so that only a small sweep runs after the last render -- are slower, 0.356 vs
+        # 0.348 ms per step: the sweeps overlap the renders anyway and small sweeps re-read the voxel state more often.)
         n_sweeps = max(2, -(-K // 32))
         args.fuse_batch = max(1, -(-K // n_sweeps))
     cfg = synthetic.CONFIGS[args.config]
@@ -218,7 +221,8 @@ def main():
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
                               exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows,
-                              fuse_batch=args.fuse_batch, spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)),
+                              fuse_batch=(fuse_plan if fuse_plan and len(fuse_plan) > 1 else args.fuse_batch),
+                              spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)),
                               blend_cus=args.blend_cus, blend_streams=args.blend_streams, bin_cus=args.bin_cus, fuse_cus=args.fuse_cus)
     spatial_order_used = int(pipe.spatial_order)
     pipe_blend_cus = int(pipe.blend_cus)
@@ -506,7 +510,7 @@ def main():
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
                         exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight,
-                        tsdf_fuse_batch=args.fuse_batch, cu_partition=dict(blend_cus=pipe_blend_cus, blend_streams=args.blend_streams,
+                        tsdf_fuse_batch=(fuse_plan if fuse_plan else args.fuse_batch), cu_partition=dict(blend_cus=pipe_blend_cus, blend_streams=args.blend_streams,
                                                                            bin_cus=args.bin_cus, fuse_cus=args.fuse_cus),
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
             steady_state=steady,

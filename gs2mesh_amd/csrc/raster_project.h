@@ -115,29 +115,25 @@ GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
 // Projection + colour, one thread per Gaussian -- a streaming kernel (no LDS, no loop): activations, Sigma once
 // for all views of the batch, EWA projection, SH colour, the (cull-tightened) tile rect -> GeomRec.
 #define GS2M_PROJECT_THREADS 256
+// One Gaussian (array position gi) for the NV views of the batch: parameter loads (+ fused activations), Sigma once, EWA
+// projection, SH colour, the (cull-tightened) tile rect, the GeomRec stores.  On return pv[v] holds what was stored (rect
+// zeroed and ok = false when nothing of the Gaussian reaches view v) and op the activated opacity: the fused
+// projection + counting kernel continues from these registers.  s_sh = this wave's DMA landing zone, [12][64] float4 (DMA_SH only).
 template <int NV, bool DMA_SH>
-GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
-k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
-          int exact_cull) {
+GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs,
+                                  int* __restrict__ radii, int exact_cull, int gi, bool valid, float4* s_sh, int lane_id,
+                                  ProjView* pv, float& op, float& thr) {
     const int ncoef = (g.D + 1) * (g.D + 1);
-    // Packed SH copy: the 192-B row of every Gaussian of the wave goes straight from HBM into LDS (global_load_lds, 12 x 1 KiB
-    // per wave), issued BEFORE the parameter loads and the projection: one memory round trip per thread instead of two in
-    // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.
-    // The colour pass then reads the 16 coefficients of one channel at a time back from LDS.
-    __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
-    constexpr bool dma_sh = DMA_SH;   // the launcher picks it (gs2m_launch_project): packed, spatially ordered model
+    constexpr bool dma_sh = DMA_SH;
     {
-        const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
-        const bool valid = gi < g.P;
-        const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
         if (dma_sh && valid) {
             const float4* s4 = reinterpret_cast<const float4*>(g.shs_packed) + (size_t)(gi >> 6) * (12 * 64) + (gi & 63);
 #pragma unroll
             for (int k = 0; k < 12; ++k)
-                if (k * 4 < ncoef * 3) gs2m_global_load_lds16(s4 + k * 64, &s_sh[wave_id][k][0]);
+                if (k * 4 < ncoef * 3) gs2m_global_load_lds16(s4 + k * 64, &s_sh[k * 64]);
         }
-        ProjView pv[NV];
-        float op = 0.0f, thr = 0.0f;
+        op = 0.0f;
+        thr = 0.0f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             pv[v].ok = false;
@@ -250,7 +246,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
                     dz = dz / len;
                     if (dma_sh) {
                         // element e = 3 k + c of the row sits in float4 e / 4, component e % 4 of this lane's column
-                        const float* row = reinterpret_cast<const float*>(&s_sh[wave_id][0][lane_id]);
+                        const float* row = reinterpret_cast<const float*>(&s_sh[lane_id]);
                         float col[3];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
@@ -314,6 +310,23 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
     }
 }
 
+// Projection + colour, one thread per Gaussian -- a streaming kernel (no loop): see project_gaussian.
+// Packed SH copy (DMA_SH): the 192-B row of every Gaussian of the wave goes straight from HBM into LDS (global_load_lds, 12 x
+// 1 KiB per wave), issued BEFORE the parameter loads and the projection: one memory round trip per thread instead of two in
+// sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.  The
+// colour pass then reads the 16 coefficients of one channel at a time back from LDS.
+template <int NV, bool DMA_SH>
+GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
+k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
+          int exact_cull) {
+    __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
+    const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
+    const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
+    ProjView pv[NV];
+    float op, thr;
+    project_gaussian<NV, DMA_SH>(g, cams, recs, radii, exact_cull, gi, gi < g.P, &s_sh[DMA_SH ? wave_id : 0][0][0], lane_id, pv, op, thr);
+}
+
 // Gaussian -> workgroup assignment of the counting sort (k_count_tiles and k_scatter must agree: the histogram row of a
 // workgroup describes exactly the Gaussians it scatters).  Step `it` of wave `wave` of the workgroup with histogram row
 // `row` starts at the returned index (64 consecutive Gaussians, one per lane); *end = one past the last index it may take;
@@ -336,8 +349,124 @@ GS2M_DEVICE int bin_step_begin(int it, int wave, int nwaves, int row, int n_wg, 
     return first < (long long)stop ? (int)first : -1;
 }
 
+// Per-(view, Gaussian) input of the counting step: the geometry half of the GeomRec + the rect in BINNING rows.
+struct CountIn {
+    float mx, my, ca, cb, cc;
+    int x0, y0, x1, y1;
+    bool ok;
+};
+// from the stored 16 x 16 tile rect (x0, y0, x1, y1) to rows of the binning grid (tiles of 16 x th pixels)
+GS2M_DEVICE void count_in_set(CountIn& c, int x0, int y0, int x1, int y1, int rows) {
+    c.ok = x1 > x0 && y1 > y0;
+    c.x0 = c.ok ? x0 : 0;
+    c.x1 = c.ok ? x1 : 0;
+    c.y0 = c.ok ? y0 / rows : 0;
+    c.y1 = c.ok ? (y1 + rows - 1) / rows : 0;
+}
+
+// The counting step for the 64 Gaussians of one wave step (wave collectives: EVERY lane calls it): balanced
+// (Gaussian, tile) expansion, the workgroup's LDS tile histogram, the kept-tile masks of the small rects.
+template <int NV>
+GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, int P, unsigned* lhist, int hw, WaveStage* stage,
+                              unsigned long long* __restrict__ tilemask, int gx, int th, int exact_cull, int lane) {
+    // ---- balanced (Gaussian, tile) expansion, one view at a time (wave collectives: every lane) ----
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
+        const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
+        if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
+        unsigned* hh = lhist + v * hw;
+        const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
+        // ---- small rects: flattened item space ----
+        const bool small = area != 0u && area <= 64u;
+        const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
+        if (smalls != 0ull) {
+            const int k = gs2m_popc64(smalls & lanes_lt(lane));
+            const unsigned incl = wave_inclusive_scan(small ? area : 0u);
+            const unsigned total = gs2m_shfl(incl, 63);
+            const unsigned start = incl - (small ? area : 0u);
+            gs2m_wave_sync();
+            stage->heads[lane] = 0u;
+            stage->heads[lane + 64] = 0u;
+            if (lane < 2) stage->heads[128 + lane] = 0u;
+            gs2m_wave_sync();
+            if (small) {
+                stage->mx[k] = pv[v].mx;
+                stage->my[k] = pv[v].my;
+                stage->ca[k] = pv[v].ca;
+                stage->cb[k] = pv[v].cb;
+                stage->cc[k] = pv[v].cc;
+                stage->thr[k] = thr;
+                cull_slopes(pv[v].ca, pv[v].cb, pv[v].cc, stage->rx[k], stage->ry[k]);
+                stage->swh[k] = start | (w << 16) | (h << 24);
+                stage->xy0[k] = xy0;
+                stage->mlo[k] = 0u;
+                stage->mhi[k] = 0u;
+                atomicOr(&stage->heads[start >> 5], 1u << (start & 31u));
+            }
+            gs2m_wave_sync();
+            int kbase = 0;
+            for (unsigned b0 = 0; b0 < total; b0 += 64u) {
+                const unsigned long long H =
+                    (unsigned long long)stage->heads[b0 >> 5] | ((unsigned long long)stage->heads[(b0 >> 5) + 1] << 32);
+                const int kk = kbase + gs2m_popc64(H & lanes_le(lane)) - 1;
+                kbase += gs2m_popc64(H);
+                const unsigned item = b0 + (unsigned)lane;
+                const bool act = item < total;
+                bool keep = false;
+                unsigned li = 0u;
+                if (act) {
+                    const unsigned swh = stage->swh[kk];
+                    const unsigned ow = (swh >> 16) & 0xffu, oh = swh >> 24;
+                    li = item - (swh & 0xffffu);
+                    unsigned rx, ry;
+                    rect_coords(li, ow, gs2m_fast_rcp((float)ow), rx, ry);
+                    const unsigned oxy = stage->xy0[kk];
+                    const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
+                    keep = true;
+                    if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
+                        keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
+                                                   stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty, th);
+                    if (keep) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
+                }
+                // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
+                const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
+                if (act && (lane == 0 || ((H >> lane) & 1ull))) {
+                    const unsigned long long rest = lane == 63 ? 0ull : (H >> (lane + 1));
+                    const int len = rest ? __ffsll(rest) : 64 - lane;
+                    const unsigned long long run = (kept >> lane) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
+                    const unsigned long long bits = run << li;
+                    stage->mlo[kk] |= (unsigned)bits;
+                    stage->mhi[kk] |= (unsigned)(bits >> 32);
+                }
+            }
+            gs2m_wave_sync();
+            if (small)
+                tilemask[(size_t)v * P + gi] = (unsigned long long)stage->mlo[k] | ((unsigned long long)stage->mhi[k] << 32);
+        }
+        // ---- rects of more than 64 tiles: the whole wave walks one owner at a time ----
+        unsigned long long bigs = gs2m_ballot(area > 64u ? 1 : 0);
+        while (bigs != 0ull) {
+            const int o = __ffsll(bigs) - 1;
+            bigs &= bigs - 1ull;
+            const unsigned ow = gs2m_shfl(w, o), oa = gs2m_shfl(area, o), oxy = gs2m_shfl(xy0, o);
+            const float omx = gs2m_shfl(pv[v].mx, o), omy = gs2m_shfl(pv[v].my, o), oca = gs2m_shfl(pv[v].ca, o),
+                        ocb = gs2m_shfl(pv[v].cb, o), occ = gs2m_shfl(pv[v].cc, o), othr = gs2m_shfl(thr, o);
+            const float oinv = gs2m_fast_rcp((float)ow);
+            float orx, ory;
+            cull_slopes(oca, ocb, occ, orx, ory);
+            for (unsigned li = (unsigned)lane; li < oa; li += 64u) {
+                unsigned rx, ry;
+                rect_coords(li, ow, oinv, rx, ry);
+                const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
+                if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
+            }
+        }
+    }
+}
+
 // Tile counting: same Gaussian -> workgroup assignment as k_scatter.  Re-reads the geometry half of the
-// GeomRecs written by k_project, expands every rect into (Gaussian, tile) pairs with the balanced walk,
+// GeomRecs written by k_project, expands every rect into (Gaussian, tile) pairs with the balanced walk (count_expand),
 // bumps the workgroup-private LDS tile histogram, records the kept tiles of small rects as bit masks and
 // writes the workgroup's histogram row.
 template <int NV>
@@ -345,7 +474,6 @@ GS2M_KERNEL void __launch_bounds__(1024)
 k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
               unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull, int interleave) {
     GS2M_DYN_LDS(unsigned, lds);
-    struct { int P; } g = {P};
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
@@ -366,29 +494,17 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
         if (first < 0) break;   // wave-uniform; the loop body only uses wave collectives
         const int gi = first + lane;
         const bool valid = gi < end;
-        struct {
-            float mx, my, ca, cb, cc;
-            int x0, y0, x1, y1;
-            bool ok;
-        } pv[NV];
+        CountIn pv[NV];
         float thr = 0.0f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            pv[v].ok = false;
-            pv[v].x0 = pv[v].y0 = pv[v].x1 = pv[v].y1 = 0;
+            count_in_set(pv[v], 0, 0, 0, 0, rows);
             pv[v].mx = pv[v].my = pv[v].ca = pv[v].cb = pv[v].cc = 0.0f;
             if (valid) {
                 const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi);
                 const float4 w2 = r4[2];
                 const unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w);
-                pv[v].x0 = (int)(rect0 & 0xffffu);
-                pv[v].y0 = (int)(rect0 >> 16);
-                pv[v].x1 = (int)(rect1 & 0xffffu);
-                pv[v].y1 = (int)(rect1 >> 16);
-                pv[v].ok = pv[v].x1 > pv[v].x0 && pv[v].y1 > pv[v].y0;
-                // rows of the binning grid (tiles of 16 x th pixels) covered by the rect
-                pv[v].y0 = pv[v].y0 / rows;
-                pv[v].y1 = (pv[v].y1 + rows - 1) / rows;
+                count_in_set(pv[v], (int)(rect0 & 0xffffu), (int)(rect0 >> 16), (int)(rect1 & 0xffffu), (int)(rect1 >> 16), rows);
                 if (pv[v].ok) {
                     const float4 w0 = r4[0];
                     const float4 w1 = r4[1];
@@ -398,105 +514,10 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
                     pv[v].cb = w0.w;
                     pv[v].cc = w1.x;
                     if (exact_cull) thr = cull_threshold(w1.y);
-                } else {
-                    pv[v].x0 = pv[v].y0 = pv[v].x1 = pv[v].y1 = 0;
                 }
             }
         }
-        // ---- balanced (Gaussian, tile) expansion, one view at a time (wave collectives: every lane) ----
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
-            const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
-            if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
-            unsigned* hh = lhist + v * hw;
-            const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
-            // ---- small rects: flattened item space ----
-            const bool small = area != 0u && area <= 64u;
-            const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
-            if (smalls != 0ull) {
-                const int k = gs2m_popc64(smalls & lanes_lt(lane));
-                const unsigned incl = wave_inclusive_scan(small ? area : 0u);
-                const unsigned total = gs2m_shfl(incl, 63);
-                const unsigned start = incl - (small ? area : 0u);
-                gs2m_wave_sync();
-                stage->heads[lane] = 0u;
-                stage->heads[lane + 64] = 0u;
-                if (lane < 2) stage->heads[128 + lane] = 0u;
-                gs2m_wave_sync();
-                if (small) {
-                    stage->mx[k] = pv[v].mx;
-                    stage->my[k] = pv[v].my;
-                    stage->ca[k] = pv[v].ca;
-                    stage->cb[k] = pv[v].cb;
-                    stage->cc[k] = pv[v].cc;
-                    stage->thr[k] = thr;
-                    cull_slopes(pv[v].ca, pv[v].cb, pv[v].cc, stage->rx[k], stage->ry[k]);
-                    stage->swh[k] = start | (w << 16) | (h << 24);
-                    stage->xy0[k] = xy0;
-                    stage->mlo[k] = 0u;
-                    stage->mhi[k] = 0u;
-                    atomicOr(&stage->heads[start >> 5], 1u << (start & 31u));
-                }
-                gs2m_wave_sync();
-                int kbase = 0;
-                for (unsigned b0 = 0; b0 < total; b0 += 64u) {
-                    const unsigned long long H =
-                        (unsigned long long)stage->heads[b0 >> 5] | ((unsigned long long)stage->heads[(b0 >> 5) + 1] << 32);
-                    const int kk = kbase + gs2m_popc64(H & lanes_le(lane)) - 1;
-                    kbase += gs2m_popc64(H);
-                    const unsigned item = b0 + (unsigned)lane;
-                    const bool act = item < total;
-                    bool keep = false;
-                    unsigned li = 0u;
-                    if (act) {
-                        const unsigned swh = stage->swh[kk];
-                        const unsigned ow = (swh >> 16) & 0xffu, oh = swh >> 24;
-                        li = item - (swh & 0xffffu);
-                        unsigned rx, ry;
-                        rect_coords(li, ow, gs2m_fast_rcp((float)ow), rx, ry);
-                        const unsigned oxy = stage->xy0[kk];
-                        const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                        keep = true;
-                        if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
-                            keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
-                                                       stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty, th);
-                        if (keep) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
-                    }
-                    // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
-                    const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
-                    if (act && (lane == 0 || ((H >> lane) & 1ull))) {
-                        const unsigned long long rest = lane == 63 ? 0ull : (H >> (lane + 1));
-                        const int len = rest ? __ffsll(rest) : 64 - lane;
-                        const unsigned long long run = (kept >> lane) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull));
-                        const unsigned long long bits = run << li;
-                        stage->mlo[kk] |= (unsigned)bits;
-                        stage->mhi[kk] |= (unsigned)(bits >> 32);
-                    }
-                }
-                gs2m_wave_sync();
-                if (small)
-                    tilemask[(size_t)v * g.P + gi] = (unsigned long long)stage->mlo[k] | ((unsigned long long)stage->mhi[k] << 32);
-            }
-            // ---- rects of more than 64 tiles: the whole wave walks one owner at a time ----
-            unsigned long long bigs = gs2m_ballot(area > 64u ? 1 : 0);
-            while (bigs != 0ull) {
-                const int o = __ffsll(bigs) - 1;
-                bigs &= bigs - 1ull;
-                const unsigned ow = gs2m_shfl(w, o), oa = gs2m_shfl(area, o), oxy = gs2m_shfl(xy0, o);
-                const float omx = gs2m_shfl(pv[v].mx, o), omy = gs2m_shfl(pv[v].my, o), oca = gs2m_shfl(pv[v].ca, o),
-                            ocb = gs2m_shfl(pv[v].cb, o), occ = gs2m_shfl(pv[v].cc, o), othr = gs2m_shfl(thr, o);
-                const float oinv = gs2m_fast_rcp((float)ow);
-                float orx, ory;
-                cull_slopes(oca, ocb, occ, orx, ory);
-                for (unsigned li = (unsigned)lane; li < oa; li += 64u) {
-                    unsigned rx, ry;
-                    rect_coords(li, ow, oinv, rx, ry);
-                    const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
-                }
-            }
-        }
+        count_expand<NV>(pv, thr, valid, gi, P, lhist, hw, stage, tilemask, gx, th, exact_cull, lane);
     }
     __syncthreads();
     for (int i = tid; i < NV * tiles; i += nthreads) {

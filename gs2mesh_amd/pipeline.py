@@ -96,7 +96,14 @@ class RenderFusePipeline:
         # fuse_batch > 1: the views are integrated `fuse_batch` at a time by the voxel-stationary batch kernel
         # (gs2m_tsdf_integrate_batch: same result as view by view, one voxel-state read + write per batch).  The left
         # image of every pending view is kept in its own buffer (a slot's image is re-rendered before the batch runs).
-        self.fuse_batch = max(1, min(int(fuse_batch), 64))
+        # a list / tuple = a PLAN of batch sizes, cycled (e.g. 10, 5, 3, 2 for a 20-view job: the sweep that runs after the
+        # last render -- nothing left to overlap it with -- is the smallest one)
+        plan = [int(b) for b in fuse_batch] if isinstance(fuse_batch, (list, tuple)) else [int(fuse_batch)]
+        self._plan = [max(1, min(b, 64)) for b in plan] or [1]
+        if len(self._plan) > 1 and min(self._plan) < 2:
+            self._plan = [max(2, b) for b in self._plan]       # inside a plan every sweep goes through the batch kernel
+        self._plan_i = 0
+        self.fuse_batch = max(self._plan)
         self._pending = []
         # two sets of image buffers: batch b + 1 is collected while batch b is still being integrated
         # (the u8 pair of a pending view is rendered straight into its buffer: no copy out of the slot)
@@ -149,7 +156,7 @@ class RenderFusePipeline:
             r.render_views(self.g, cams, bg=self.bg, out_color=self.color[0], out_rgb8=self.rgb8[0], sync=False)
             if depth is not None and self.fuse_batch > 1:
                 self._pending.append((k, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
-                if len(self._pending) == self.fuse_batch:
+                if len(self._pending) == self._plan[self._plan_i % len(self._plan)]:
                     self._flush_batch()
             elif depth is not None:
                 self.volume.integrate(RGBDImage(self.rgb8[0][0], depth, depth_scale=depth_scale, depth_trunc=depth_trunc),
@@ -186,7 +193,7 @@ class RenderFusePipeline:
                     t.record_stream(self.fuse_stream)
             self._pending.append((len(self._pending), depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
             self._fused[j].record(rs)                      # the slot's image has been copied out: free to re-render
-            if len(self._pending) == self.fuse_batch:
+            if len(self._pending) == self._plan[self._plan_i % len(self._plan)]:
                 self._flush_batch(cur)
         elif depth is not None:
             fs = self.fuse_stream
@@ -206,6 +213,7 @@ class RenderFusePipeline:
         if not self._pending:
             return
         pend, self._pending = self._pending, []
+        self._plan_i += 1
         p0 = pend[0]
         if any((p[4], p[5], p[6]) != (p0[4], p0[5], p0[6]) for p in pend):
             raise ValueError("fuse_batch: the views of a batch must share depth_scale / depth_trunc / min_depth")
@@ -236,8 +244,9 @@ class RenderFusePipeline:
 
     def drain(self):
         """Host waits for everything submitted so far (render + fuse streams; a partial batch is integrated first); no
-        status query, no device-wide sync."""
+        status query, no device-wide sync.  The batch plan starts over."""
         self._flush_batch(torch.cuda.current_stream(self.device) if self.inflight > 1 else None)
+        self._plan_i = 0
         if self.inflight > 1:
             for s in self.render_streams:
                 s.synchronize()

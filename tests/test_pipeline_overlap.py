@@ -54,7 +54,7 @@ def test_overlapped_pipeline_equals_serial(inflight):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("inflight,fuse_batch", [(1, 4), (3, 4), (2, 2)])
+@pytest.mark.parametrize("inflight,fuse_batch", [(1, 4), (3, 4), (2, 2), (3, [3, 2]), (1, [2, 3])])
 def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
     """fuse_batch > 1: the views are integrated by the voxel-stationary batch kernel, 4 (then the remaining 2) at a time,
     from per-view copies of the left image: images and volume are bit-identical to the serial view-by-view order."""
