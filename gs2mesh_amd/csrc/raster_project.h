@@ -14,6 +14,19 @@
 #pragma once
 #include "raster_math.h"
 
+// Workgroup-private tile histogram of k_count_tiles: two 16-bit counters per LDS word.  Tile t shares its word with tile
+// t + hw (hw = words per view = ceil(tiles / 2)), NOT with tile t + 1: the lanes of a wave walk ADJACENT tiles of the same
+// rect, and two neighbours in one word were a same-address atomic pair on every second lane (0.79 bank-conflict cycles per
+// LDS instruction, PMC round 2); now neighbouring tiles are neighbouring words = different banks.
+GS2M_DEVICE void hist_bump(unsigned* hh, int hw, int t) {
+    const bool hi = t >= hw;
+    atomicAdd(&hh[hi ? t - hw : t], hi ? 0x10000u : 1u);
+}
+GS2M_DEVICE unsigned hist_get(const unsigned* hh, int hw, int t) {
+    const bool hi = t >= hw;
+    return (hh[hi ? t - hw : t] >> (hi ? 16 : 0)) & 0xffffu;
+}
+
 struct ProjView {
     float mx, my, ca, cb, cc, depth, cova, covc;
     int x0, y0, x1, y1, radius;
@@ -245,22 +258,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                     dy = dy / len;
                     dz = dz / len;
                     if (dma_sh) {
-                        // element e = 3 k + c of the row sits in float4 e / 4, component e % 4 of this lane's column
-                        const float* row = reinterpret_cast<const float*>(&s_sh[lane_id]);
-                        float col[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            float coef[16];
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) {
-                                const int e = 3 * k + c;
-                                coef[k] = k < ncoef ? row[(e >> 2) * (64 * 4) + (e & 3)] : 0.0f;
-                            }
-                            col[c] = sh_channel<1>(g.D, coef, 0, dx, dy, dz);
-                        }
-                        cr = col[0];
-                        cg = col[1];
-                        cb = col[2];
+                        sh_rgb_from_lds(g.D, s_sh, lane_id, dx, dy, dz, cr, cg, cb);   // b128 reads of this lane's row
                     } else {
                         cr = sh_channel(g.D, sh, 0, dx, dy, dz);
                         cg = sh_channel(g.D, sh, 1, dx, dy, dz);
@@ -427,7 +425,7 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
                     if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
                         keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
                                                    stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty, th);
-                    if (keep) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
+                    if (keep) hist_bump(hh, hw, ty * gx + tx);
                 }
                 // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
                 const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
@@ -459,7 +457,7 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
                 unsigned rx, ry;
                 rect_coords(li, ow, oinv, rx, ry);
                 const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) atomicAdd(&hh[(ty * gx + tx) >> 1], 1u << (((ty * gx + tx) & 1) << 4));
+                if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) hist_bump(hh, hw, ty * gx + tx);
             }
         }
     }
@@ -522,7 +520,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     __syncthreads();
     for (int i = tid; i < NV * tiles; i += nthreads) {
         const int v = i / tiles, t = i - v * tiles;
-        hist[((size_t)v * n_wg + row) * tiles + t] = (lhist[v * hw + (t >> 1)] >> ((t & 1) << 4)) & 0xffffu;
+        hist[((size_t)v * n_wg + row) * tiles + t] = hist_get(lhist + v * hw, hw, t);
     }
 }
 

@@ -8,7 +8,9 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "C2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", tag)
+src = os.path.join(root, "gpurun_out", f"{tag}_{cfg}")
+if not os.path.isdir(src):
+    src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
@@ -16,7 +18,7 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
 for name in ("bench.json", "stats_bench.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
-        shutil.copy(p, os.path.join(dst, f"{tag}_{name}"))
+        shutil.copy(p, os.path.join(dst, f"{tag}_{cfg}_{name}"))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in glob.glob(os.path.join(src, "pmc_*")):
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
@@ -24,21 +26,30 @@ for d in glob.glob(os.path.join(src, "pmc_*")):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if k.startswith("k_")}
-json.dump(summary, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
-stage_of = {"k_project<2>": "project", "k_count_tiles<2>": "count_tiles", "k_hist_colscan": "hist_colscan", "k_tile_scan": "tile_scan",
-            "k_scatter<2>": "scatter", "k_sort_tiles_small": "sort_tiles", "k_tsdf_touch": "tsdf_touch",
-            "k_tsdf_integrate": "tsdf_integrate"}
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_{cfg}.json"), "w"), indent=1, sort_keys=True)
+prefix_of = (("k_project", "project"), ("k_count_tiles", "count_tiles"), ("k_hist_colscan", "hist_colscan"), ("k_tile_scan", "tile_scan"),
+             ("k_scatter", "scatter"), ("k_sort_tiles_small", "sort_tiles"), ("k_tsdf_touch", "tsdf_touch"),
+             ("k_tsdf_integrate", "tsdf_integrate"), ("k_blend", "blend"))
+stage_of = {}
+for k in summary:
+    for pre, st in prefix_of:
+        if k.startswith(pre):
+            stage_of[k] = st
+            break
 bench = json.load(open(os.path.join(src, "bench.json"))) if os.path.exists(os.path.join(src, "bench.json")) else {}
 traffic = {}
 for k, cs in summary.items():
-    stage = stage_of.get(k, "blend" if k.startswith("k_blend") else None)
+    stage = stage_of.get(k)
     if stage and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
         traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                               fetch_kib=cs["FETCH_SIZE"], write_kib=cs["WRITE_SIZE"],
                               valu_insts_per_launch=int(cs["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in cs else None,
                               valu_trans_per_launch=int(cs["SQ_INSTS_VALU_TRANS_F32"]) if "SQ_INSTS_VALU_TRANS_F32" in cs else None,
                               date=f"round {tag[1]}" if tag[:1] == "r" and tag[1:2].isdigit() else tag,
-                              cull=bench.get("config", {}).get("exact_tile_cull", 1), source=f"profiles/{tag}_pmc.json")
+                              salu_insts_per_launch=int(cs["SQ_INSTS_SALU"]) if "SQ_INSTS_SALU" in cs else None,
+                              branch_insts_per_launch=int(cs["SQ_INSTS_BRANCH"]) if "SQ_INSTS_BRANCH" in cs else None,
+                              lds_bank_conflict_cycles=int(cs["SQ_LDS_BANK_CONFLICT"]) if "SQ_LDS_BANK_CONFLICT" in cs else None,
+                              cull=bench.get("config", {}).get("exact_tile_cull", 1), source=f"profiles/{tag}_pmc_{cfg}.json")
 tp = os.path.join(dst, "pmc_traffic.json")
 allt = json.load(open(tp)) if os.path.exists(tp) else {}
 allt[cfg] = traffic
