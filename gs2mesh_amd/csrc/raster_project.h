@@ -486,12 +486,38 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     __syncthreads();
     // histogram row of this workgroup: the workgroups of an XCD own consecutive rows (see k_scatter)
     const int row = (int)gs2m_xcd_contiguous(blockIdx.x, (unsigned)n_wg);
+    // The records of the NEXT wave step are loaded before the current one is expanded (a workgroup of a 2 M-Gaussian model
+    // takes ~8 steps per wave, and every step used to start with two dependent HBM round trips: rect, then geometry).
+    float4 nw0[NV], nw1[NV], nw2[NV];
+    int end = 0;
+    int first = bin_step_begin(0, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
+    auto fetch = [&](int f0, int e0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            nw0[v] = nw1[v] = nw2[v] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (f0 >= 0 && f0 + lane < e0) {
+                const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + f0 + lane);
+                nw2[v] = r4[2];
+                nw0[v] = r4[0];
+                nw1[v] = r4[1];
+            }
+        }
+    };
+    fetch(first, end);
     for (int it = 0;; ++it) {
-        int end;
-        const int first = bin_step_begin(it, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
         if (first < 0) break;   // wave-uniform; the loop body only uses wave collectives
         const int gi = first + lane;
         const bool valid = gi < end;
+        float4 w0[NV], w1[NV], w2[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            w0[v] = nw0[v];
+            w1[v] = nw1[v];
+            w2[v] = nw2[v];
+        }
+        int end_next = 0;
+        const int first_next = bin_step_begin(it + 1, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end_next);
+        fetch(first_next, end_next);
         CountIn pv[NV];
         float thr = 0.0f;
 #pragma unroll
@@ -499,23 +525,21 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
             count_in_set(pv[v], 0, 0, 0, 0, rows);
             pv[v].mx = pv[v].my = pv[v].ca = pv[v].cb = pv[v].cc = 0.0f;
             if (valid) {
-                const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi);
-                const float4 w2 = r4[2];
-                const unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w);
+                const unsigned rect0 = __float_as_uint(w2[v].z), rect1 = __float_as_uint(w2[v].w);
                 count_in_set(pv[v], (int)(rect0 & 0xffffu), (int)(rect0 >> 16), (int)(rect1 & 0xffffu), (int)(rect1 >> 16), rows);
                 if (pv[v].ok) {
-                    const float4 w0 = r4[0];
-                    const float4 w1 = r4[1];
-                    pv[v].mx = w0.x;
-                    pv[v].my = w0.y;
-                    pv[v].ca = w0.z;
-                    pv[v].cb = w0.w;
-                    pv[v].cc = w1.x;
-                    if (exact_cull) thr = cull_threshold(w1.y);
+                    pv[v].mx = w0[v].x;
+                    pv[v].my = w0[v].y;
+                    pv[v].ca = w0[v].z;
+                    pv[v].cb = w0[v].w;
+                    pv[v].cc = w1[v].x;
+                    if (exact_cull) thr = cull_threshold(w1[v].y);
                 }
             }
         }
         count_expand<NV>(pv, thr, valid, gi, P, lhist, hw, stage, tilemask, gx, th, exact_cull, lane);
+        first = first_next;
+        end = end_next;
     }
     __syncthreads();
     for (int i = tid; i < NV * tiles; i += nthreads) {
@@ -562,20 +586,37 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
     // working set of a walk that alternates between the views)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+        // next-step prefetch (rect + depth vector, id, tile mask) as in k_count_tiles
+        float4 n_w2;
+        unsigned n_kid;
+        unsigned long long n_msk;
+        int end = 0;
+        int first = bin_step_begin(0, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
+        auto fetch = [&](int f0, int e0) __attribute__((always_inline)) {
+            n_w2 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            n_kid = (unsigned)(f0 + lane);
+            n_msk = 0ull;
+            if (f0 >= 0 && f0 + lane < e0) {
+                if (ids) n_kid = (unsigned)ids[f0 + lane];
+                n_w2 = reinterpret_cast<const float4*>(recs + (size_t)v * P + f0 + lane)[2];
+                n_msk = tilemask[(size_t)v * P + f0 + lane];   // only meaningful (and only used) for rects of <= 64 tiles
+            }
+        };
+        fetch(first, end);
         for (int it = 0;; ++it) {
-            int end;
-            const int first = bin_step_begin(it, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
             if (first < 0) break;   // wave-uniform
             const int gi = first + lane;
-            unsigned rect0 = 0u, rect1 = 0u, dbits = 0u;
-            unsigned kid = (unsigned)gi;   // low word of the sort key: the Gaussian's id (ties in depth resolve as in the reference)
-            if (gi < end) {
-                if (ids) kid = (unsigned)ids[gi];
-                const float4 w2 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gi)[2];
-                rect0 = __float_as_uint(w2.z);
-                rect1 = __float_as_uint(w2.w);
-                dbits = __float_as_uint(w2.y);
+            const float4 w2 = n_w2;
+            unsigned kid = n_kid;   // low word of the sort key: the Gaussian's id (ties in depth resolve as in the reference)
+            const unsigned long long msk_pre = n_msk;
+            {
+                int end_next = 0;
+                const int first_next = bin_step_begin(it + 1, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end_next);
+                fetch(first_next, end_next);
+                first = first_next;      // rotated here: the wave-uniform `continue` below skips nothing of the pipeline
+                end = end_next;
             }
+            unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w), dbits = __float_as_uint(w2.y);
             const int x0 = (int)(rect0 & 0xffffu), x1 = (int)(rect1 & 0xffffu);
             int y0 = (int)(rect0 >> 16), y1 = (int)(rect1 >> 16);
             const bool ok = x1 > x0 && y1 > y0;
@@ -590,8 +631,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
             const bool small = area != 0u && area <= 64u;
             const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
             if (smalls != 0ull) {
-                unsigned long long msk = 0ull;
-                if (small) msk = tilemask[(size_t)v * P + gi];
+                const unsigned long long msk = small ? msk_pre : 0ull;
                 const int k = gs2m_popc64(smalls & lanes_lt(lane));
                 const unsigned incl = wave_inclusive_scan(small ? area : 0u);
                 const unsigned total = gs2m_shfl(incl, 63);
