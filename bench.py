@@ -57,6 +57,14 @@ def alg_bytes(cfg, p_vis, p_vis_union, N_eye, U_frame=0.0):
     return alg, B_pair
 
 
+def committed_traffic(cfg_name):
+    """HBM bytes per launch and stage from the committed PMC passes (profiles/pmc_traffic.json; not measured in this run)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(cfg_name, {})
+    except Exception:
+        return {}
+
+
 def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     """Render-only sub-measurement (no TSDF, serial on one stream, hipEvents per launch): used for the C3 sub-line."""
     import torch
@@ -103,13 +111,16 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     R.set_option(_lib.OPT_STAGE_TIMING, 0)
     _, ov, _ = R.status(2)
     alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye)
-    stages = {k: dict(avg_us=round(1e3 * ms / max(c, 1), 2), frac_hbm=round(alg[k] / max(1e-9, 1e-3 * ms / max(c, 1)) / HBM_PEAK, 4))
+    tr = committed_traffic(cfg_name)
+    stages = {k: dict(avg_us=round(1e3 * ms / max(c, 1), 2), frac_hbm=round(alg[k] / max(1e-9, 1e-3 * ms / max(c, 1)) / HBM_PEAK, 4),
+                      alg_bytes=int(alg[k]), traffic=(tr.get(k, {}).get("hbm_bytes_per_launch") if tr.get(k, {}).get("cull") == args.cull else None))
               for k, (ms, c) in st.items()}
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
     return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {len(cams)} pairs, "
                          f"serial on one stream",
                 num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis, overflow=bool(ov),
                 ms_per_pair_wall=round(1e3 * dt, 4), stages=stages,
+                traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 * FETCH + WRITE) KiB per launch)",
                 binning_us=round(sum(stages[k]["avg_us"] for k in ("count_tiles", "hist_colscan", "tile_scan", "scatter", "sort_tiles")), 1),
                 raster_roofline=dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
                                      achieved_GBps=round(B_pair / t_raster / 1e9, 1),
@@ -158,6 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 render-only sub-measurement")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the 2K-step job of the steady-state probe")
     args = ap.parse_args()
 
     import torch
@@ -200,8 +212,10 @@ def main():
     g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
     gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
     gd["raw"] = True
-    n_local = K + Wm
-    # timed views of this rank: [lo_k, lo_k + K) of the job's K_total views; the warm-up views precede them on the ring
+    # timed views of this rank: [lo_k, lo_k + K) of the job's K_total views; the warm-up views precede them on the ring; at
+    # N = 1 another K views follow for the 2K-step job of the steady-state probe (slope between the K- and the 2K-step job)
+    probe = world == 1 and not args.no_steady_state
+    n_local = K + Wm + (K if probe else 0)
     poses = synthetic.ring_poses(n_local, cfg.ring_radius, first=lo_k - Wm, total=max(K_total, 1))
     cams, cams_np, depths, Es = [], [], [], []
     for p in poses:
@@ -303,23 +317,26 @@ def main():
     dt = statistics.median(dts)
     t_red = statistics.median(reds) if reds else None
 
-    # ---- one more (untimed) repeat with a timing event after every pair: steady-state step time vs pipeline fill / drain
-    vol.reset()
-    barrier()
-    pipe.trace_events = []
-    for i in range(Wm, Wm + K):
-        step(i)
-    pipe.drain()
-    barrier()
-    evs, pipe.trace_events = pipe.trace_events, None
-    pipe.finish()
+    # ---- steady state vs fill / drain: the same job with 2K steps, timed the same way; slope between the two job lengths
     steady = None
-    lo_i = min(args.inflight, K - 2)
-    if len(evs) == K and K - 1 - lo_i >= 1:
-        t_ss = evs[lo_i].elapsed_time(evs[K - 1]) / (K - 1 - lo_i)      # ms per step between the first full pipeline and the last pair
-        steady = dict(steady_state_ms_per_step=round(t_ss, 4), fill_drain_ms=round(1e3 * dt - t_ss * K, 4),
-                      note=f"hipEvents after every pair's compositing: (t[{K - 1}] - t[{lo_i}]) / {K - 1 - lo_i}; "
-                           "fill_drain = job time - K x steady state (pipeline fill, last TSDF sweep, final sync)")
+    if probe:
+        d2 = []
+        for _ in range(max(3, min(7, len(dts)))):
+            vol.reset()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(Wm, Wm + 2 * K):
+                step(i)
+            pipe.drain()
+            barrier()
+            d2.append(time.perf_counter() - t0)
+            pipe.finish()
+        dt2 = statistics.median(d2)
+        t_ss = (dt2 - dt) / K
+        steady = dict(steady_state_ms_per_step=round(1e3 * t_ss, 4), fill_drain_ms=round(1e3 * (dt - K * t_ss), 4),
+                      ms_per_step_2K_job=round(1e3 * dt2 / (2 * K), 4),
+                      note=f"slope between the {K}-step and the {2 * K}-step job (both timed as the contract says): steady state = "
+                           f"(T({2 * K}) - T({K})) / {K}; fill_drain = T({K}) - {K} x steady state (pipeline fill, last TSDF sweep, final sync)")
 
     # ---- instrumented pass (hipEvents around every kernel launch, on the work stream) ---------
     vol.reset()
@@ -388,9 +405,11 @@ def main():
                     algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_us=round(stages[dom]["avg_us"], 2), valu=valu,
                     note="blend is VALU-bound (exp + 10 VALU ops per contributing pixel x instance, data served from LDS / "
                          "the matrix cores); HBM fraction reported as the contract asks, see DESIGN.md")
+    tr_all = committed_traffic(args.config)
     per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launches=v["launches"],
                           alg_GBps=round(alg[k] / max(v["avg_us"], 1e-9) / 1e3, 1),
-                          frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4))
+                          frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4),
+                          traffic=(tr_all.get(k, {}).get("hbm_bytes_per_launch") if tr_all.get(k, {}).get("cull") == args.cull else None))
                   for k, v in stages.items()}
     raster_roofline = dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
                            achieved_GBps=round(B_pair / t_raster / 1e9, 1), frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4),

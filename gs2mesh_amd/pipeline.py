@@ -115,7 +115,6 @@ class RenderFusePipeline:
         self._rendered = [torch.cuda.Event() for _ in range(self.inflight)]
         self._fused = [torch.cuda.Event() for _ in range(self.inflight)]
         self._n = 0
-        self.trace_events = None   # a list: submit() appends a timing event recorded after every pair (bench.py's steady-state probe)
 
     # -- set-up ------------------------------------------------------------------------------------
     def prepare(self, cams, headroom: float = 1.3):
@@ -183,10 +182,6 @@ class RenderFusePipeline:
             self._rendered[j].record(rs)
             if batched:
                 self._bcopied[self._bset][k].record(rs)
-            if self.trace_events is not None:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record(rs)
-                self.trace_events.append(ev)
         if depth is not None and self.fuse_batch > 1:
             for t in (depth, mask):
                 if torch.is_tensor(t) and t.is_cuda:

@@ -28,7 +28,7 @@ for d in glob.glob(os.path.join(src, "pmc_*")):
 summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if k.startswith("k_")}
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_{cfg}.json"), "w"), indent=1, sort_keys=True)
 prefix_of = (("k_project", "project"), ("k_count_tiles", "count_tiles"), ("k_hist_colscan", "hist_colscan"), ("k_tile_scan", "tile_scan"),
-             ("k_scatter", "scatter"), ("k_sort_tiles_small", "sort_tiles"), ("k_tsdf_touch", "tsdf_touch"),
+             ("k_scatter", "scatter"), ("k_sort_tiles", "sort_tiles"), ("k_tsdf_touch", "tsdf_touch"),
              ("k_tsdf_integrate", "tsdf_integrate"), ("k_blend", "blend"))
 stage_of = {}
 for k in summary:
@@ -38,9 +38,20 @@ for k in summary:
             break
 bench = json.load(open(os.path.join(src, "bench.json"))) if os.path.exists(os.path.join(src, "bench.json")) else {}
 traffic = {}
-for k, cs in summary.items():
+for k, cs in sorted(summary.items()):
     stage = stage_of.get(k)
     if stage and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        if stage in traffic:      # a stage made of several kernels (the per-tile sort: one kernel per size class): sums
+            t = traffic[stage]
+            t["kernel"] += " + " + k
+            t["hbm_bytes_per_launch"] += int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
+            t["fetch_kib"] += cs["FETCH_SIZE"]
+            t["write_kib"] += cs["WRITE_SIZE"]
+            for name, key in (("valu_insts_per_launch", "SQ_INSTS_VALU"), ("salu_insts_per_launch", "SQ_INSTS_SALU"),
+                              ("branch_insts_per_launch", "SQ_INSTS_BRANCH"), ("lds_bank_conflict_cycles", "SQ_LDS_BANK_CONFLICT")):
+                if key in cs and t.get(name) is not None:
+                    t[name] += int(cs[key])
+            continue
         traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                               fetch_kib=cs["FETCH_SIZE"], write_kib=cs["WRITE_SIZE"],
                               valu_insts_per_launch=int(cs["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in cs else None,
