@@ -130,8 +130,8 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=49)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)     # = the driver's command: `python bench.py` reproduces its number
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cull", type=int, default=int(os.environ.get("GS2M_BENCH_CULL", "1")),
                     help="exact tile culling (image-preserving); 0 = reference instance lists")

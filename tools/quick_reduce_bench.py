@@ -15,14 +15,16 @@ vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=(cfg.tsdf_n
 intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
 img = torch.from_numpy(synthetic.color_pattern(W, H)).to(dev)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 49
-for mode in ("allreduce", "reduce_scatter", "allreduce"):
+full_ring = len(sys.argv) > 3 and sys.argv[3] == "ring"     # views all around the object: the block union of a whole job
+for mode, payload, algo in (("reduce_scatter", "f32", "rccl"), ("reduce_scatter", "f32", "rccl"), ("reduce_scatter", "packed", "rccl"),
+                            ("reduce_scatter", "packed", "direct"), ("allreduce", "packed", "rccl"), ("allreduce", "f32", "rccl")):
     vol.reset()
-    for p in synthetic.ring_poses(n, cfg.ring_radius, 0, 8 * n):
+    for p in synthetic.ring_poses(n, cfg.ring_radius, 0, n if full_ring else 8 * n):
         d = synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2, H / 2, cfg.sphere_radius, dev)
         E = np.eye(4); E[:3] = p
         vol.integrate(RGBDImage(img, d, depth_trunc=cfg.baseline * 20), intr, E, min_depth=cfg.baseline * 4)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    info = reduce_volume(vol, mode=mode, always_collective=True)
+    info = reduce_volume(vol, mode=mode, always_collective=True, payload=payload, algo=algo)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(json.dumps(dict(mode=mode, ms=round(1e3 * dt, 2), blocks=info["n_blocks_union"], MB=round(info["bytes_per_rank"] / 1e6, 1))))
+    print(json.dumps(dict(mode=mode, payload=info["payload"], algo=info["algo"], ms=round(1e3 * dt, 2), blocks=info["n_blocks_union"], MB=round(info["bytes_per_rank"] / 1e6, 1))))
 dist.destroy_process_group()
