@@ -36,6 +36,7 @@ OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
 OPT_BLEND_WG_PER_CU = 6
+OPT_BLEND_JOIN = 7
 XFORM_SUM_F32, XFORM_RAW_F32, XFORM_SUM_PACKED = 0, 1, 2
 XFORM_PACKED_MAX_FRAMES = 1023
 OPT_DEBUG_SYNC = 3
@@ -49,6 +50,7 @@ _PROTOS = {
     "gs2m_stream_create": (i32, [C.POINTER(vp), i32, C.POINTER(C.c_uint32), i32]),
     "gs2m_stream_destroy": (i32, [vp]),
     "gs2m_raster_set_blend_stream": (i32, [vp, vp]),
+    "gs2m_raster_join": (i32, [vp, vp]),
     "gs2m_raster_create": (i32, [C.POINTER(vp), i32]),
     "gs2m_raster_destroy": (i32, [vp]),
     "gs2m_raster_set_option": (i32, [vp, i32, i32]),

@@ -39,7 +39,8 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_blend_wg_per_cu = 0;
+    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_blend_wg_per_cu = 0, opt_blend_join = 1;
+    bool blend_pending = false;   // a compositing launch sits on blend_stream and the call's stream has not waited for it
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -188,6 +189,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             }
             r->opt_blend_wg_per_cu = value;
             return 0;
+        case GS2M_OPT_BLEND_JOIN: r->opt_blend_join = value != 0; return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
         case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
@@ -218,6 +220,17 @@ extern "C" int gs2m_stream_create(gs2m_stream* out, int device, const uint32_t* 
 
 extern "C" int gs2m_stream_destroy(gs2m_stream s) {
     if (s) HIPCHK(hipStreamDestroy((hipStream_t)s));
+    return 0;
+}
+
+extern "C" int gs2m_raster_join(gs2m_raster* r, gs2m_stream stream) {
+    if (!r) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    // always enqueued when a compositing stream is set: the event is re-recorded by every call, waiting for the latest
+    // record is what a consumer of the image / a re-user of the arenas needs, whichever stream asks
+    if (r->blend_stream && r->ev_blended && r->last_P > 0) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, r->ev_blended, 0));
     return 0;
 }
 
@@ -418,6 +431,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
         HIPCHK(hipEventRecord(r->ev_binned, st));
         HIPCHK(hipStreamWaitEvent(bs, r->ev_binned, 0));
     }
+    r->blend_pending = false;
     {
         StageTimer tm(r, bs, GS2M_STAGE_BLEND);
         if (gs2m_launch_blend(bs, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
@@ -427,7 +441,10 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     }
     if (bs != st) {
         HIPCHK(hipEventRecord(r->ev_blended, bs));
-        HIPCHK(hipStreamWaitEvent(st, r->ev_blended, 0));
+        // GS2M_OPT_BLEND_JOIN 0: the call's stream goes on without waiting for the compositing (the next view's binning
+        // chain can follow at once); whoever needs the image, or re-uses this handle, calls gs2m_raster_join first
+        if (r->opt_blend_join || r->opt_debug) HIPCHK(hipStreamWaitEvent(st, r->ev_blended, 0));
+        else r->blend_pending = true;
     }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;
@@ -710,6 +727,7 @@ extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_view
         return 1;
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (r->blend_stream && r->blend_stream != (hipStream_t)stream) HIPCHK(hipStreamSynchronize(r->blend_stream));
     HIPCHK(hipGetLastError());
     // slot 0 is sticky: an overflow in ANY call since the last query is reported (a later call on the same handle that
     // fits does not erase it), with the largest instance count any of those calls needed

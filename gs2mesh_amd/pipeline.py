@@ -29,7 +29,8 @@ class RenderFusePipeline:
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0,
                  exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
                  lib=None, fuse_batch: int = 1, spatial_order="auto", blend_cus: int = 0, blend_streams: int = 2,
-                 bin_cus: str = "all", fuse_cus: str = "all", blend_wg_per_cu: int = 0, blend_stream_plain: bool = False):
+                 bin_cus: str = "all", fuse_cus: str = "all", blend_wg_per_cu: int = 0, blend_stream_plain: bool = False,
+                 layout: str = "per_slot", bin_streams: int = 1):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
@@ -62,6 +63,10 @@ class RenderFusePipeline:
             self.rgb8.append(self._own8[j])
         self._masked = []
         self.blend_cus = 0
+        self.layout = layout if self.inflight > 1 else "per_slot"
+        self._blend_torch = None
+        if self.layout not in ("per_slot", "two_stage"):
+            raise ValueError("layout must be 'per_slot' or 'two_stage'")
         if self.inflight == 1:
             # serial mode: everything on the caller's current stream
             self.render_streams, self.fuse_stream = [None], None
@@ -85,9 +90,23 @@ class RenderFusePipeline:
                 self._masked.append(m)
                 return m.torch
 
-            self.render_streams = [make(bin_cus) for _ in range(self.inflight)]
+            if self.layout == "two_stage":
+                # TWO-STAGE layout: every binning chain on `bin_streams` shared streams, every compositing launch on ONE
+                # further stream, without the join back (GS2M_OPT_BLEND_JOIN 0): the binning of view i + 1 follows the
+                # binning of view i at once and the compositing stream always has its next launch queued.  Three or four
+                # streams in all = no two of them share one of the 4 hardware queues (cf. per_slot: 6 render streams).
+                bins = [acquire(device, None, total, lib=lib) for _ in range(max(1, int(bin_streams)))]
+                blend = acquire(device, None, total, lib=lib)
+                self._masked += bins + [blend]
+                self.render_streams = [bins[j % len(bins)].torch for j in range(self.inflight)]
+                self._blend_torch = blend.torch
+                for r in self.rasterizers:
+                    r.set_blend_stream(blend.handle)
+                    r.set_option(_lib.OPT_BLEND_JOIN, 0)
+            else:
+                self.render_streams = [make(bin_cus) for _ in range(self.inflight)]
             self.fuse_stream = make(fuse_cus)
-            if self.blend_cus or blend_stream_plain:
+            if self.layout == "per_slot" and (self.blend_cus or blend_stream_plain):
                 bl = [acquire(device, (0, self.blend_cus) if self.blend_cus else None, total, lib=lib)
                       for _ in range(max(1, int(blend_streams)))]
                 self._masked += bl
@@ -169,6 +188,8 @@ class RenderFusePipeline:
         rs.wait_stream(cur)
         with torch.cuda.stream(rs):
             rs.wait_event(self._fused[j])          # the view that last used this slot's images is integrated
+            if self._blend_torch is not None:
+                r.join(rs.cuda_stream)             # two-stage layout: the slot's previous compositing has read its arenas
             batched = depth is not None and self.fuse_batch > 1
             self.rgb8[j] = self._own8[j]   # fuse-less / view-by-view: the slot's own buffer (ordered by _fused[j] above)
             if batched:
@@ -179,9 +200,10 @@ class RenderFusePipeline:
                     rs.wait_event(self._batch_done[self._bset])
                 self.rgb8[j] = self._bpair[self._bset][k]
             r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j], sync=False)
-            self._rendered[j].record(rs)
+            done_on = self._blend_torch if self._blend_torch is not None else rs      # the stream the images are complete on
+            self._rendered[j].record(done_on)
             if batched:
-                self._bcopied[self._bset][k].record(rs)
+                self._bcopied[self._bset][k].record(done_on)
         if depth is not None and self.fuse_batch > 1:
             for t in (depth, mask):
                 if torch.is_tensor(t) and t.is_cuda:
@@ -245,6 +267,8 @@ class RenderFusePipeline:
         if self.inflight > 1:
             for s in self.render_streams:
                 s.synchronize()
+            if self._blend_torch is not None:
+                self._blend_torch.synchronize()
             self.fuse_stream.synchronize()
         else:
             torch.cuda.current_stream(self.device).synchronize()
@@ -268,6 +292,7 @@ class RenderFusePipeline:
             self.drain()
             for r in self.rasterizers:
                 r.set_blend_stream(None)
+                r.set_option(_lib.OPT_BLEND_JOIN, 1)
             for m in self._masked:
                 m.close()
             self._masked = []

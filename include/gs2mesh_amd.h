@@ -80,6 +80,9 @@ enum {
                                      The compositing grid otherwise refills every slot a retiring workgroup frees, and the
                                      1024-thread binning / TSDF workgroups of the NEXT views (other streams) only get placed
                                      in its tail; with a cap every CU keeps wave slots and LDS free for them.  Same image. */
+    GS2M_OPT_BLEND_JOIN = 7,      /* with a compositing stream set: 1 (default) = the call's stream waits for the compositing
+                                     before the call returns to it (everything ordered on the stream the caller passed);
+                                     0 = it does not -- gs2m_raster_join orders a stream behind the handle's compositing.   */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and
@@ -108,6 +111,10 @@ int gs2m_raster_set_option(gs2m_raster* r, int option, int value);
  * stream (NULL = back to the call's stream).  The library orders it with two events (binning -> compositing -> back),
  * so for the caller all work of a call is still ordered on the stream it passed. */
 int gs2m_raster_set_blend_stream(gs2m_raster* r, gs2m_stream blend_stream);
+
+/* Makes `stream` wait for the latest compositing launch of the handle (no-op without a compositing stream).  Needed with
+ * GS2M_OPT_BLEND_JOIN 0 before anything reads the images of the last call or re-uses the handle. */
+int gs2m_raster_join(gs2m_raster* r, gs2m_stream stream);
 
 /* Pre-size the arenas (optional; every forward grows them on demand).
  * P Gaussians, n_views views of W x H rendered per call, `instances` (Gaussian,tile)

@@ -67,7 +67,8 @@ def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
 
 
 @pytest.mark.parametrize("kw", [dict(blend_cus=224), dict(blend_cus=192, bin_cus="rest", fuse_cus="rest", blend_streams=1),
-                                dict(blend_cus=224, fuse_cus="blend", blend_streams=3)])
+                                dict(blend_cus=224, fuse_cus="blend", blend_streams=3), dict(layout="two_stage"),
+                                dict(layout="two_stage", bin_streams=2)])
 def test_cu_partitioned_streams_equal_serial(kw):
     """CU-masked streams (gs2m_stream_create / gs2m_raster_set_blend_stream): the compositing launches run on streams
     restricted to a subset of the CUs, ordered against the binning chain by events inside the library -- same images, same

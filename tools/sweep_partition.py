@@ -55,9 +55,11 @@ for spec in a.configs.split(","):
     inflight = int(f[4]) if len(f) > 4 else a.inflight
     wgcap = int(f[5]) if len(f) > 5 else 0
     plain = bool(int(f[6])) if len(f) > 6 else False
+    layout = f[7] if len(f) > 7 else "per_slot"
+    nbin = int(f[8]) if len(f) > 8 else 1
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=inflight, device=0, exact_tile_cull=1, blend_variant=4, tile_rows=2,
                               fuse_batch=fuse_batch, blend_cus=blend_cus, blend_streams=nbs, bin_cus=bin_cus, fuse_cus=fuse_cus,
-                              blend_wg_per_cu=wgcap, blend_stream_plain=plain)
+                              blend_wg_per_cu=wgcap, blend_stream_plain=plain, layout=layout, bin_streams=nbin)
     pipe.prepare(cams[0], headroom=2.0)
 
     def step(i):
