@@ -1,4 +1,5 @@
 // raster_bin.hip -- tile offsets + per-tile depth sort (integer work).
+#include <cstdlib>
 #include "raster_sort.h"
 #include "raster_internal.h"
 
@@ -19,6 +20,12 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
     // class that is (almost) empty from launching hundreds of workgroups of 40-80 KiB LDS that wait for CU space just to
     // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
     GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap);
+    static const int light = getenv("GS2M_SORT_LIGHT") ? atoi(getenv("GS2M_SORT_LIGHT")) : 1;   // development A/B knob
+    if (light && class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0) {
+        // every size class was empty last time: ONE LDS-free launch that still sorts whatever it finds (k_sort_tiles_rank)
+        GS2M_LAUNCH(k_sort_tiles_rank, dim3(32, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
+        return;
+    }
     const int full[3] = {tiles < 1024 ? tiles : 1024, tiles < 512 ? tiles : 512, tiles < 512 ? tiles : 512};
     int g[3];
     for (int c = 0; c < 3; ++c) {

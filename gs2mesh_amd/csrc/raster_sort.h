@@ -588,3 +588,42 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
         __syncthreads();
     }
 }
+
+// LDS-free stand-in for the three size-class kernels, launched INSTEAD of them when the previous call on the handle found
+// every class empty (the usual case at 16 x 32 tiles of a 300 k-Gaussian model: no list above 512 instances).  The class
+// kernels carry 40-80 KiB of static LDS per workgroup; under the pipelined load (a compositing grid of another stream holds
+// 157 of the 160 KiB of every CU) even their EMPTY launches waited 30-40 us each for a CU with room -- three times per view
+// on the critical chain of its slot (kernel trace, round 3).  This kernel needs no LDS, so its 256-thread workgroups are
+// placed at once.  It is not a hint-dependent shortcut: if the view DOES have larger lists it sorts them, slowly but
+// exactly -- rank sort through `tmp` (keys are unique: rank = number of smaller keys = final position; the list is
+// L1 / L2 resident and a workgroup only re-reads what its own threads wrote, visible after the workgroup barrier).
+GS2M_KERNEL void __launch_bounds__(256)
+k_sort_tiles_rank(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
+                  const unsigned* __restrict__ tile_start, int tiles, unsigned cap, const unsigned* __restrict__ sort_lists) {
+    const int tid = (int)threadIdx.x;
+    const int v = (int)blockIdx.y;
+    for (int cls = 0; cls < GS2M_SORT_CLASSES; ++cls) {
+        const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + cls) * (tiles + 1);
+        const unsigned count = list[0];
+        for (unsigned li = blockIdx.x; li < count; li += gridDim.x) {
+            const int t = (int)list[1 + li];
+            unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
+            unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
+            if (b > cap) b = cap;
+            if (e > cap) e = cap;
+            const int n = (int)(e - b);
+            unsigned long long* kv = keys + (size_t)v * cap + b;
+            unsigned long long* tv = tmp + (size_t)v * cap + b;
+            for (int i = tid; i < n; i += 256) {
+                const unsigned long long key = kv[i];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) rank += kv[j] < key ? 1 : 0;
+                tv[rank] = key;
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) kv[i] = tv[i];
+            __syncthreads();
+        }
+    }
+}
+

@@ -218,6 +218,54 @@ def test_crowded_tile_uses_the_merge_path_and_saturates(backend, P):
     assert_image_close(img, ref_img)
 
 
+def test_lists_grow_after_a_view_without_large_lists(backend):
+    """The size-class kernels of the per-tile sort are replaced by ONE LDS-free launch (k_sort_tiles_rank) when the previous
+    call on the handle found every class empty.  That launch is not a hint-dependent shortcut: a view that suddenly HAS lists
+    of 600 ... 9000 instances (all three classes) after a sparse one is still sorted exactly."""
+    W, H, f = 48, 32, 60.0
+    be = backend
+    d = be.dev
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    r = Rasterizer(0, lib=be.lib)
+
+    def render(xyz, o, cols, s, q):
+        return r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                         d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols), scales=d(s),
+                         rotations=d(q))
+
+    rng = np.random.default_rng(5)
+    P0 = 200                                                     # sparse view: no list above 512 instances
+    xyz0 = rng.uniform(-0.3, 0.3, (P0, 3)).astype(np.float32)
+    s0 = np.full((P0, 3), 0.01, np.float32)
+    q0 = np.tile([1, 0, 0, 0], (P0, 1)).astype(np.float32)
+    render(xyz0, rng.uniform(0.1, 0.5, P0).astype(np.float32), rng.uniform(0, 1, (P0, 3)).astype(np.float32), s0, q0)
+    render(xyz0, rng.uniform(0.1, 0.5, P0).astype(np.float32), rng.uniform(0, 1, (P0, 3)).astype(np.float32), s0, q0)
+    # crowded view on the SAME handle and image size: the class hint read back from the sparse views says "all empty"
+    P = 12000
+    xyz = rng.normal(0, 0.02, (P, 3)).astype(np.float32)
+    xyz[:, 1] -= 0.53                                            # ~8300 in the tile above the centre
+    xyz[:3000, 0] += 1.07                                        # a second, smaller stack in the tile right of it
+    xyz[3000:3700, 0] -= 1.07                                    # and a third of ~700 bottom left
+    xyz[3000:3700, 1] += 1.06
+    xyz[:, 2] = rng.uniform(-0.2, 0.2, P)
+    o = rng.uniform(0.02, 0.4, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    s = np.full((P, 3), 0.012, np.float32)
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    img, radii = render(xyz, o, cols, s, q)
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    assert r.last_num_rendered == ref_n
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
+                                 cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+    sizes = (ref_ranges[:, 1] - ref_ranges[:, 0]).astype(np.int64)
+    assert sizes.max() > 8192 and ((sizes > 512) & (sizes <= 8192)).any(), sizes
+    pl, ranges = r.download_binning(0, ref_n, 3 * 2)
+    np.testing.assert_array_equal(ranges, ref_ranges)
+    np.testing.assert_array_equal(pl, ref_pl)
+    assert_image_close(be.host(img), ref_img)
+
+
 @pytest.mark.parametrize("depths", ["uniform", "clustered", "equal"])
 def test_mid_size_lists_use_the_bucket_sort(backend, depths):
     """512 < n <= 4096 instances per tile: bucket + rank sort (k_sort_tiles_bucket).  `uniform`: depths spread over the
