@@ -390,7 +390,7 @@ extern "C" int gs2m_tsdf_integrate_batch(gs2m_tsdf* t, int n_frames, const float
         }
         {
             Gs2mRange rg("gs2m:tsdf_integrate_batch");
-            gs2m_launch_tsdf_integrate_batch(st, t->n_cu * 2, t->V, t->d_bframes);
+            gs2m_launch_tsdf_integrate_batch(st, t->n_cu, t->V, t->d_bframes);
         }
         if (tm) {
             (void)hipEventRecord(e3, st);

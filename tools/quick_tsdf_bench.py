@@ -8,6 +8,7 @@ from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableT
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C2"); ap.add_argument("--frames", type=int, default=24)
 ap.add_argument("--same", type=int, default=0); ap.add_argument("--color", type=int, default=1)
+ap.add_argument("--batch", type=int, default=0, help="frames per voxel-stationary sweep (0 = frame by frame)")
 a = ap.parse_args()
 cfg = synthetic.CONFIGS[a.config]; W, H = cfg.width, cfg.height; dev = torch.device("cuda:0")
 poses = synthetic.ring_poses(a.frames, cfg.ring_radius, 0, cfg.n_pairs)
@@ -20,6 +21,12 @@ vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, TSDFVolumeColorType.RG
                          max_blocks=(cfg.tsdf_n // 16) ** 3)
 intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
 def run():
+    if a.batch:
+        for i0 in range(0, a.frames, a.batch):
+            idx = [0 if a.same else i for i in range(i0, min(a.frames, i0 + a.batch))]
+            vol.integrate_batch([RGBDImage(col, deps[k], depth_scale=1.0, depth_trunc=cfg.baseline * 20) for k in idx], intr,
+                                [Es[k] for k in idx], min_depth=cfg.baseline * 4)
+        return
     for i in range(a.frames):
         k = 0 if a.same else i
         vol.integrate(RGBDImage(col, deps[k], depth_scale=1.0, depth_trunc=cfg.baseline * 20), intr, Es[k], min_depth=cfg.baseline * 4)
