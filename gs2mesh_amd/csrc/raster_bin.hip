@@ -19,7 +19,8 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
     // possibly stale): the class kernels walk their lists grid-stride, so any grid >= 1 is correct -- the hint only keeps a
     // class that is (almost) empty from launching hundreds of workgroups of 40-80 KiB LDS that wait for CU space just to
     // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
-    GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap);
+    static const int wave_bucket = getenv("GS2M_SORT_WAVE_BUCKET") ? atoi(getenv("GS2M_SORT_WAVE_BUCKET")) : 1;   // 0 = bitonic only
+    GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap, wave_bucket);
     static const int light = getenv("GS2M_SORT_LIGHT") ? atoi(getenv("GS2M_SORT_LIGHT")) : 1;   // development A/B knob
     if (light && class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0) {
         // every size class was empty last time: ONE LDS-free launch that still sorts whatever it finds (k_sort_tiles_rank)

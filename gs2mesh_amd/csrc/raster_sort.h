@@ -308,9 +308,117 @@ GS2M_DEVICE void sort_wave_regs(unsigned long long* __restrict__ kv, int n, int 
     }
 }
 
+// Bucket + rank sort of one list by ONE WAVE (64 < n <= 64 E <= 512 keys; round 3): the same idea as sort_list_bucket below,
+// without a workgroup barrier.  The depths of a tile's instances spread over its frustum, so a monotone map of the depth onto
+// 64 E equal-width buckets leaves 0-3 keys in almost every bucket: one LDS counting pass gives every key its bucket and its
+// arrival slot, a wave scan turns the counts into starts, and the exact position inside the bucket is the number of smaller
+// keys there (keys are unique, so the ranks are a permutation: the same total order as any comparison sort -- ascending
+// depth, ties by id).  ~60 instructions per key-lane instead of the ~45 compare-exchange stages x E registers of the bitonic
+// network (C2: k_sort_tiles_small 31.6 -> see profiles/r3_experiments.txt).  Returns false (nothing written) when a bucket holds
+// more than GS2M_WAVE_BUCKET_MAX keys (clustered or equal depths): the caller then runs the bitonic network.
+#define GS2M_WAVE_BUCKET_MAX 12
+template <int E>
+GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int n, const int lane, unsigned long long* s_key,
+                                  unsigned* s_cnt) {
+    static_assert(E >= 2 && (E & 1) == 0, "two 16-bit counters per word, E / 2 words per lane");
+    constexpr int NB = 64 * E;      // buckets (>= n)
+    unsigned long long k[E];
+    unsigned dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = r * 64 + lane;
+        k[r] = i < n ? kv[i] : ~0ull;
+        if (i < n) {
+            const unsigned d = (unsigned)(k[r] >> 32);
+            dmin = d < dmin ? d : dmin;
+            dmax = d > dmax ? d : dmax;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const unsigned a = gs2m_shfl_xor(dmin, m), c = gs2m_shfl_xor(dmax, m);
+        dmin = a < dmin ? a : dmin;
+        dmax = c > dmax ? c : dmax;
+    }
+    gs2m_wave_sync();   // the previous list's readers of s_cnt / s_key are done (a wave may sort several lists)
+#pragma unroll
+    for (int w = 0; w < E / 2; ++w) s_cnt[w * 64 + lane] = 0u;
+    gs2m_wave_sync();
+    // monotone map depth -> bucket (float conversion, multiplication by a positive constant and truncation are non-decreasing)
+    const float scale = (float)NB / ((float)(dmax - dmin) + 1.0f) * 0.99999f;
+    auto bucket_of = [&](unsigned long long key) -> unsigned {
+        const unsigned b = (unsigned)((float)((unsigned)(key >> 32) - dmin) * scale);
+        return b < (unsigned)NB ? b : (unsigned)NB - 1u;
+    };
+    unsigned short slot[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        slot[r] = 0;
+        if (r * 64 + lane < n) {
+            const unsigned b = bucket_of(k[r]);
+            const unsigned old = atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) << 4));
+            slot[r] = (unsigned short)((old >> ((b & 1u) << 4)) & 0xffffu);
+        }
+    }
+    gs2m_wave_sync();
+    // lane l owns buckets [l E, (l + 1) E) = words [l E / 2, (l + 1) E / 2)
+    unsigned cw[E / 2];
+    unsigned sum = 0u, mx = 0u;
+#pragma unroll
+    for (int w = 0; w < E / 2; ++w) {
+        cw[w] = s_cnt[lane * (E / 2) + w];
+        const unsigned c0 = cw[w] & 0xffffu, c1 = cw[w] >> 16;
+        sum += c0 + c1;
+        mx = c0 > mx ? c0 : mx;
+        mx = c1 > mx ? c1 : mx;
+    }
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned y = gs2m_shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        const unsigned o = gs2m_shfl_xor(mx, m);
+        mx = o > mx ? o : mx;
+    }
+    if (mx > GS2M_WAVE_BUCKET_MAX) return false;   // wave-uniform
+    unsigned run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < E / 2; ++w) {
+        const unsigned c0 = cw[w] & 0xffffu, c1 = cw[w] >> 16;
+        s_cnt[lane * (E / 2) + w] = run | ((run + c0) << 16);   // starts (<= 512)
+        run += c0 + c1;
+    }
+    if (lane == 63) s_cnt[NB / 2] = (unsigned)n;                 // sentinel: start of bucket NB
+    gs2m_wave_sync();
+    auto start_of = [&](unsigned b) -> unsigned { return (s_cnt[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; };
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+        if (r * 64 + lane < n) s_key[start_of(bucket_of(k[r])) + slot[r]] = k[r];
+    gs2m_wave_sync();
+    // rank inside the bucket -> final position
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int j = r * 64 + lane;
+        if (j < n) {
+            const unsigned long long key = s_key[j];
+            const unsigned b = bucket_of(key);
+            const unsigned lo = start_of(b), hi = start_of(b + 1u);
+            unsigned rank = 0u;
+            for (unsigned q = lo; q < hi; ++q) rank += s_key[q] < key ? 1u : 0u;
+            kv[lo + rank] = key;
+        }
+    }
+    return true;
+}
+
 GS2M_KERNEL void __launch_bounds__(64)
 k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
-                   unsigned cap) {
+                   unsigned cap, int bucket) {
+    __shared__ unsigned long long s_key[GS2M_SORT_WAVE];
+    __shared__ unsigned s_cnt[GS2M_SORT_WAVE / 2 + 2];
     const int lane = (int)threadIdx.x;
     const int t = (int)blockIdx.x, v = (int)blockIdx.y;
     unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
@@ -321,9 +429,13 @@ k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __rest
     if (n <= 1 || n > GS2M_SORT_WAVE) return;  // larger tiles: k_sort_tiles
     unsigned long long* kv = keys + (size_t)v * cap + b;
     if (n <= 64) sort_wave_regs<1>(kv, n, lane);
-    else if (n <= 128) sort_wave_regs<2>(kv, n, lane);
-    else if (n <= 256) sort_wave_regs<4>(kv, n, lane);
-    else sort_wave_regs<8>(kv, n, lane);
+    else if (n <= 128) {
+        if (!(bucket && sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<2>(kv, n, lane);
+    } else if (n <= 256) {
+        if (!(bucket && sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<4>(kv, n, lane);
+    } else {
+        if (!(bucket && sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<8>(kv, n, lane);
+    }
 }
 
 template <int E>
