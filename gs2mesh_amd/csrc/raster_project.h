@@ -314,7 +314,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
 // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.  The
 // colour pass then reads the 16 coefficients of one channel at a time back from LDS.
 template <int NV, bool DMA_SH>
-GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
+GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // 108 VGPRs (80 with DMA_SH); forcing 5 waves per SIMD (96, spills): C2 30 -> 36 us, C3 149 -> 204
 k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
           int exact_cull) {
     __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
