@@ -135,75 +135,110 @@ GS2M_DEVICE float sh_channel(int deg, const float* sh, int c, float x, float y, 
     return result < 0.0f ? 0.0f : result;
 }
 
-// The same three channels from the wave-transposed row in LDS (k_project<.., true>: float4 j of this lane's 192-B row sits
-// at s_sh[j * 64 + lane]; element e = 3 k + c of the row = component e % 4 of float4 e / 4).  One ds_read_b128 per float4 --
-// a 16-B lane stride is conflict-free for b128 reads, while the per-channel b32 read-back of round 2 hit every bank four
-// times (6 conflict cycles per LDS instruction, PMC) -- streamed three float4 (four coefficients x three channels) at a
-// time, so no 48 registers hold the row.  The basis factors are formed once for the three channels; every product and every
-// addition is the one sh_channel performs, in its order (a * b * c = (a * b) * c, sums left to right): bit-identical.
-GS2M_DEVICE void sh_rgb_from_lds(int deg, const float4* s_sh, int lane, float x, float y, float z, float& out_r, float& out_g,
-                                 float& out_b) {
-    const float4 F0 = s_sh[lane];
-    float r = GS2M_SH_C0 * F0.x, g = GS2M_SH_C0 * F0.y, b = GS2M_SH_C0 * F0.z;
-#define GS2M_SH_ADD(bk, s0, s1, s2) \
-    do {                           \
-        r = r + (bk) * (s0);       \
-        g = g + (bk) * (s1);       \
-        b = b + (bk) * (s2);       \
+// The same three channels for NV view directions at once, STREAMING the 192-B row: float4 j of the row comes from
+// `row(j)` (LDS: the wave-transposed landing zone of k_project<.., true>, one ds_read_b128 per float4 -- a 16-B lane stride is
+// conflict-free for b128 reads, the per-channel b32 read-back of round 2 hit every bank four times; HBM: the packed copy or the
+// [P,16,3] layout, one dwordx4 load per float4).  Element e = 3 k + c of the row = component e % 4 of float4 e / 4; three
+// float4 = four coefficients x three channels are in flight at a time, so no 48 registers hold the row (k_project<2, false>:
+// 108 -> see DESIGN.md).  The basis factors are formed once per view for the three channels; every product and every addition
+// is the one sh_channel performs, in its order (a * b * c = (a * b) * c, sums left to right): bit-identical.
+template <int NV, typename Row>
+GS2M_DEVICE void sh_rgb_stream(int deg, Row row, const float (*dir)[3], float (*out)[3]) {
+    float acc[NV][3];
+    const float4 F0 = row(0);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        acc[v][0] = GS2M_SH_C0 * F0.x;
+        acc[v][1] = GS2M_SH_C0 * F0.y;
+        acc[v][2] = GS2M_SH_C0 * F0.z;
+    }
+#define GS2M_SH_ADD(v, bk, s0, s1, s2)    \
+    do {                                  \
+        acc[v][0] = acc[v][0] + (bk) * (s0); \
+        acc[v][1] = acc[v][1] + (bk) * (s1); \
+        acc[v][2] = acc[v][2] + (bk) * (s2); \
     } while (0)
-#define GS2M_SH_SUB(bk, s0, s1, s2) \
-    do {                           \
-        r = r - (bk) * (s0);       \
-        g = g - (bk) * (s1);       \
-        b = b - (bk) * (s2);       \
+#define GS2M_SH_SUB(v, bk, s0, s1, s2)    \
+    do {                                  \
+        acc[v][0] = acc[v][0] - (bk) * (s0); \
+        acc[v][1] = acc[v][1] - (bk) * (s1); \
+        acc[v][2] = acc[v][2] - (bk) * (s2); \
     } while (0)
     if (deg > 0) {
-        const float4 F1 = s_sh[64 + lane], F2 = s_sh[128 + lane];
-        const float b1 = GS2M_SH_C1 * y, b2 = GS2M_SH_C1 * z, b3 = GS2M_SH_C1 * x;
-        GS2M_SH_SUB(b1, F0.w, F1.x, F1.y);   // k = 1: elements 3, 4, 5
-        GS2M_SH_ADD(b2, F1.z, F1.w, F2.x);   // k = 2: 6, 7, 8
-        GS2M_SH_SUB(b3, F2.y, F2.z, F2.w);   // k = 3: 9, 10, 11
+        const float4 F1 = row(1), F2 = row(2);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float x = dir[v][0], y = dir[v][1], z = dir[v][2];
+            const float b1 = GS2M_SH_C1 * y, b2 = GS2M_SH_C1 * z, b3 = GS2M_SH_C1 * x;
+            GS2M_SH_SUB(v, b1, F0.w, F1.x, F1.y);   // k = 1: elements 3, 4, 5
+            GS2M_SH_ADD(v, b2, F1.z, F1.w, F2.x);   // k = 2: 6, 7, 8
+            GS2M_SH_SUB(v, b3, F2.y, F2.z, F2.w);   // k = 3: 9, 10, 11
+        }
         if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z;
-            const float xy = x * y, yz = y * z, xz = x * z;
             {
-                const float4 F3 = s_sh[192 + lane], F4 = s_sh[256 + lane], F5 = s_sh[320 + lane];
-                const float b4 = 1.0925484305920792f * xy, b5 = -1.0925484305920792f * yz;
-                const float b6 = 0.31539156525252005f * (2.0f * zz - xx - yy), b7 = -1.0925484305920792f * xz;
-                GS2M_SH_ADD(b4, F3.x, F3.y, F3.z);   // k = 4: 12, 13, 14
-                GS2M_SH_ADD(b5, F3.w, F4.x, F4.y);   // k = 5: 15, 16, 17
-                GS2M_SH_ADD(b6, F4.z, F4.w, F5.x);   // k = 6: 18, 19, 20
-                GS2M_SH_ADD(b7, F5.y, F5.z, F5.w);   // k = 7: 21, 22, 23
+                const float4 F3 = row(3), F4 = row(4), F5 = row(5);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float x = dir[v][0], y = dir[v][1], z = dir[v][2];
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    const float xy = x * y, yz = y * z, xz = x * z;
+                    const float b4 = 1.0925484305920792f * xy, b5 = -1.0925484305920792f * yz;
+                    const float b6 = 0.31539156525252005f * (2.0f * zz - xx - yy), b7 = -1.0925484305920792f * xz;
+                    GS2M_SH_ADD(v, b4, F3.x, F3.y, F3.z);   // k = 4: 12, 13, 14
+                    GS2M_SH_ADD(v, b5, F3.w, F4.x, F4.y);   // k = 5: 15, 16, 17
+                    GS2M_SH_ADD(v, b6, F4.z, F4.w, F5.x);   // k = 6: 18, 19, 20
+                    GS2M_SH_ADD(v, b7, F5.y, F5.z, F5.w);   // k = 7: 21, 22, 23
+                }
             }
-            const float4 F6 = s_sh[384 + lane];
-            const float b8 = 0.5462742152960396f * (xx - yy);
-            GS2M_SH_ADD(b8, F6.x, F6.y, F6.z);       // k = 8: 24, 25, 26
+            const float4 F6 = row(6);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float x = dir[v][0], y = dir[v][1];
+                const float xx = x * x, yy = y * y;
+                const float b8 = 0.5462742152960396f * (xx - yy);
+                GS2M_SH_ADD(v, b8, F6.x, F6.y, F6.z);       // k = 8: 24, 25, 26
+            }
             if (deg > 2) {
-                const float4 F7 = s_sh[448 + lane], F8 = s_sh[512 + lane];
-                const float b9 = -0.5900435899266435f * y * (3.0f * xx - yy), b10 = 2.890611442640554f * xy * z;
-                const float b11 = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
-                GS2M_SH_ADD(b9, F6.w, F7.x, F7.y);    // k = 9: 27, 28, 29
-                GS2M_SH_ADD(b10, F7.z, F7.w, F8.x);   // k = 10: 30, 31, 32
-                GS2M_SH_ADD(b11, F8.y, F8.z, F8.w);   // k = 11: 33, 34, 35
-                const float4 F9 = s_sh[576 + lane], F10 = s_sh[640 + lane], F11 = s_sh[704 + lane];
-                const float b12 = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-                const float b13 = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
-                const float b14 = 1.445305721320277f * z * (xx - yy), b15 = -0.5900435899266435f * x * (xx - 3.0f * yy);
-                GS2M_SH_ADD(b12, F9.x, F9.y, F9.z);      // k = 12: 36, 37, 38
-                GS2M_SH_ADD(b13, F9.w, F10.x, F10.y);    // k = 13: 39, 40, 41
-                GS2M_SH_ADD(b14, F10.z, F10.w, F11.x);   // k = 14: 42, 43, 44
-                GS2M_SH_ADD(b15, F11.y, F11.z, F11.w);   // k = 15: 45, 46, 47
+                {
+                    const float4 F7 = row(7), F8 = row(8);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const float x = dir[v][0], y = dir[v][1], z = dir[v][2];
+                        const float xx = x * x, yy = y * y, zz = z * z;
+                        const float xy = x * y;
+                        const float b9 = -0.5900435899266435f * y * (3.0f * xx - yy), b10 = 2.890611442640554f * xy * z;
+                        const float b11 = -0.4570457994644658f * y * (4.0f * zz - xx - yy);
+                        GS2M_SH_ADD(v, b9, F6.w, F7.x, F7.y);    // k = 9: 27, 28, 29
+                        GS2M_SH_ADD(v, b10, F7.z, F7.w, F8.x);   // k = 10: 30, 31, 32
+                        GS2M_SH_ADD(v, b11, F8.y, F8.z, F8.w);   // k = 11: 33, 34, 35
+                    }
+                }
+                const float4 F9 = row(9), F10 = row(10), F11 = row(11);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float x = dir[v][0], y = dir[v][1], z = dir[v][2];
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    const float b12 = 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+                    const float b13 = -0.4570457994644658f * x * (4.0f * zz - xx - yy);
+                    const float b14 = 1.445305721320277f * z * (xx - yy), b15 = -0.5900435899266435f * x * (xx - 3.0f * yy);
+                    GS2M_SH_ADD(v, b12, F9.x, F9.y, F9.z);      // k = 12: 36, 37, 38
+                    GS2M_SH_ADD(v, b13, F9.w, F10.x, F10.y);    // k = 13: 39, 40, 41
+                    GS2M_SH_ADD(v, b14, F10.z, F10.w, F11.x);   // k = 14: 42, 43, 44
+                    GS2M_SH_ADD(v, b15, F11.y, F11.z, F11.w);   // k = 15: 45, 46, 47
+                }
             }
         }
     }
 #undef GS2M_SH_ADD
 #undef GS2M_SH_SUB
-    r += 0.5f;
-    g += 0.5f;
-    b += 0.5f;
-    out_r = r < 0.0f ? 0.0f : r;
-    out_g = g < 0.0f ? 0.0f : g;
-    out_b = b < 0.0f ? 0.0f : b;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float r = acc[v][c] + 0.5f;
+            out[v][c] = r < 0.0f ? 0.0f : r;
+        }
+    }
 }
 
 // ---- exact tile test (extension, GS2M_OPT_EXACT_TILE_CULL; image-preserving) --------------

@@ -132,7 +132,7 @@ GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
 // projection, SH colour, the (cull-tightened) tile rect, the GeomRec stores.  On return pv[v] holds what was stored (rect
 // zeroed and ok = false when nothing of the Gaussian reaches view v) and op the activated opacity: the fused
 // projection + counting kernel continues from these registers.  s_sh = this wave's DMA landing zone, [12][64] float4 (DMA_SH only).
-template <int NV, bool DMA_SH>
+template <int NV, bool DMA_SH, bool STREAM = true>
 GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs,
                                   int* __restrict__ radii, int exact_cull, int gi, bool valid, float4* s_sh, int lane_id,
                                   ProjView* pv, float& op, float& thr) {
@@ -184,36 +184,39 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                 project_view(cams[v], px, py, pz, cov3, pv[v]);
                 any = any || pv[v].ok;
             }
-            float sh[48];
-            const bool need_sh = any && (g.colors_precomp == nullptr) && !dma_sh;
-            if (need_sh) {
+            // colour: the 192-B SH row is STREAMED for all views at once where it is 16-B aligned (packed copy, [P,16,3] or
+            // the DMA landing zone): three float4 in flight instead of 48 registers for the row.  dc + rest split layouts
+            // and M != 16 keep the register path below.
+            // STREAM (chosen by the launcher from the layout) compiles the 48-register path out.
+            const bool stream_sh = STREAM && (g.colors_precomp == nullptr) && (dma_sh || g.shs_packed != nullptr || (g.shs_rest == nullptr && g.M == 16));
+            float rgb_v[NV][3];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) rgb_v[v][0] = rgb_v[v][1] = rgb_v[v][2] = 0.0f;
+            if (dma_sh) gs2m_wait_dma();   // this lane's row has landed (a lane only reads its own column: no barrier)
+            if (stream_sh && any && !dma_sh) {
+                float dirs[NV][3];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    // forward.cu:25-27: dir = (pos - campos) / length
+                    float dx = px - cams[v].campos[0], dy = py - cams[v].campos[1], dz = pz - cams[v].campos[2];
+                    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                    dirs[v][0] = dx / len;
+                    dirs[v][1] = dy / len;
+                    dirs[v][2] = dz / len;
+                }
                 if (g.shs_packed) {
-                    // wave-transposed copy (k_pack_sh): float4 k of 64 consecutive Gaussians is 1 KiB contiguous
+                    // wave-transposed copy (k_pack_sh): float4 j of 64 consecutive Gaussians is 1 KiB contiguous
                     const float4* s4 = reinterpret_cast<const float4*>(g.shs_packed) + (size_t)(gi >> 6) * (12 * 64) + (gi & 63);
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        if (k * 4 < ncoef * 3) {
-                            const float4 t = s4[k * 64];
-                            sh[4 * k] = t.x;
-                            sh[4 * k + 1] = t.y;
-                            sh[4 * k + 2] = t.z;
-                            sh[4 * k + 3] = t.w;
-                        }
-                    }
-                } else if (g.shs_rest == nullptr && g.M == 16) {
-                    // 192-B row, 16-B aligned: 12 x dwordx4
-                    const float4* s4 = reinterpret_cast<const float4*>(g.shs + 48 * (size_t)gi);
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) {
-                        if (k * 4 < ncoef * 3) {
-                            const float4 t = s4[k];
-                            sh[4 * k] = t.x;
-                            sh[4 * k + 1] = t.y;
-                            sh[4 * k + 2] = t.z;
-                            sh[4 * k + 3] = t.w;
-                        }
-                    }
-                } else if (g.shs_rest == nullptr) {
+                    sh_rgb_stream<NV>(g.D, [&](int j) { return s4[j * 64]; }, dirs, rgb_v);
+                } else {
+                    const float4* s4 = reinterpret_cast<const float4*>(g.shs + 48 * (size_t)gi);   // 192-B row, 16-B aligned
+                    sh_rgb_stream<NV>(g.D, [&](int j) { return s4[j]; }, dirs, rgb_v);
+                }
+            }
+            float sh[STREAM ? 1 : 48];
+            const bool need_sh = !STREAM && any && (g.colors_precomp == nullptr) && !stream_sh;
+            if constexpr (!STREAM) if (need_sh) {
+                if (g.shs_rest == nullptr) {
                     const float* s = g.shs + (size_t)gi * g.M * 3;
 #pragma unroll
                     for (int k = 0; k < 48; ++k)
@@ -230,7 +233,6 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                 }
             }
             if (exact_cull) thr = cull_threshold(op);
-            if (dma_sh) gs2m_wait_dma();   // this lane's row has landed (a lane only reads its own column: no barrier)
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 GeomRec* rec = recs + (size_t)v * g.P + gi;
@@ -250,16 +252,31 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                     cr = g.colors_precomp[3 * (size_t)gi];
                     cg = g.colors_precomp[3 * (size_t)gi + 1];
                     cb = g.colors_precomp[3 * (size_t)gi + 2];
-                } else {
-                    // forward.cu:25-27: dir = (pos - campos) / length
-                    float dx = px - cams[v].campos[0], dy = py - cams[v].campos[1], dz = pz - cams[v].campos[2];
+                } else if (dma_sh) {
+                    // forward.cu:25-27: dir = (pos - campos) / length; the row is read back from LDS view by view
+                    float dirs[1][3], col[1][3];
+                    const float dx = px - cams[v].campos[0], dy = py - cams[v].campos[1], dz = pz - cams[v].campos[2];
                     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-                    dx = dx / len;
-                    dy = dy / len;
-                    dz = dz / len;
-                    if (dma_sh) {
-                        sh_rgb_from_lds(g.D, s_sh, lane_id, dx, dy, dz, cr, cg, cb);   // b128 reads of this lane's row
-                    } else {
+                    dirs[0][0] = dx / len;
+                    dirs[0][1] = dy / len;
+                    dirs[0][2] = dz / len;
+                    sh_rgb_stream<1>(g.D, [&](int j) { return s_sh[j * 64 + lane_id]; }, dirs, col);
+                    cr = col[0][0];
+                    cg = col[0][1];
+                    cb = col[0][2];
+                } else if (stream_sh) {
+                    cr = rgb_v[v][0];
+                    cg = rgb_v[v][1];
+                    cb = rgb_v[v][2];
+                } else {
+                    cr = cg = cb = 0.0f;
+                    if constexpr (!STREAM) {
+                        // forward.cu:25-27: dir = (pos - campos) / length
+                        float dx = px - cams[v].campos[0], dy = py - cams[v].campos[1], dz = pz - cams[v].campos[2];
+                        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+                        dx = dx / len;
+                        dy = dy / len;
+                        dz = dz / len;
                         cr = sh_channel(g.D, sh, 0, dx, dy, dz);
                         cg = sh_channel(g.D, sh, 1, dx, dy, dz);
                         cb = sh_channel(g.D, sh, 2, dx, dy, dz);
@@ -313,8 +330,8 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
 // 1 KiB per wave), issued BEFORE the parameter loads and the projection: one memory round trip per thread instead of two in
 // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.  The
 // colour pass then reads the 16 coefficients of one channel at a time back from LDS.
-template <int NV, bool DMA_SH>
-GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // 108 VGPRs (80 with DMA_SH); forcing 5 waves per SIMD (96, spills): C2 30 -> 36 us, C3 149 -> 204
+template <int NV, bool DMA_SH, bool STREAM = true>
+GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // forcing 5 waves per SIMD on the round-2 kernel (96 VGPRs, spills): C2 30 -> 36 us, C3 149 -> 204
 k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
           int exact_cull) {
     __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
@@ -322,7 +339,7 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
     const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
     ProjView pv[NV];
     float op, thr;
-    project_gaussian<NV, DMA_SH>(g, cams, recs, radii, exact_cull, gi, gi < g.P, &s_sh[DMA_SH ? wave_id : 0][0][0], lane_id, pv, op, thr);
+    project_gaussian<NV, DMA_SH, STREAM>(g, cams, recs, radii, exact_cull, gi, gi < g.P, &s_sh[DMA_SH ? wave_id : 0][0][0], lane_id, pv, op, thr);
 }
 
 // Gaussian -> workgroup assignment of the counting sort (k_count_tiles and k_scatter must agree: the histogram row of a

@@ -26,10 +26,15 @@ void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUnif
     // no row of a culled Gaussian and runs 16 instead of 12 waves per CU (C2: 28 vs 30 us)
     static const int dma_knob = getenv("GS2M_PROJECT_DMA") ? atoi(getenv("GS2M_PROJECT_DMA")) : 1;  // tuning knob
     const bool dma = dma_knob && g.shs_packed != nullptr && g.colors_precomp == nullptr && g.ids != nullptr;
+    // the colour pass streams the SH row three float4 at a time where the row is 16-B aligned (packed copy, [P,16,3]) or not
+    // needed (precomputed colours); dc + rest split layouts / M != 16 keep the 48-register path (k_project<.., .., false>)
+    const bool stream = g.colors_precomp != nullptr || g.shs_packed != nullptr || (g.shs_rest == nullptr && g.M == 16);
     if (nv == 2 && dma) GS2M_LAUNCH((k_project<2, true>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (nv == 2) GS2M_LAUNCH((k_project<2, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (nv == 2 && stream) GS2M_LAUNCH((k_project<2, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (nv == 2) GS2M_LAUNCH((k_project<2, false, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
     else if (dma) GS2M_LAUNCH((k_project<1, true>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else GS2M_LAUNCH((k_project<1, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (stream) GS2M_LAUNCH((k_project<1, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else GS2M_LAUNCH((k_project<1, false, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
 }
 
 int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
