@@ -13,7 +13,13 @@ if not os.path.isdir(src):
     src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: a directory can hold the files of several runs; the last one counts."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
+for f in newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, f"{tag}_bench_{cfg}_kernel_stats.csv"))
 for name in ("bench.json", "stats_bench.json"):
     p = os.path.join(src, name)
@@ -21,7 +27,7 @@ for name in ("bench.json", "stats_bench.json"):
         shutil.copy(p, os.path.join(dst, f"{tag}_{cfg}_{name}"))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in glob.glob(os.path.join(src, "pmc_*")):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
