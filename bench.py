@@ -151,7 +151,7 @@ def main():
                     help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
     ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "0")),
                     help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way); "
-                         "0 (default) = the K views of a job in equal sweeps of at most 32 views, at least two")
+                         "0 (default) = the K views of a job in equal sweeps of at most 32 views")
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
@@ -199,10 +199,12 @@ def main():
     Wm = args.warmup
     fuse_plan = None
     if args.fuse_batch <= 0:
-        # the K views of a job in equal sweeps of at most 32 views, at least two.  (Measured in round 3: sweeps of decreasing
-        # size -- 10, 5, 3, 2 for K = 20, so that only a small sweep runs after the last render -- are slower, 0.356 vs
-        # 0.348 ms per step: the sweeps overlap the renders anyway and small sweeps re-read the voxel state more often.)
-        n_sweeps = max(2, -(-K // 32))
+        # the K views of a job in equal sweeps of at most 32 views.  Measured in round 3: the pipelined step is additive over
+        # the kernels that fill the chip, so a sweep gains nothing from running next to the renders -- what counts is its own
+        # time, and that falls with its size (the voxel state is read and written once per sweep): one sweep of 20 for the
+        # driver's 20-step job 28.4 us per frame and 0.3224 ms per step, two of 10 34.3 us and 0.3254 ms; sweeps of
+        # decreasing size (10, 5, 3, 2: only a small sweep after the last render) 0.356 vs 0.348 ms.
+        n_sweeps = max(1, -(-K // 32))
         args.fuse_batch = max(1, -(-K // n_sweeps))
     cfg = synthetic.CONFIGS[args.config]
     Wd, Ht = cfg.width, cfg.height

@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #define GS2M_KERNEL __global__
+#define GS2M_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))   // occupancy of a kernel by construction (register budget = 512 / n)
 #define GS2M_DEVICE __device__ __forceinline__
 #define GS2M_PLATFORM_NAME "hip-gfx950"
 

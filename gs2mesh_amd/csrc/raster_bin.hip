@@ -20,7 +20,10 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
     // class that is (almost) empty from launching hundreds of workgroups of 40-80 KiB LDS that wait for CU space just to
     // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
     static const int wave_bucket = getenv("GS2M_SORT_WAVE_BUCKET") ? atoi(getenv("GS2M_SORT_WAVE_BUCKET")) : 1;   // 0 = bitonic only
-    GS2M_LAUNCH(k_sort_tiles_small, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap, wave_bucket);
+    static const int small_wpb = getenv("GS2M_SORT_SMALL_WPB") ? atoi(getenv("GS2M_SORT_SMALL_WPB")) : 4;       // development A/B knob
+    if (small_wpb == 1) GS2M_LAUNCH(k_sort_tiles_small<1>, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap, wave_bucket);
+    else if (small_wpb == 2) GS2M_LAUNCH(k_sort_tiles_small<2>, dim3((tiles + 1) / 2, nv), dim3(128), 0, st, keys, tile_start, tiles, cap, wave_bucket);
+    else GS2M_LAUNCH(k_sort_tiles_small<4>, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, tiles, cap, wave_bucket);
     static const int light = getenv("GS2M_SORT_LIGHT") ? atoi(getenv("GS2M_SORT_LIGHT")) : 1;   // development A/B knob
     if (light && class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0) {
         // every size class was empty last time: ONE LDS-free launch that still sorts whatever it finds (k_sort_tiles_rank)
@@ -37,7 +40,13 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
         }
         if (g[c] < 1) g[c] = 1;
     }
-    GS2M_LAUNCH((k_sort_tiles_bucket<4096, 256, 0>), dim3(g[0], nv), dim3(256), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    GS2M_LAUNCH((k_sort_tiles_bucket<8192, 512, 1>), dim3(g[1], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    static const int keys_per_thread = getenv("GS2M_SORT_KEYS_PER_THREAD") ? atoi(getenv("GS2M_SORT_KEYS_PER_THREAD")) : 8;   // A/B knob: 16 = round 2
+    if (keys_per_thread == 16) {
+        GS2M_LAUNCH(k_sort_tiles_bucket_4096x16, dim3(g[0], nv), dim3(256), 0, st, keys, tile_start, tiles, cap, sort_lists);
+        GS2M_LAUNCH(k_sort_tiles_bucket_8192x16, dim3(g[1], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    } else {
+        GS2M_LAUNCH(k_sort_tiles_bucket_4096x8, dim3(g[0], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+        GS2M_LAUNCH(k_sort_tiles_bucket_8192x8, dim3(g[1], nv), dim3(1024), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    }
     GS2M_LAUNCH(k_sort_tiles, dim3(g[2], nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
 }

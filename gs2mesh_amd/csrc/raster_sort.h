@@ -395,32 +395,57 @@ GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int
     gs2m_wave_sync();
     auto start_of = [&](unsigned b) -> unsigned { return (s_cnt[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; };
 #pragma unroll
-    for (int r = 0; r < E; ++r)
-        if (r * 64 + lane < n) s_key[start_of(bucket_of(k[r])) + slot[r]] = k[r];
+    for (int r = 0; r < E; ++r) {
+        const unsigned st = start_of(r * 64 + lane < n ? bucket_of(k[r]) : 0u);   // unconditional read: E reads in flight
+        if (r * 64 + lane < n) s_key[st + slot[r]] = k[r];
+    }
     gs2m_wave_sync();
-    // rank inside the bucket -> final position
+    // rank inside the bucket -> final position.  A lane first reads its E keys and the bounds of their buckets, then all E
+    // buckets are walked in lock step for `mx` rounds (the largest bucket of the list: wave-uniform, <= GS2M_WAVE_BUCKET_MAX,
+    // typically 3-5): E independent LDS reads per round instead of E dependent walks one after the other.
+    // All LDS reads are unconditional (every index is inside the arrays; lanes without a key get len = 0): a read under a
+    // lane condition compiles to its own branch + wait, which would serialise the E reads again.
+    unsigned long long key[E];
+    unsigned lo[E], len[E], rank[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) key[r] = s_key[r * 64 + lane];
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        const int j = r * 64 + lane;
-        if (j < n) {
-            const unsigned long long key = s_key[j];
-            const unsigned b = bucket_of(key);
-            const unsigned lo = start_of(b), hi = start_of(b + 1u);
-            unsigned rank = 0u;
-            for (unsigned q = lo; q < hi; ++q) rank += s_key[q] < key ? 1u : 0u;
-            kv[lo + rank] = key;
+        const bool in = r * 64 + lane < n;
+        const unsigned b = in ? bucket_of(key[r]) : 0u;
+        const unsigned st = start_of(b), en = start_of(b + 1u);
+        lo[r] = st;
+        len[r] = in ? en - st : 0u;
+        rank[r] = 0u;
+    }
+    const unsigned rounds = (unsigned)gs2m_uniform((int)mx);
+    for (unsigned q = 0; q < rounds; ++q) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const bool more = q < len[r];
+            const unsigned long long other = s_key[more ? lo[r] + q : lo[r]];
+            rank[r] += (more && other < key[r]) ? 1u : 0u;
         }
     }
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+        if (r * 64 + lane < n) kv[lo[r] + rank[r]] = key[r];
     return true;
 }
 
-GS2M_KERNEL void __launch_bounds__(64)
+// WPB waves per workgroup, one list per wave (no workgroup barrier: a wave leaves as soon as its list is done).  C2 launches
+// 7600 lists per pair: as single-wave workgroups their dispatch alone took a third of the kernel.
+template <int WPB>
+GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
                    unsigned cap, int bucket) {
-    __shared__ unsigned long long s_key[GS2M_SORT_WAVE];
-    __shared__ unsigned s_cnt[GS2M_SORT_WAVE / 2 + 2];
-    const int lane = (int)threadIdx.x;
-    const int t = (int)blockIdx.x, v = (int)blockIdx.y;
+    __shared__ unsigned long long s_key_all[WPB][GS2M_SORT_WAVE];
+    __shared__ unsigned s_cnt_all[WPB][GS2M_SORT_WAVE / 2 + 2];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    unsigned long long* s_key = s_key_all[wave];
+    unsigned* s_cnt = s_cnt_all[wave];
+    const int t = gs2m_uniform((int)blockIdx.x * WPB + wave), v = (int)blockIdx.y;
+    if (t >= tiles) return;
     unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
     unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
     if (b > cap) b = cap;
@@ -463,14 +488,16 @@ GS2M_DEVICE void sort_block_regs(unsigned long long* __restrict__ kv, int n, uns
 // cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:303-308) for the mid-size lists that dominate a 2 M-Gaussian
 // scene (C3: 7.5 M keys in 4 240 lists, 275 us -> see profiles/r2*).  A list whose depths are so clustered that a
 // bucket holds more than GS2M_BUCKET_MAX keys falls back to the bitonic network (same result).
-// CAP = keys per list this instantiation takes (> CAP / 2 is left to it, <= CAP / 2 to the smaller one), THREADS = CAP / 16:
-// <4096, 256> (40 KiB of LDS: 4 workgroups per CU) for the bulk, <8192, 512> (80 KiB: 2 per CU) for the densest tiles.
+// CAP = keys per list this instantiation takes (> CAP / 2 is left to it, <= CAP / 2 to the smaller one), THREADS = CAP / 16
+// or CAP / 8: <4096, .> (40 KiB of LDS: 4 workgroups per CU) for the bulk, <8192, .> (80 KiB: 2 per CU) for the densest
+// tiles.  The sort of a list is a chain of short LDS phases between barriers: with CAP / 8 threads a list gets twice the
+// waves for the same LDS, i.e. 8 instead of 4 waves per SIMD to cover the LDS latency.
 #define GS2M_BUCKET_MAX 48
 template <int CAP, int THREADS>
 GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int n, unsigned long long* s_key, unsigned* s_cnt,
                                   unsigned* s_red, const int tid) {
     constexpr int NW = THREADS / 64, E = CAP / THREADS;
-    static_assert(E == 16, "16 keys per thread");
+    static_assert(E == 16 || E == 8, "8 or 16 keys per thread");
     const int lane = tid & 63, wave = tid >> 6;
     // ---- the keys (16 per thread, registers) and the depth range of the list
     unsigned long long k[E];
@@ -498,8 +525,12 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
         s_red[wave] = dmin;
         s_red[NW + wave] = dmax;
     }
-    int nb = THREADS * 4;                              // buckets: power of two >= n (>= 4 per thread for the scan)
-    while (nb < n) nb <<= 1;
+    // buckets: a power of two >= n when that fits, at most CAP / 2 (>= 4 per thread for the scan).  The cap keeps the
+    // counters at CAP / 4 words: 36.1 / 72.2 KiB per workgroup = 4 / 2 workgroups per CU (with CAP buckets the arrays were
+    // 144 bytes over the half / quarter of the 160 KiB and the kernels ran at 1 / 3 workgroups per CU); a list of n > CAP / 2
+    // keys then averages up to 2 keys per bucket.
+    int nb = THREADS * 4;
+    while (nb < n && nb < CAP / 2) nb <<= 1;
     for (int i = tid; i < nb / 2 + 1; i += THREADS) s_cnt[i] = 0u;
     __syncthreads();
 #pragma unroll
@@ -556,6 +587,7 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
     unsigned wg_max = 0u;
 #pragma unroll
     for (int w = 0; w < NW; ++w) wg_max = s_red[3 * NW + w] > wg_max ? s_red[3 * NW + w] : wg_max;
+    wg_max = (unsigned)gs2m_uniform((int)wg_max);
     if (wg_max > GS2M_BUCKET_MAX) {
         // clustered depths: LDS bitonic network over the whole list (same result; O(n log^2 n))
         __syncthreads();
@@ -592,27 +624,50 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int i = r * THREADS + tid;
-        if (i < n) s_key[start_of(bucket_of(k[r])) + slot[r]] = k[r];
+        const unsigned st = start_of(i < n ? bucket_of(k[r]) : 0u);   // unconditional read: E reads in flight
+        if (i < n) s_key[st + slot[r]] = k[r];
     }
     __syncthreads();
     // ---- rank inside the bucket -> final position; slot j of the bucket-ordered array goes to lo + rank
-    for (int j = tid; j < n; j += THREADS) {
-        const unsigned long long key = s_key[j];
-        const unsigned b = bucket_of(key);
-        const unsigned lo = start_of(b), hi = start_of(b + 1u);
-        unsigned rank = 0u;
-        for (unsigned q = lo; q < hi; ++q) rank += s_key[q] < key ? 1u : 0u;
-        kv[lo + rank] = key;
+    // (as in sort_wave_bucket: keys and bucket bounds first, then the buckets of a thread's keys walked in lock step for
+    // `wg_max` rounds -- 8 independent LDS reads per round; two passes of 8 keys when a thread holds 16)
+    constexpr int RC = 8;
+#pragma unroll
+    for (int c = 0; c < E / RC; ++c) {
+        unsigned long long key[RC];
+        unsigned lo[RC], len[RC], rank[RC];
+        // unconditional LDS reads (indices inside the arrays: j < CAP, buckets <= nb), lanes without a key get len = 0
+#pragma unroll
+        for (int r = 0; r < RC; ++r) key[r] = s_key[(c * RC + r) * THREADS + tid];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            const bool in = (c * RC + r) * THREADS + tid < n;
+            const unsigned b = in ? bucket_of(key[r]) : 0u;
+            const unsigned st = start_of(b), en = start_of(b + 1u);
+            lo[r] = st;
+            len[r] = in ? en - st : 0u;
+            rank[r] = 0u;
+        }
+        for (unsigned q = 0; q < wg_max; ++q) {
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                const bool more = q < len[r];
+                const unsigned long long other = s_key[more ? lo[r] + q : lo[r]];
+                rank[r] += (more && other < key[r]) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RC; ++r)
+            if ((c * RC + r) * THREADS + tid < n) kv[lo[r] + rank[r]] = key[r];
     }
 }
 
 // list = sort_lists[v][cls]: word 0 = number of tiles of the class, then their ids (k_tile_scan); a small grid walks it
 template <int CAP, int THREADS, int CLS>
-GS2M_KERNEL void __launch_bounds__(THREADS)
-k_sort_tiles_bucket(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles, unsigned cap,
-                    const unsigned* __restrict__ sort_lists) {
+GS2M_DEVICE void sort_tiles_bucket_body(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
+                                        unsigned cap, const unsigned* __restrict__ sort_lists) {
     __shared__ unsigned long long s_key[CAP];   // keys grouped by bucket
-    __shared__ unsigned s_cnt[CAP / 2 + 2];     // two 16-bit counters / start offsets per word: <= CAP buckets
+    __shared__ unsigned s_cnt[CAP / 4 + 2];     // two 16-bit counters / start offsets per word: <= CAP / 2 buckets
     __shared__ unsigned s_red[4 * (THREADS / 64)];
     const int tid = (int)threadIdx.x, v = (int)blockIdx.y;
     const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + CLS) * (tiles + 1);
@@ -630,6 +685,19 @@ k_sort_tiles_bucket(unsigned long long* __restrict__ keys, const unsigned* __res
         __syncthreads();   // the LDS arrays are reused by the next list
     }
 }
+// The occupancy attribute (a literal: it takes no template argument) makes the residency the LDS allows real: 4 workgroups
+// of the <4096> class, 2 of the <8192> class per CU = 4 waves per SIMD with 16 keys per thread (128 registers), 8 with 8 keys
+// per thread (64 registers).
+#define GS2M_SORT_BUCKET_KERNEL(NAME, CAP, THREADS, CLS, WAVES)                                                           \
+    GS2M_KERNEL void __launch_bounds__(THREADS) GS2M_WAVES_PER_SIMD(WAVES)                                                      \
+    NAME(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles, unsigned cap,        \
+         const unsigned* __restrict__ sort_lists) {                                                                      \
+        sort_tiles_bucket_body<CAP, THREADS, CLS>(keys, tile_start, tiles, cap, sort_lists);                              \
+    }
+GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_4096x16, 4096, 256, 0, 4)
+GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_8192x16, 8192, 512, 1, 4)
+GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_4096x8, 4096, 512, 0, 8)
+GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_8192x8, 8192, 1024, 1, 8)
 
 // Lists of more than GS2M_SORT_BUCKET_CAP instances (rare: a tile stack of a very dense scene): LDS-sorted runs of
 // GS2M_SORT_LDS keys (register-blocked bitonic, 3 stages through LDS), then rank-based merge passes through HBM

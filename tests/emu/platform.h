@@ -19,6 +19,7 @@
 #include <functional>
 
 #define GS2M_KERNEL
+#define GS2M_WAVES_PER_SIMD(n)
 #define GS2M_DEVICE static inline
 #define GS2M_PLATFORM_NAME "cpu-emulator"
 #define __launch_bounds__(...)

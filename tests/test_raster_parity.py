@@ -302,6 +302,53 @@ def test_mid_size_lists_use_the_bucket_sort(backend, depths):
     assert_image_close(img, ref_img)
 
 
+def test_dense_lists_use_the_large_bucket_class(backend):
+    """4096 < n <= 8192 instances in a list on a FRESH handle (no class hint: the size-class kernels run, not the LDS-free
+    stand-in): the <8192> bucket + rank sort with its capped bucket count (up to 2 keys per bucket on average), next to
+    lists of the <4096> class and of <= 512 instances (wave bucket sort).  Instance lists equal the oracle's exactly."""
+    W, H, f = 48, 32, 60.0
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    rng = np.random.default_rng(23)
+    P = 9400
+    xyz = rng.normal(0, 0.02, (P, 3)).astype(np.float32)
+    xyz[:, 1] -= 0.53                                            # ~6000 in the tile above the centre
+    xyz[6000:9000, 0] += 1.07                                    # ~3000 in the tile right of it
+    xyz[9000:, 0] -= 1.07                                        # ~400 bottom left
+    xyz[9000:, 1] += 1.06
+    xyz[:, 2] = rng.uniform(-0.2, 0.2, P)
+    o = rng.uniform(0.02, 0.4, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    s = np.full((P, 3), 0.012, np.float32)
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    r, img, radii = run_forward(backend, cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    assert r.last_num_rendered == ref_n
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
+                                 cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+    sizes = (ref_ranges[:, 1] - ref_ranges[:, 0]).astype(np.int64)
+    assert ((sizes > 4096) & (sizes <= 8192)).any() and ((sizes > 512) & (sizes <= 4096)).any() and ((sizes > 64) & (sizes <= 512)).any(), sizes
+    pl, ranges = r.download_binning(0, ref_n, 3 * 2)
+    np.testing.assert_array_equal(ranges, ref_ranges)
+    np.testing.assert_array_equal(pl, ref_pl)
+    assert_image_close(img, ref_img)
+
+
+@pytest.mark.parametrize("env", [{"GS2M_SORT_KEYS_PER_THREAD": "16", "GS2M_SORT_SMALL_WPB": "1"},
+                                 {"GS2M_SORT_SMALL_WPB": "2", "GS2M_SORT_WAVE_BUCKET": "0"}])
+def test_sort_geometry_knobs_do_not_change_results(env):
+    """The A/B knobs of the per-tile sort (16 keys per thread in the size-class kernels, 1 / 2 lists per workgroup in the
+    small-list kernel, bitonic network only) are read once per process: the sort tests again in a subprocess (emulator)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_raster_parity.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "mid_size_lists or dense_lists or lists_grow"], capture_output=True, text=True, timeout=1800,
+                       env=dict(os.environ, **env), cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_arena_overflow_is_detected_and_retried(backend):
     W, H, f = 96, 80, 90.0
     g, s, q, o, shs, left, _ = scene(2000, 8, W, H, f, log_s=math.log(0.08))
