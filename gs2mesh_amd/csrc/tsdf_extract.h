@@ -151,13 +151,13 @@ k_mc_emit(TsdfVolume V, const McDevTables* __restrict__ T, McGeom G, unsigned n_
             for (int j = 0; j < 3; ++j) {
                 const int e = T->tri[ci][3 * t + j];
                 const int c_lo = G.edge[e][0], c_hi = G.edge[e][1], axis = G.edge[e][2];
-                const float f0 = fabsf(f[c_lo]), f1 = fabsf(f[c_hi]);
+                const double f0 = fabs((double)f[c_lo]), f1 = fabs((double)f[c_hi]);   // Open3D: |double(f)|, sums in double
                 // global voxel index of the lower corner
                 const int gx = bx * GS2M_TSDF_RES + x + G.corner[c_lo][0];
                 const int gy = by * GS2M_TSDF_RES + y + G.corner[c_lo][1];
                 const int gz = bz * GS2M_TSDF_RES + z + G.corner[c_lo][2];
                 double p[3] = {half + voxel_length * gx, half + voxel_length * gy, half + voxel_length * gz};
-                p[axis] += (double)f0 * voxel_length / (double)(f0 + f1);
+                p[axis] += f0 * voxel_length / (f0 + f1);
                 double* vo = vertices + (out * 3 + j) * 3;
                 vo[0] = p[0];
                 vo[1] = p[1];
@@ -165,16 +165,17 @@ k_mc_emit(TsdfVolume V, const McDevTables* __restrict__ T, McGeom G, unsigned n_
                 if (colors) {
                     double col[3] = {0, 0, 0};
                     if (V.has_color) {
+                        double cend[2][3];   // corner colours: mean colour (sum / weight) / 255
                         for (int s = 0; s < 2; ++s) {
                             const int cc = s ? c_hi : c_lo;
                             const int cx = x + G.corner[cc][0], cy = y + G.corner[cc][1], cz = z + G.corner[cc][2];
                             const int sl = nb_slot[(cx >> 4) | ((cy >> 4) << 1) | ((cz >> 4) << 2)];
                             const size_t vi = GS2M_TSDF_VINDEX(cx & 15, cy & 15, cz & 15);
                             const double wv = (double)V.weight[(size_t)sl * GS2M_TSDF_VOX + vi];
-                            const double wgt = (double)(s ? f0 : f1) / (double)(f0 + f1);  // (f1*c0 + f0*c1)/(f0+f1)
                             for (int ch = 0; ch < 3; ++ch)
-                                col[ch] += wgt * ((double)V.rgb[((size_t)sl * 3 + ch) * GS2M_TSDF_VOX + vi] / wv) / 255.0;
+                                cend[s][ch] = ((double)V.rgb[((size_t)sl * 3 + ch) * GS2M_TSDF_VOX + vi] / wv) / 255.0;
                         }
+                        for (int ch = 0; ch < 3; ++ch) col[ch] = (f1 * cend[0][ch] + f0 * cend[1][ch]) / (f0 + f1);   // Open3D's form
                     }
                     double* co = colors + (out * 3 + j) * 3;
                     co[0] = col[0];

@@ -110,6 +110,9 @@ def tsdf_lib():
         lib.oracle_tsdf_block_updates.restype = C.c_int64
         lib.oracle_tsdf_block_updates.argtypes = [vp]
         lib.oracle_tsdf_export.argtypes = [vp, vp, vp, vp, vp]
+        lib.oracle_tsdf_extract_mesh.restype = C.c_int64
+        lib.oracle_tsdf_extract_mesh.argtypes = [vp, vp, vp, vp]
+        lib.oracle_tsdf_mesh_copy.argtypes = [vp, vp, vp, vp]
         _tsdf = lib
     return _tsdf
 
@@ -256,7 +259,7 @@ def activate(scaling_raw, rotation_raw, opacity_raw):
 # --------------------------------------------------------------------------------------
 
 class ScalableTSDFVolume:
-    """Restated open3d.pipelines.integration.ScalableTSDFVolume (integration only)."""
+    """Restated open3d.pipelines.integration.ScalableTSDFVolume (integrate + extract_triangle_mesh)."""
 
     def __init__(self, voxel_length, sdf_trunc, color_type=1, volume_unit_resolution=16,
                  depth_sampling_stride=4):
@@ -313,6 +316,22 @@ class ScalableTSDFVolume:
         color = np.zeros((n, nv, 3), np.float64)
         self._lib.oracle_tsdf_export(self._h, _ptr(keys), _ptr(tsdf), _ptr(weight), _ptr(color))
         return keys, tsdf, weight, color
+
+
+    def extract_triangle_mesh(self, tri_table):
+        """Restated ``ScalableTSDFVolume::ExtractTriangleMesh``.  ``tri_table``: the 256 rows of the classic marching-cubes
+        table (lists of edge ids, e.g. ``tools/mc_classic_table.T``).  -> dict(vertices [nv,3] f64, colors [nv,3] f64,
+        triangles [nt,3] i32, zero_offset_vertices)."""
+        tab = np.full((256, 16), -1, np.int8)
+        for c, row in enumerate(tri_table):
+            tab[c, :len(row)] = row
+        nv, nz = C.c_int64(0), C.c_int64(0)
+        nt = int(self._lib.oracle_tsdf_extract_mesh(self._h, _ptr(tab), C.addressof(nv), C.addressof(nz)))
+        v = np.zeros((int(nv.value), 3), np.float64)
+        col = np.zeros((int(nv.value), 3), np.float64)
+        tri = np.zeros((nt, 3), np.int32)
+        self._lib.oracle_tsdf_mesh_copy(self._h, _ptr(v), _ptr(col), _ptr(tri))
+        return dict(vertices=v, colors=col, triangles=tri, zero_offset_vertices=int(nz.value))
 
 
 def dist_multiplier(width, height, fx, fy, cx, cy):

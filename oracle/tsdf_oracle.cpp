@@ -1,5 +1,5 @@
 /*
- * tsdf_oracle.cpp -- CPU restatement of Open3D 0.17.0 ScalableTSDFVolume::Integrate.
+ * tsdf_oracle.cpp -- CPU restatement of Open3D 0.17.0 ScalableTSDFVolume::Integrate and ::ExtractTriangleMesh.
  *
  * TEST INFRASTRUCTURE ONLY (and bench.py's cpu_baseline leg).  Nothing in the product
  * path may import, link or execute this file.
@@ -87,6 +87,10 @@ struct Volume {
     std::vector<Vec3i> order; /* allocation order, for export */
     int64_t block_updates = 0;
     int num_threads = 0;
+    /* result of the last oracle_tsdf_extract_mesh */
+    std::vector<double> mesh_vertices, mesh_colors;
+    std::vector<int32_t> mesh_triangles;
+    int64_t mesh_zero_offset_vertices = 0;
 };
 
 inline int IndexOf(int x, int y, int z, int res) { return x * res * res + y * res + z; }
@@ -324,6 +328,137 @@ void oracle_tsdf_export(oracle_tsdf* vol, int32_t* keys, float* tsdf, float* wei
                 for (int c = 0; c < 3; ++c) color[(b * nv + i) * 3 + c] = u.voxels[i].color[c];
         }
     }
+}
+
+/* ScalableTSDFVolume::ExtractTriangleMesh (Open3D 0.17.0 cpp/open3d/pipelines/integration/ScalableTSDFVolume.cpp, the
+ * call of gs2mesh_utils/tsdf_utils.py:108), restated from knowledge of upstream -- PARITY UNPINNED like the rest of this
+ * file.  Marching cubes after P. Bourke's polygonise: for every volume unit and every voxel (x, y, z) of it the cube of
+ * the voxel and its +1 neighbours (`shift`; a corner outside the unit is looked up in the neighbouring unit, a missing
+ * unit gives weight 0) is skipped when any corner has weight 0; corner i is inside when tsdf < 0; for every cut edge
+ * (edge_table bit) the vertex is created once, keyed by the edge's global index (unit_index * resolution + (x, y, z) +
+ * edge_shift, 4th component = axis):
+ *     pt = half_voxel + voxel_length * edge_index.xyz;   pt[axis] += f0 * voxel_length / (f0 + f1)
+ * with f0 = |double(f[edge_to_vert[e][0]])|, f1 likewise, colour (f1 c0 + f0 c1) / (f0 + f1), c = voxel colour / 255; the
+ * triangles of tri_table[cube_index] are pushed as (e[i], e[i + 2], e[i + 1]).  Upstream walks its unordered_map of units
+ * (implementation-defined order): the mesh is defined up to the numbering of vertices and the order of triangles; here the
+ * units are walked in allocation order.  `tri_table` [256][16] (-1 terminated rows) is passed in by the caller (the table
+ * tools/mc_classic_table.py holds and verifies = MarchingCubesConst.h's); edge_table is derived from it (the edges a row
+ * uses are exactly the cut edges of the case -- one of the properties that script checks).
+ * Returns the number of triangles; *n_vertices = vertices; *n_zero = vertices whose offset along the edge is exactly 0
+ * (tsdf == 0 at the lower corner: several edges then share one position -- upstream keeps them apart). */
+int64_t oracle_tsdf_extract_mesh(oracle_tsdf* vol, const int8_t* tri_table, int64_t* n_vertices, int64_t* n_zero) {
+    static const int shift[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+    static const int edge_shift[12][4] = {{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 1, 0, 0}, {0, 0, 0, 1}, {0, 0, 1, 0}, {1, 0, 1, 1},
+                                          {0, 1, 1, 0}, {0, 0, 1, 1}, {0, 0, 0, 2}, {1, 0, 0, 2}, {1, 1, 0, 2}, {0, 1, 0, 2}};
+    static const int edge_to_vert[12][2] = {{0, 1}, {1, 2}, {3, 2}, {0, 3}, {4, 5}, {5, 6}, {7, 6}, {4, 7}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+    int edge_table[256];
+    for (int c = 0; c < 256; ++c) {
+        edge_table[c] = 0;
+        for (int i = 0; i < 16 && tri_table[c * 16 + i] >= 0; ++i) edge_table[c] |= 1 << tri_table[c * 16 + i];
+    }
+    struct Vec4i {
+        int v[4];
+        bool operator==(const Vec4i& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3]; }
+    };
+    struct Vec4iHash {
+        size_t operator()(const Vec4i& k) const {
+            size_t seed = 0;
+            for (int i = 0; i < 4; ++i) seed ^= std::hash<int>()(k.v[i]) + 0x9e3779b9 + (seed << 6) + (seed >> 2);
+            return seed;
+        }
+    };
+    std::unordered_map<Vec4i, int, Vec4iHash> edgeindex_to_vertexindex;
+    vol->mesh_vertices.clear();
+    vol->mesh_colors.clear();
+    vol->mesh_triangles.clear();
+    vol->mesh_zero_offset_vertices = 0;
+    const int res = vol->resolution;
+    const double half_voxel_length = vol->voxel_length * 0.5;
+    int edge_to_index[12];
+    for (const Vec3i& index0 : vol->order) {
+        const Unit& volume0 = *vol->units[index0];
+        for (int x = 0; x < res; x++)
+            for (int y = 0; y < res; y++)
+                for (int z = 0; z < res; z++) {
+                    int cube_index = 0;
+                    float w[8], f[8];
+                    double c[8][3];
+                    for (int i = 0; i < 8; i++) {
+                        Vec3i index1 = index0;
+                        int idx1[3] = {x + shift[i][0], y + shift[i][1], z + shift[i][2]};
+                        const TSDFVoxel* vox = nullptr;
+                        if (idx1[0] < res && idx1[1] < res && idx1[2] < res) {
+                            vox = &volume0.voxels[IndexOf(idx1[0], idx1[1], idx1[2], res)];
+                        } else {
+                            int* i1 = &index1.x;
+                            for (int j = 0; j < 3; j++)
+                                if (idx1[j] >= res) {
+                                    idx1[j] -= res;
+                                    i1[j] += 1;
+                                }
+                            auto it = vol->units.find(index1);
+                            if (it != vol->units.end()) vox = &it->second->voxels[IndexOf(idx1[0], idx1[1], idx1[2], res)];
+                        }
+                        if (vox) {
+                            w[i] = vox->weight;
+                            f[i] = vox->tsdf;
+                            for (int k = 0; k < 3; ++k) c[i][k] = vol->color_type == 1 ? vox->color[k] / 255.0 : 0.0;
+                        } else {
+                            w[i] = 0.0f;
+                            f[i] = 0.0f;
+                        }
+                        if (w[i] == 0.0f) {
+                            cube_index = 0;
+                            break;
+                        } else if (f[i] < 0.0f) {
+                            cube_index |= (1 << i);
+                        }
+                    }
+                    if (cube_index == 0 || cube_index == 255) continue;
+                    for (int i = 0; i < 12; i++) {
+                        if (!(edge_table[cube_index] & (1 << i))) continue;
+                        Vec4i edge_index;
+                        edge_index.v[0] = index0.x * res + x + edge_shift[i][0];
+                        edge_index.v[1] = index0.y * res + y + edge_shift[i][1];
+                        edge_index.v[2] = index0.z * res + z + edge_shift[i][2];
+                        edge_index.v[3] = edge_shift[i][3];
+                        auto found = edgeindex_to_vertexindex.find(edge_index);
+                        if (found == edgeindex_to_vertexindex.end()) {
+                            const int vi = (int)(vol->mesh_vertices.size() / 3);
+                            edge_to_index[i] = vi;
+                            edgeindex_to_vertexindex[edge_index] = vi;
+                            double pt[3] = {half_voxel_length + vol->voxel_length * edge_index.v[0],
+                                            half_voxel_length + vol->voxel_length * edge_index.v[1],
+                                            half_voxel_length + vol->voxel_length * edge_index.v[2]};
+                            const double f0 = std::abs((double)f[edge_to_vert[i][0]]);
+                            const double f1 = std::abs((double)f[edge_to_vert[i][1]]);
+                            pt[edge_index.v[3]] += f0 * vol->voxel_length / (f0 + f1);
+                            if (f0 == 0.0) vol->mesh_zero_offset_vertices++;
+                            for (int k = 0; k < 3; ++k) vol->mesh_vertices.push_back(pt[k]);
+                            const double* c0 = c[edge_to_vert[i][0]];
+                            const double* c1 = c[edge_to_vert[i][1]];
+                            for (int k = 0; k < 3; ++k) vol->mesh_colors.push_back((f1 * c0[k] + f0 * c1[k]) / (f0 + f1));
+                        } else {
+                            edge_to_index[i] = found->second;
+                        }
+                    }
+                    for (int i = 0; i < 16 && tri_table[cube_index * 16 + i] != -1; i += 3) {
+                        vol->mesh_triangles.push_back(edge_to_index[tri_table[cube_index * 16 + i]]);
+                        vol->mesh_triangles.push_back(edge_to_index[tri_table[cube_index * 16 + i + 2]]);
+                        vol->mesh_triangles.push_back(edge_to_index[tri_table[cube_index * 16 + i + 1]]);
+                    }
+                }
+    }
+    if (n_vertices) *n_vertices = (int64_t)(vol->mesh_vertices.size() / 3);
+    if (n_zero) *n_zero = vol->mesh_zero_offset_vertices;
+    return (int64_t)(vol->mesh_triangles.size() / 3);
+}
+
+/* vertices [nv,3] f64, colors [nv,3] f64 (zeros without colour), triangles [nt,3] i32 of the last extraction */
+void oracle_tsdf_mesh_copy(oracle_tsdf* vol, double* vertices, double* colors, int32_t* triangles) {
+    if (vertices) memcpy(vertices, vol->mesh_vertices.data(), vol->mesh_vertices.size() * sizeof(double));
+    if (colors) memcpy(colors, vol->mesh_colors.data(), vol->mesh_colors.size() * sizeof(double));
+    if (triangles) memcpy(triangles, vol->mesh_triangles.data(), vol->mesh_triangles.size() * sizeof(int32_t));
 }
 
 } /* extern "C" */
