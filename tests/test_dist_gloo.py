@@ -114,8 +114,14 @@ def test_eight_ranks_reduce_scatter_direct_and_owner_side_mesh(tmp_path):
     assert owned_all == set(ref)
     got = np.concatenate(parts, axis=0)
     assert got.shape == tri_ref.shape and len(got) > 1000
-    key = lambda t: t[np.lexsort(np.round(np.concatenate([t.mean(axis=1), t[:, 0]], axis=1) * 1e5).astype(np.int64).T[::-1])]
-    np.testing.assert_allclose(key(got), key(tri_ref), atol=2e-6, rtol=0)
+    # the sharded tsdf differs from the single-process one by the order of the sums (<= 1e-5): the triangles are matched by
+    # nearest neighbour in the 9-D space of their three vertices (emission order of the vertices is the same on both sides);
+    # the match must be a bijection and every vertex within 2e-6
+    from scipy.spatial import cKDTree
+    a, b = got.reshape(len(got), 9), tri_ref.reshape(len(tri_ref), 9)
+    dist, nn = cKDTree(b).query(a, k=1)
+    assert len(np.unique(nn)) == len(b)
+    np.testing.assert_allclose(a, b[nn], atol=2e-6, rtol=0)
 
 
 def test_halo_copies_are_not_exchanged_twice(tmp_path):
