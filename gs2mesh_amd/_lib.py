@@ -31,7 +31,7 @@ class Gaussians(C.Structure):
                 ("xyz", vp), ("scales", vp), ("rotations", vp), ("opacities", vp), ("shs", vp), ("shs_rest", vp)]
 
 
-ABI_VERSION = 300   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
+ABI_VERSION = 301   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
 OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
@@ -69,6 +69,7 @@ _PROTOS = {
     "gs2m_raster_download_binning": (i32, [vp, vp, i32, i64, vp, C.c_int32, vp]),
     "gs2m_tsdf_extract_count": (i32, [vp, vp, C.POINTER(i64)]),
     "gs2m_tsdf_extract": (i32, [vp, vp, i64, vp, vp, C.POINTER(i64)]),
+    "gs2m_tsdf_extract_indexed": (i32, [vp, vp, i64, vp, vp, vp, C.POINTER(i64)]),
     "gs2m_stereo_depth_occlusion": (i32, [vp, vp, i32, i32, f64, f64, vp, vp, vp]),
     "gs2m_tsdf_create": (i32, [C.POINTER(vp), f64, f64, i32, i32, i32, i64, i32]),
     "gs2m_tsdf_destroy": (i32, [vp]),

@@ -567,6 +567,11 @@ extern "C" int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t
 
 extern "C" int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
                                  double* colors, int64_t* n_triangles) {
+    return gs2m_tsdf_extract_indexed(t, stream, max_triangles, vertices, colors, nullptr, n_triangles);
+}
+
+extern "C" int gs2m_tsdf_extract_indexed(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
+                                         double* colors, int32_t* edge_index, int64_t* n_triangles) {
     if (!t || !vertices || max_triangles < 0) {
         gs2m_set_error("gs2m_tsdf_extract: bad argument");
         return 1;
@@ -578,6 +583,6 @@ extern "C" int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_t
     int64_t nb = 0;
     if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
     gs2m_launch_mc_emit((hipStream_t)stream, t->V, t->d_mc, (unsigned)nb, t->d_blk_tris, (unsigned long long)max_triangles,
-                        t->voxel_length, t->unit_length, vertices, colors);
+                        t->voxel_length, t->unit_length, vertices, colors, edge_index);
     return 0;
 }

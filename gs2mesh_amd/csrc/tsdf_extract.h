@@ -106,11 +106,11 @@ k_mc_scan(unsigned* __restrict__ blk_tris, unsigned n_blocks, unsigned long long
     if (tid == 1023) *n_total = part[1023];
 }
 
-// pass 2: emit.  vertices / colours: [n_tri][3][3] float64 (Open3D meshes are double).
+// pass 2: emit.  vertices / colours: [n_tri][3][3] float64 (Open3D meshes are double); edge_index (optional): [n_tri][3][4] int32.
 GS2M_KERNEL void __launch_bounds__(256)
 k_mc_emit(TsdfVolume V, const McDevTables* __restrict__ T, McGeom G, unsigned n_blocks,
           const unsigned* __restrict__ blk_off, unsigned long long max_tris, double voxel_length, double unit_length,
-          double* __restrict__ vertices, double* __restrict__ colors) {
+          double* __restrict__ vertices, double* __restrict__ colors, int* __restrict__ edge_index) {
     __shared__ int nb_slot[8];
     __shared__ unsigned scan[256];
     const int tid = (int)threadIdx.x;
@@ -162,6 +162,13 @@ k_mc_emit(TsdfVolume V, const McDevTables* __restrict__ T, McGeom G, unsigned n_
                 vo[0] = p[0];
                 vo[1] = p[1];
                 vo[2] = p[2];
+                if (edge_index) {   // Open3D's vertex key: global voxel index of the edge's lower corner + axis
+                    int* eo = edge_index + (out * 3 + j) * 4;
+                    eo[0] = gx;
+                    eo[1] = gy;
+                    eo[2] = gz;
+                    eo[3] = axis;
+                }
                 if (colors) {
                     double col[3] = {0, 0, 0};
                     if (V.has_color) {

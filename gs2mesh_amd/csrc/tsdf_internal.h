@@ -22,5 +22,5 @@ void gs2m_launch_mc_count(hipStream_t st, const TsdfVolume& V, const McDevTables
                           unsigned* blk_tris, unsigned long long* n_total);
 void gs2m_launch_mc_emit(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
                          const unsigned* blk_off, unsigned long long max_tris, double voxel_length, double unit_length,
-                         double* vertices, double* colors);
+                         double* vertices, double* colors, int* edge_index);
 void gs2m_set_error(const char* fmt, ...);

@@ -64,12 +64,12 @@ void gs2m_launch_mc_count(hipStream_t st, const TsdfVolume& V, const McDevTables
 }
 void gs2m_launch_mc_emit(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
                          const unsigned* blk_off, unsigned long long max_tris, double voxel_length, double unit_length,
-                         double* vertices, double* colors) {
+                         double* vertices, double* colors, int* edge_index) {
     McGeom G;
     for (int i = 0; i < 8; ++i)
         for (int a = 0; a < 3; ++a) G.corner[i][a] = mc_corner[i][a];
     for (int e = 0; e < 12; ++e)
         for (int a = 0; a < 3; ++a) G.edge[e][a] = mc_edge[e][a];
     GS2M_LAUNCH(k_mc_emit, dim3(n_blocks), dim3(256), 0, st, V, T, G, n_blocks, blk_off, max_tris, voxel_length,
-                unit_length, vertices, colors);
+                unit_length, vertices, colors, edge_index);
 }

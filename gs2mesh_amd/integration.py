@@ -252,7 +252,7 @@ class ScalableTSDFVolume:
 
     def extract_triangle_mesh(self, stream=None):
         """``volume.extract_triangle_mesh()`` (tsdf_utils.py:108): marching cubes on the GPU
-        (``gs2m_tsdf_extract``), vertices welded on the host -> ``gs2mesh_amd.mesh.TriangleMesh``."""
+        (``gs2m_tsdf_extract_indexed``), vertices welded on the host by their cut edge -> ``gs2mesh_amd.mesh.TriangleMesh``."""
         from .mesh import TriangleMesh
         st = stream or C.c_void_p(0)
         n = C.c_int64(0)
@@ -264,17 +264,20 @@ class ScalableTSDFVolume:
         if host:
             verts = np.zeros((nt, 3, 3), np.float64)
             cols = np.zeros((nt, 3, 3), np.float64)
+            eidx = np.zeros((nt, 3, 4), np.int32)
         else:
             verts = torch.zeros((nt, 3, 3), dtype=torch.float64, device=f"cuda:{self.device}")
             cols = torch.zeros((nt, 3, 3), dtype=torch.float64, device=f"cuda:{self.device}")
+            eidx = torch.zeros((nt, 3, 4), dtype=torch.int32, device=f"cuda:{self.device}")
         got = C.c_int64(0)
-        _lib.check(self._lib.gs2m_tsdf_extract(self._h, _stream_of(verts, stream), nt, _ptr(verts), _ptr(cols),
-                                               C.byref(got)), self._lib)
+        _lib.check(self._lib.gs2m_tsdf_extract_indexed(self._h, _stream_of(verts, stream), nt, _ptr(verts), _ptr(cols),
+                                                       _ptr(eidx), C.byref(got)), self._lib)
         self.status(stream)
         if not host:
-            verts, cols = verts.cpu().numpy(), cols.cpu().numpy()
+            verts, cols, eidx = verts.cpu().numpy(), cols.cpu().numpy(), eidx.cpu().numpy()
         has_color = self.color_type == TSDFVolumeColorType.RGB8
-        return TriangleMesh.from_triangle_soup(verts, cols if has_color else None)
+        # welded by Open3D's vertex identity (the cut edge), not by position
+        return TriangleMesh.from_triangle_soup(verts, cols if has_color else None, edge_index=eidx)
 
     # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
     def block_keys(self, like=None, stream=None, raise_on_overflow=True):

@@ -16,15 +16,22 @@ class TriangleMesh:
                               else np.asarray(vertex_colors, np.float64))
         self.vertex_normals = np.zeros((0, 3), np.float64)
         self.triangle_normals = np.zeros((0, 3), np.float64)
+        self.edge_index = np.zeros((0, 4), np.int32)   # per vertex, after extraction: the cut edge (Open3D's vertex key)
 
     # ---- construction from the un-welded GPU output ------------------------------------------
     @staticmethod
-    def from_triangle_soup(verts, cols=None):
-        """verts [n,3,3] float64: vertices shared by neighbouring triangles are bit-identical -> exact weld."""
+    def from_triangle_soup(verts, cols=None, edge_index=None):
+        """verts [n,3,3] float64.  With ``edge_index`` [n,3,4] int32 (the cut edge of every emitted vertex: global voxel
+        index of its lower corner + axis) the vertices are welded by that key, which is Open3D's own vertex identity
+        (ExtractTriangleMesh's edge -> vertex map); without it by position (vertices shared by neighbouring triangles are
+        bit-identical) -- the same mesh unless a tsdf value is exactly 0, where up to three edges share one position."""
         v = np.ascontiguousarray(verts, np.float64).reshape(-1, 3)
         if v.shape[0] == 0:
             return TriangleMesh()
-        key = v.view([("", np.float64)] * 3).reshape(-1)
+        if edge_index is not None:
+            key = np.ascontiguousarray(edge_index, np.int32).reshape(-1, 4).view([("", np.int32)] * 4).reshape(-1)
+        else:
+            key = v.view([("", np.float64)] * 3).reshape(-1)
         _, first, inv = np.unique(key, return_index=True, return_inverse=True)
         # keep first-appearance order (deterministic, independent of float ordering)
         order = np.argsort(first, kind="stable")
@@ -33,6 +40,8 @@ class TriangleMesh:
         tri = rank[inv].reshape(-1, 3).astype(np.int32)
         sel = first[order]
         m = TriangleMesh(v[sel], tri, None if cols is None else np.asarray(cols, np.float64).reshape(-1, 3)[sel])
+        if edge_index is not None:
+            m.edge_index = np.ascontiguousarray(edge_index, np.int32).reshape(-1, 4)[sel]   # [n_vertices, 4]: Open3D's vertex keys
         return m
 
     # ---- Open3D API subset -----------------------------------------------------------------
@@ -100,6 +109,8 @@ class TriangleMesh:
             self.vertex_colors = self.vertex_colors[used]
         if self.vertex_normals.shape[0] == used.shape[0]:
             self.vertex_normals = self.vertex_normals[used]
+        if self.edge_index.shape[0] == used.shape[0]:
+            self.edge_index = self.edge_index[used]
         return self
 
     def has_vertex_normals(self):

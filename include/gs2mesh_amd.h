@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GS2M_VERSION 300 /* 0.3.0: round-3 ABI (sum-form exchange buffers, sticky overflow word, masked streams);
+#define GS2M_VERSION 301 /* 0.3.0: round-3 ABI (sum-form exchange buffers, sticky overflow word, masked streams);
                             the Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
@@ -372,6 +372,12 @@ int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, con
 int gs2m_tsdf_extract_count(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_triangles);
 int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
                       double* colors, int64_t* n_triangles);
+/* The same + edge_index[n,3,4] (int32, DEVICE, may be NULL): per emitted vertex Open3D's vertex key -- the global voxel
+ * index of the lower corner of the cut edge and the edge's axis (ExtractTriangleMesh's `edge_index`).  Welding by this key
+ * instead of by position reproduces Open3D's vertex set also where a tsdf value is exactly 0 (the vertices of up to
+ * three cut edges then share one position and Open3D keeps them apart). */
+int gs2m_tsdf_extract_indexed(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
+                              double* colors, int32_t* edge_index, int64_t* n_triangles);
 
 /* ------------------------------------------------------------------------------------ */
 /* stereo post-processing (between the stereo network and the TSDF)                     */

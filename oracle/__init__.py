@@ -112,7 +112,8 @@ def tsdf_lib():
         lib.oracle_tsdf_export.argtypes = [vp, vp, vp, vp, vp]
         lib.oracle_tsdf_extract_mesh.restype = C.c_int64
         lib.oracle_tsdf_extract_mesh.argtypes = [vp, vp, vp, vp]
-        lib.oracle_tsdf_mesh_copy.argtypes = [vp, vp, vp, vp]
+        lib.oracle_tsdf_mesh_copy.argtypes = [vp, vp, vp, vp, vp]
+        lib.oracle_tsdf_import.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
         _tsdf = lib
     return _tsdf
 
@@ -330,8 +331,18 @@ class ScalableTSDFVolume:
         v = np.zeros((int(nv.value), 3), np.float64)
         col = np.zeros((int(nv.value), 3), np.float64)
         tri = np.zeros((nt, 3), np.int32)
-        self._lib.oracle_tsdf_mesh_copy(self._h, _ptr(v), _ptr(col), _ptr(tri))
-        return dict(vertices=v, colors=col, triangles=tri, zero_offset_vertices=int(nz.value))
+        eidx = np.zeros((int(nv.value), 4), np.int32)
+        self._lib.oracle_tsdf_mesh_copy(self._h, _ptr(v), _ptr(col), _ptr(tri), _ptr(eidx))
+        return dict(vertices=v, colors=col, triangles=tri, edge_index=eidx, zero_offset_vertices=int(nz.value))
+
+    def import_state(self, keys, tsdf, weight, color=None):
+        """Test aid: set the state of the units ``keys`` [n,3] directly; tsdf / weight [n,res^3] in (x, y, z) index order
+        x * res^2 + y * res + z, color [n,res^3,3] float64 or None."""
+        k = np.ascontiguousarray(keys, np.int32)
+        t = np.ascontiguousarray(tsdf, np.float32)
+        w = np.ascontiguousarray(weight, np.float32)
+        c = None if color is None else np.ascontiguousarray(color, np.float64)
+        self._lib.oracle_tsdf_import(self._h, int(k.shape[0]), _ptr(k), _ptr(t), _ptr(w), _ptr(c))
 
 
 def dist_multiplier(width, height, fx, fy, cx, cy):

@@ -89,7 +89,7 @@ struct Volume {
     int num_threads = 0;
     /* result of the last oracle_tsdf_extract_mesh */
     std::vector<double> mesh_vertices, mesh_colors;
-    std::vector<int32_t> mesh_triangles;
+    std::vector<int32_t> mesh_triangles, mesh_edge_index;
     int64_t mesh_zero_offset_vertices = 0;
 };
 
@@ -344,8 +344,8 @@ void oracle_tsdf_export(oracle_tsdf* vol, int32_t* keys, float* tsdf, float* wei
  * units are walked in allocation order.  `tri_table` [256][16] (-1 terminated rows) is passed in by the caller (the table
  * tools/mc_classic_table.py holds and verifies = MarchingCubesConst.h's); edge_table is derived from it (the edges a row
  * uses are exactly the cut edges of the case -- one of the properties that script checks).
- * Returns the number of triangles; *n_vertices = vertices; *n_zero = vertices whose offset along the edge is exactly 0
- * (tsdf == 0 at the lower corner: several edges then share one position -- upstream keeps them apart). */
+ * Returns the number of triangles; *n_vertices = vertices; *n_zero = vertices that lie exactly on a corner of their edge
+ * (tsdf == 0 at one end: several edges then share one position -- upstream keeps them apart). */
 int64_t oracle_tsdf_extract_mesh(oracle_tsdf* vol, const int8_t* tri_table, int64_t* n_vertices, int64_t* n_zero) {
     static const int shift[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
     static const int edge_shift[12][4] = {{0, 0, 0, 0}, {1, 0, 0, 1}, {0, 1, 0, 0}, {0, 0, 0, 1}, {0, 0, 1, 0}, {1, 0, 1, 1},
@@ -371,6 +371,7 @@ int64_t oracle_tsdf_extract_mesh(oracle_tsdf* vol, const int8_t* tri_table, int6
     vol->mesh_vertices.clear();
     vol->mesh_colors.clear();
     vol->mesh_triangles.clear();
+    vol->mesh_edge_index.clear();
     vol->mesh_zero_offset_vertices = 0;
     const int res = vol->resolution;
     const double half_voxel_length = vol->voxel_length * 0.5;
@@ -433,7 +434,8 @@ int64_t oracle_tsdf_extract_mesh(oracle_tsdf* vol, const int8_t* tri_table, int6
                             const double f0 = std::abs((double)f[edge_to_vert[i][0]]);
                             const double f1 = std::abs((double)f[edge_to_vert[i][1]]);
                             pt[edge_index.v[3]] += f0 * vol->voxel_length / (f0 + f1);
-                            if (f0 == 0.0) vol->mesh_zero_offset_vertices++;
+                            if (f0 == 0.0 || f1 == 0.0) vol->mesh_zero_offset_vertices++;
+                            for (int k = 0; k < 4; ++k) vol->mesh_edge_index.push_back(edge_index.v[k]);
                             for (int k = 0; k < 3; ++k) vol->mesh_vertices.push_back(pt[k]);
                             const double* c0 = c[edge_to_vert[i][0]];
                             const double* c1 = c[edge_to_vert[i][1]];
@@ -454,11 +456,39 @@ int64_t oracle_tsdf_extract_mesh(oracle_tsdf* vol, const int8_t* tri_table, int6
     return (int64_t)(vol->mesh_triangles.size() / 3);
 }
 
-/* vertices [nv,3] f64, colors [nv,3] f64 (zeros without colour), triangles [nt,3] i32 of the last extraction */
-void oracle_tsdf_mesh_copy(oracle_tsdf* vol, double* vertices, double* colors, int32_t* triangles) {
+/* vertices [nv,3] f64, colors [nv,3] f64 (zeros without colour), triangles [nt,3] i32, edge_index [nv,4] i32 (the key
+ * upstream's edgeindex_to_vertexindex map holds for the vertex) of the last extraction */
+void oracle_tsdf_mesh_copy(oracle_tsdf* vol, double* vertices, double* colors, int32_t* triangles, int32_t* edge_index) {
     if (vertices) memcpy(vertices, vol->mesh_vertices.data(), vol->mesh_vertices.size() * sizeof(double));
     if (colors) memcpy(colors, vol->mesh_colors.data(), vol->mesh_colors.size() * sizeof(double));
     if (triangles) memcpy(triangles, vol->mesh_triangles.data(), vol->mesh_triangles.size() * sizeof(int32_t));
+    if (edge_index) memcpy(edge_index, vol->mesh_edge_index.data(), vol->mesh_edge_index.size() * sizeof(int32_t));
+}
+
+/* Test aid: set the state of n volume units directly (allocating them): keys [n,3], tsdf / weight [n,res^3] in IndexOf
+ * order (x * res^2 + y * res + z), color [n,res^3,3] f64 (may be null).  No upstream counterpart. */
+void oracle_tsdf_import(oracle_tsdf* vol, int64_t n, const int32_t* keys, const float* tsdf, const float* weight,
+                        const double* color) {
+    const size_t nv = (size_t)vol->resolution * vol->resolution * vol->resolution;
+    for (int64_t b = 0; b < n; ++b) {
+        const Vec3i k{keys[3 * b], keys[3 * b + 1], keys[3 * b + 2]};
+        auto it = vol->units.find(k);
+        if (it == vol->units.end()) {
+            std::unique_ptr<Unit> u(new Unit());
+            u->origin[0] = k.x * vol->unit_length;
+            u->origin[1] = k.y * vol->unit_length;
+            u->origin[2] = k.z * vol->unit_length;
+            u->voxels.resize(nv);
+            it = vol->units.emplace(k, std::move(u)).first;
+            vol->order.push_back(k);
+        }
+        for (size_t i = 0; i < nv; ++i) {
+            TSDFVoxel& v = it->second->voxels[i];
+            v.tsdf = tsdf[b * nv + i];
+            v.weight = weight[b * nv + i];
+            for (int c = 0; c < 3; ++c) v.color[c] = color ? color[(b * nv + i) * 3 + c] : 0.0;
+        }
+    }
 }
 
 } /* extern "C" */

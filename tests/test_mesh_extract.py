@@ -86,10 +86,11 @@ def test_fused_sphere_mesh_is_an_oriented_manifold_on_the_sphere(backend):
     np.testing.assert_array_equal(m2.triangles, mesh.triangles)
 
 
-def canonical_mesh(vertices, colors, triangles):
-    """Numbering-independent form: vertices sorted lexicographically, every triangle rotated so that its smallest index
-    comes first (winding kept), triangles sorted."""
-    order = np.lexsort((vertices[:, 2], vertices[:, 1], vertices[:, 0]))
+def canonical_mesh(vertices, colors, triangles, vertex_key=None):
+    """Numbering-independent form: vertices sorted lexicographically (by position, or by the columns of ``vertex_key``),
+    every triangle rotated so that its smallest index comes first (winding kept), triangles sorted."""
+    k = vertices if vertex_key is None else np.asarray(vertex_key)
+    order = np.lexsort(tuple(k[:, c] for c in range(k.shape[1] - 1, -1, -1)))
     rank = np.empty(order.size, np.int64)
     rank[order] = np.arange(order.size)
     t = rank[np.asarray(triangles, np.int64)]
@@ -133,6 +134,59 @@ def test_fused_sphere_mesh_equals_the_restated_open3d_extraction(backend):
     np.testing.assert_array_equal(v, ov)
     np.testing.assert_array_equal(t, ot)
     np.testing.assert_allclose(c, oc, rtol=0, atol=1e-12)
+
+
+def test_exact_zero_tsdf_values_keep_open3ds_vertices_apart(backend):
+    """A diagonal plane through voxel centres: tsdf == 0 exactly on those voxels, so the cut edges that end there (up to
+    three, one per axis) put their vertices at ONE position.  Open3D keys vertices by edge and keeps them apart; the device
+    path emits every vertex with its edge key (gs2m_tsdf_extract_indexed) and welds by it: same vertex count, same triangles
+    as the restated ExtractTriangleMesh -- a weld by position would merge them."""
+    import sys
+    import oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import mc_classic_table
+    from gs2mesh_amd.mesh import TriangleMesh
+    be = backend
+    vl = 1.0 / 32
+    vol = ScalableTSDFVolume(vl, 4 * vl, TSDFVolumeColorType.RGB8, max_blocks=64, lib=be.lib)
+    ref = oracle.ScalableTSDFVolume(vl, 4 * vl, 1)
+    keys = np.array([[bx, by, bz] for bx in range(2) for by in range(2) for bz in range(2)], np.int32)
+    n = len(keys)
+    x, y, z = np.meshgrid(np.arange(16), np.arange(16), np.arange(16), indexing="ij")
+    vidx = ((z >> 2) * 16 + (x >> 2) * 4 + (y >> 2)) * 64 + (z & 3) * 16 + (x & 3) * 4 + (y & 3)   # device layout
+    wsum = np.zeros((n, 4096), np.float32)
+    w = np.ones((n, 4096), np.float32)
+    rgb = np.zeros((n, 3, 4096), np.uint32)
+    o_tsdf = np.zeros((n, 4096), np.float32)
+    o_col = np.zeros((n, 4096, 3), np.float64)
+    for b, k in enumerate(keys):
+        g = (k[0] * 16 + x) + (k[1] * 16 + y) + (k[2] * 16 + z)            # integer: exact in fp32
+        f = np.clip((g - 40).astype(np.float32) / np.float32(8.0), -1, 1)  # == 0 exactly on the plane x + y + z = 40
+        wsum[b, vidx.reshape(-1)] = f.reshape(-1)
+        rgb[b, 0, vidx.reshape(-1)] = ((k[0] * 16 + x) * 4).reshape(-1)
+        rgb[b, 1, :] = 128
+        o_tsdf[b] = f.reshape(-1)                                          # (x, y, z) index order
+        o_col[b, :, 0] = ((k[0] * 16 + x) * 4).reshape(-1)
+        o_col[b, :, 1] = 128
+    buf = np.concatenate([wsum[:, None], w[:, None], rgb.astype(np.float32)], axis=1)
+    vol.unpack_sum(be.dev(keys), be.dev(np.ascontiguousarray(buf)))
+    ref.import_state(keys, o_tsdf, w, o_col)
+    om = ref.extract_triangle_mesh(mc_classic_table.T)
+    assert om["zero_offset_vertices"] > 100
+    mesh = vol.extract_triangle_mesh()
+    assert mesh.vertices.shape == om["vertices"].shape and mesh.triangles.shape == om["triangles"].shape
+    # positions alone do not identify the vertices here
+    assert len(np.unique(om["vertices"], axis=0)) < len(om["vertices"])
+    # numbering-independent comparison: vertices ordered by their edge key on both sides
+    ov, oc, ot = canonical_mesh(om["vertices"], om["colors"], om["triangles"], vertex_key=om["edge_index"])
+    v, c, t = canonical_mesh(mesh.vertices, mesh.vertex_colors, mesh.triangles, vertex_key=mesh.edge_index)
+    np.testing.assert_array_equal(v, ov)
+    np.testing.assert_array_equal(t, ot)
+    np.testing.assert_allclose(c, oc, rtol=0, atol=1e-12)
+    # and a weld by position would have lost vertices
+    soup = mesh.vertices[mesh.triangles]
+    assert TriangleMesh.from_triangle_soup(soup).vertices.shape[0] < mesh.vertices.shape[0]
 
 
 class FakeRenderer:
