@@ -66,6 +66,47 @@ def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
         assert np.array_equal(a, b)
 
 
+def test_model_updated_orders_the_render_streams_after_the_callers_stream():
+    """The render streams wait for the caller's stream once per slot, not per step (pipeline.py): a model changed in place on
+    the caller's stream needs `model_updated()` -- packed copies dropped, every render stream re-armed -- and the next renders
+    show the new model, bit for bit what a fresh handle renders."""
+    import torch
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+    cfg = synthetic.CONFIGS["C1"]
+    dev = torch.device("cuda:0")
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+    gd["raw"] = True
+    W, H = cfg.width, cfg.height
+    poses = synthetic.ring_poses(4, cfg.ring_radius, 0, 4)
+    cams = []
+    for p in poses:
+        l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
+        cams.append([camera_from(l), camera_from(r)])
+    pipe = RenderFusePipeline(gd, W, H, None, None, inflight=3, device=0)
+    pipe.prepare(cams[0])
+    for i in range(4):
+        pipe.submit(cams[i])
+    # in-place update on the caller's (current) stream while earlier renders may still be in flight on theirs
+    pipe.drain()
+    gd["xyz"].mul_(0.9)
+    gd["opacity"].add_(0.5)
+    gd["features_dc"].mul_(0.5)
+    pipe.model_updated()
+    got = []
+    for i in range(4):
+        slot = pipe.submit(cams[i])
+        pipe.wait_rendered(slot)
+        got.append(pipe.color[slot].cpu().numpy().copy())
+    pipe.finish()
+    pipe.close()
+    fresh = Rasterizer(0)
+    for i in range(4):
+        res = fresh.render_views(gd, cams[i])
+        assert np.array_equal(res["color"].cpu().numpy(), got[i]), i
+
+
 @pytest.mark.parametrize("kw", [dict(blend_cus=224), dict(blend_cus=192, bin_cus="rest", fuse_cus="rest", blend_streams=1),
                                 dict(blend_cus=224, fuse_cus="blend", blend_streams=3), dict(layout="two_stage"),
                                 dict(layout="two_stage", bin_streams=2)])
