@@ -66,6 +66,7 @@ GS2M_DEVICE int gs2m_syncthreads_count(int pred) { return __syncthreads_count(pr
 GS2M_DEVICE float gs2m_fast_exp(float x) { return __expf(x); }
 GS2M_DEVICE float gs2m_fast_log(float x) { return __logf(x); }
 GS2M_DEVICE float gs2m_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // v_rcp_f32 (1 ulp)
+GS2M_DEVICE float gs2m_fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32 (1 ulp)
 GS2M_DEVICE float gs2m_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (flushes denormal results)
 GS2M_DEVICE float gs2m_fast_log2(float x) { return __log2f(x); }
 // keep a loop-invariant float in its VGPR (stops the compiler re-materialising int->float converts in hot loops)

@@ -265,11 +265,14 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             const bool have = base + (unsigned)lane < r1;
             const float op = have ? rb.y : 1.0f;
             const float lo = gs2m_fast_log2(op);                           // log2 o
-            const float t2 = fmaxf(2.0f * (gs2m_fast_log(op * 255.0f) + 1.0e-4f), 0.0f);  // 2 ln(255 o) (+ margin)
+            // The bounding box is a conservative pre-filter (margins: 1e-4 on the threshold, 0.1 % + 0.01 px on the half
+            // extents): 1-ulp hardware rcp / sqrt and ln(255 o) = (log2 o + log2 255) ln 2 instead of a second logarithm, a
+            // correctly rounded division and two correctly rounded square roots (-30 % of the staging step's vector ops).
+            const float t2 = fmaxf(2.0f * ((lo + 7.99435343685885793770f) * 0.69314718055994530942f + 1.0e-4f), 0.0f);  // 2 ln(255 o) (+ margin)
             const float det = ra.z * rb.x - ra.w * ra.w;                   // conic determinant (> 0)
-            const float inv = 1.0f / det;
-            const float hx = sqrtf(t2 * rb.x * inv) * 1.001f + 0.01f;      // cov_xx = cc/det
-            const float hy = sqrtf(t2 * ra.z * inv) * 1.001f + 0.01f;      // cov_yy = ca/det
+            const float inv = gs2m_fast_rcp(det);
+            const float hx = gs2m_fast_sqrt(t2 * rb.x * inv) * 1.001f + 0.01f;      // cov_xx = cc/det
+            const float hy = gs2m_fast_sqrt(t2 * ra.z * inv) * 1.001f + 0.01f;      // cov_yy = ca/det
             const bool xl = ra.x - hx <= qx0 + 7.0f, xr = ra.x + hx >= qx0 + 8.0f;
             const bool box = op * 255.0f >= 0.9999f && det > 0.0f;
             const bool degenerate = !(det > 0.0f);  // no box: test every pixel of the tile rect

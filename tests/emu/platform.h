@@ -112,6 +112,7 @@ static inline T gs2m_shfl_up(T v, int d) {
 static inline float gs2m_fast_exp(float x) { return expf(x); }
 static inline float gs2m_fast_log(float x) { return logf(x); }
 static inline float gs2m_fast_rcp(float x) { return 1.0f / x; }
+static inline float gs2m_fast_sqrt(float x) { return sqrtf(x); }
 static inline float gs2m_fast_exp2(float x) { return exp2f(x); }
 static inline float gs2m_fast_log2(float x) { return log2f(x); }
 #define GS2M_KEEP_F32(x) ((void)0)
