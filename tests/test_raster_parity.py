@@ -334,6 +334,39 @@ def test_dense_lists_use_the_large_bucket_class(backend):
     assert_image_close(img, ref_img)
 
 
+@pytest.mark.parametrize("n", [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193])
+@pytest.mark.parametrize("ties", [False, True])
+def test_list_sizes_at_the_boundaries_of_the_sort_paths(backend, n, ties):
+    """One list of exactly n instances, n on both sides of every hand-over of the per-tile sort: register network of 1 / 2 /
+    4 / 8 keys per lane and the wave bucket sort (64, 128, 256, 512), size-class kernels (512 | 513, 4096 | 4097), run +
+    merge sort (8192 | 8193).  `ties`: depths from 9 values (long runs of equal depth: order by Gaussian id, the bucket
+    sort's overflow fallback).  The instance list equals the oracle's exactly."""
+    W, H, f = 48, 32, 60.0
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    rng = np.random.default_rng(1000 + n)
+    xyz = rng.normal(0, 0.004, (n, 3)).astype(np.float32)
+    xyz[:, 1] -= 0.53                                             # all in the tile above the centre
+    z = rng.uniform(-0.2, 0.2, n)
+    xyz[:, 2] = np.round(z * 20) / 20 if ties else z
+    xyz = xyz.astype(np.float32)
+    o = rng.uniform(0.02, 0.3, n).astype(np.float32)
+    cols = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    s = np.full((n, 3), 0.003, np.float32)
+    q = np.tile([1, 0, 0, 0], (n, 1)).astype(np.float32)
+    r, img, radii = run_forward(backend, cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    assert r.last_num_rendered == ref_n
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
+                                 cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+    sizes = (ref_ranges[:, 1] - ref_ranges[:, 0]).astype(np.int64)
+    assert sizes.max() == n and (sizes > 0).sum() == 1, sizes     # exactly one list, of exactly n instances
+    pl, ranges = r.download_binning(0, ref_n, 3 * 2)
+    np.testing.assert_array_equal(ranges, ref_ranges)
+    np.testing.assert_array_equal(pl, ref_pl)
+    assert_image_close(img, ref_img)
+
+
 @pytest.mark.parametrize("env", [{"GS2M_SORT_KEYS_PER_THREAD": "16", "GS2M_SORT_SMALL_WPB": "1"},
                                  {"GS2M_SORT_SMALL_WPB": "2", "GS2M_SORT_WAVE_BUCKET": "0"}])
 def test_sort_geometry_knobs_do_not_change_results(env):
