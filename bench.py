@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--bin-cus", default=os.environ.get("GS2M_BENCH_BIN_CUS", "all"), choices=["all", "rest", "blend", "own"],
                     help="with --blend-cus: binning chains on unmasked streams (all) or on the CUs the compositing leaves (rest)")
     ap.add_argument("--fuse-cus", default=os.environ.get("GS2M_BENCH_FUSE_CUS", "all"), choices=["all", "rest", "blend", "own"])
+    ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "2")), choices=[1, 2],
+                    help="2 (default) = two consecutive stereo pairs share every launch of the binning chain and the compositing "
+                         "(GS2M_OPT_PAIR_BATCH; same images and volume; C2 0.315 -> 0.305 ms per step); 1 = one pair per launch")
     ap.add_argument("--min-repeats", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -206,6 +209,13 @@ def main():
         # decreasing size (10, 5, 3, 2: only a small sweep after the last render) 0.356 vs 0.348 ms.
         n_sweeps = max(1, -(-K // 32))
         args.fuse_batch = max(1, -(-K // n_sweeps))
+    if args.pairs_per_launch > 1:
+        # two pairs per launch render into consecutive buffers of the pending sweep: even sweep sizes (an odd last view is
+        # flushed on its own); nothing to pair up in a one-view job or without the pipeline
+        if args.fuse_batch < 2 or args.inflight < 2 or K < 2:
+            args.pairs_per_launch = 1
+        else:
+            args.fuse_batch += args.fuse_batch % 2
     cfg = synthetic.CONFIGS[args.config]
     Wd, Ht = cfg.width, cfg.height
     cx, cy = Wd / 2.0, Ht / 2.0
@@ -239,11 +249,12 @@ def main():
                               exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows,
                               fuse_batch=(fuse_plan if fuse_plan and len(fuse_plan) > 1 else args.fuse_batch),
                               spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)),
-                              blend_cus=args.blend_cus, blend_streams=args.blend_streams, bin_cus=args.bin_cus, fuse_cus=args.fuse_cus)
+                              blend_cus=args.blend_cus, blend_streams=args.blend_streams, bin_cus=args.bin_cus, fuse_cus=args.fuse_cus,
+                              pairs_per_launch=(args.pairs_per_launch if args.inflight > 1 else 1))
     spatial_order_used = int(pipe.spatial_order)
     pipe_blend_cus = int(pipe.blend_cus)
     R = pipe.rasterizers[0]
-    color, rgb8 = pipe.color[0], pipe.rgb8[0]
+    color, rgb8 = pipe.color[0][:2], pipe._own8[0][:2]     # one pair's worth of slot 0's buffers: the serial / parity passes
 
     def step(i):
         pipe.submit(cams[i], depths[i], Es[i], depth_scale=1.0, depth_trunc=depth_trunc, min_depth=min_depth)
@@ -531,7 +542,7 @@ def main():
             config=dict(workload=f"{args.config}: {cfg.P} synth_v1 Gaussians (SH deg 3), {K} stereo pairs/GPU at "
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
-                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight,
+                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight, pairs_per_launch=int(pipe.ppl),
                         tsdf_fuse_batch=(fuse_plan if fuse_plan else args.fuse_batch), cu_partition=dict(blend_cus=pipe_blend_cus, blend_streams=args.blend_streams,
                                                                            bin_cus=args.bin_cus, fuse_cus=args.fuse_cus),
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),

@@ -37,6 +37,7 @@ OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
 OPT_BLEND_WG_PER_CU = 6
 OPT_BLEND_JOIN = 7
+OPT_PAIR_BATCH = 8
 XFORM_SUM_F32, XFORM_RAW_F32, XFORM_SUM_PACKED = 0, 1, 2
 XFORM_PACKED_MAX_FRAMES = 1023
 OPT_DEBUG_SYNC = 3

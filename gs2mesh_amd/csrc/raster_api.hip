@@ -39,7 +39,7 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_blend_wg_per_cu = 0, opt_blend_join = 1;
+    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_blend_wg_per_cu = 0, opt_blend_join = 1, opt_pair_batch = 0;
     bool blend_pending = false;   // a compositing launch sits on blend_stream and the call's stream has not waited for it
     struct EvPair {
         int stage;
@@ -47,7 +47,7 @@ struct gs2m_raster {
     };
     std::vector<EvPair> ev_live;        // recorded, not yet read
     std::vector<hipEvent_t> ev_free;    // recycled events
-    CamUniform* d_cams = nullptr;  // [GS2M_MAX_VIEWS]
+    CamUniform* d_cams = nullptr;  // [GS2M_MAX_PASS_VIEWS]
     GeomRec* d_recs = nullptr;
     size_t recs_cap = 0;  // records
     unsigned long long* d_tilemask = nullptr;
@@ -117,7 +117,7 @@ extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
     HIPCHK(hipSetDevice(device));
     gs2m_raster* r = new gs2m_raster();
     r->device = device;
-    if (hipMalloc((void**)&r->d_cams, sizeof(CamUniform) * GS2M_MAX_VIEWS) != hipSuccess ||
+    if (hipMalloc((void**)&r->d_cams, sizeof(CamUniform) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
         hipMalloc((void**)&r->d_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
         hipHostMalloc((void**)&r->h_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
         hipMemset(r->d_status, 0, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess) {
@@ -190,6 +190,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             r->opt_blend_wg_per_cu = value;
             return 0;
         case GS2M_OPT_BLEND_JOIN: r->opt_blend_join = value != 0; return 0;
+        case GS2M_OPT_PAIR_BATCH: r->opt_pair_batch = value != 0; return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
         case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
@@ -254,7 +255,7 @@ static int binning_tiles(const gs2m_raster* r, int W, int H) {
     return gx * ((gy + r->opt_tile_rows - 1) / r->opt_tile_rows);
 }
 
-static void geometry(int P, int* chunk, int* n_wg) {
+static void geometry(int P, int* chunk, int* n_wg, int pairs = 1) {
     // ~256 workgroups (one per CU: the per-workgroup tile histogram rows / cursors scale with their number;
     // measured optimum on C2/C3), chunks a multiple of 256 Gaussians
     static int target = 0;
@@ -263,7 +264,10 @@ static void geometry(int P, int* chunk, int* n_wg) {
         target = e ? atoi(e) : 256;
         if (target < 1) target = 256;
     }
-    int c = (P + target - 1) / target;
+    // `pairs` groups of views share a launch (blockIdx.y): the workgroups of a group are target / pairs, the launch still
+    // fills the chip, and what a workgroup pays once (LDS clear, its histogram row, cursor set-up) is paid half as often
+    const int tgt = target / pairs > 0 ? target / pairs : 1;
+    int c = (P + tgt - 1) / tgt;
     c = (c + 255) / 256 * 256;
     if (c < 256) c = 256;
     if (c > 64000) c = 64000;  // k_count_tiles keeps 16-bit per-tile counters per workgroup (chunk + one sub-chunk < 65536)
@@ -278,7 +282,7 @@ extern "C" int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, in
         return 1;
     }
     HIPCHK(hipSetDevice(r->device));
-    const int nv = n_views < GS2M_MAX_VIEWS ? (n_views < 1 ? 1 : n_views) : GS2M_MAX_VIEWS;
+    const int nv = n_views < GS2M_MAX_PASS_VIEWS ? (n_views < 1 ? 1 : n_views) : GS2M_MAX_PASS_VIEWS;
     const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
     int chunk, n_wg;
     geometry(P, &chunk, &n_wg);
@@ -345,14 +349,17 @@ struct StageTimer {  // RAII: a rocTX range (GS2M_ROCTX=1) and, when timing is o
     }
 };
 
-// One fused pass over nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams.
-static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, float* out_color,
+// One fused pass over `pairs` groups of nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams.
+// A group is what one projection / counting / scatter workgroup handles (a stereo pair: parameters and Sigma once for both
+// eyes); with pairs = 2 (GS2M_OPT_PAIR_BATCH) two groups share every launch (blockIdx.y), each with half the workgroups.
+static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W, int H, float* out_color,
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
+    const int nvt = nv * pairs;   // views of the pass: the scans, the per-tile sort and the compositing take them all (grid.y)
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
     const int gys = (gy + r->opt_tile_rows - 1) / r->opt_tile_rows;  // binning rows (tiles of 16 x 16*rows pixels)
     const int tiles = gx * gys;
     int chunk, n_wg;
-    geometry(g.P, &chunk, &n_wg);
+    geometry(g.P, &chunk, &n_wg, pairs);
     // threads per counting / scatter workgroup: the chunk (<= 1024), halved until the wave staging fits next to the
     // tile cursors in the 160 KiB LDS (large images)
     int wg_threads = (gs2m_count_threads(chunk) + 63) / 64 * 64;
@@ -370,7 +377,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
         if (guess < 65536) guess = 65536;
         r->inst_cap = (unsigned)(guess > 0xfffffff0ll ? 0xfffffff0ll : guess);
     }
-    if (gs2m_raster_reserve(r, g.P, nv, W, H, 0)) return 1;
+    if (gs2m_raster_reserve(r, g.P, nvt, W, H, 0)) return 1;
     const unsigned cap = r->inst_cap;
     const int cull_arg_p = r->opt_exact_cull, cull_arg_s = r->opt_exact_cull;  // same option for counting and scatter
     // (round 3: projection and counting fused into one kernel -- the counting workgroups projecting their own Gaussians and
@@ -378,29 +385,29 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     // its own LDS atomics and tile tests, not by re-reading the records; 128 VGPRs for 1024-thread workgroups.  Not kept.)
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
-        gs2m_launch_project(nv, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p);
+        gs2m_launch_project(nv, pairs, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p);
     }
     if (dbg_check(r, st, "project")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_COUNT);
-        if (gs2m_launch_count_tiles(nv, n_wg, wg_threads, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
+        if (gs2m_launch_count_tiles(nv, pairs, n_wg, wg_threads, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
                                     cull_arg_p, g.ids != nullptr))
             return 1;
     }
     if (dbg_check(r, st, "count_tiles")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_COLSCAN);
-        gs2m_launch_hist_colscan(st, nv, r->d_hist, n_wg, tiles, r->d_tile_count);
+        gs2m_launch_hist_colscan(st, nvt, r->d_hist, n_wg, tiles, r->d_tile_count);
     }
     if (dbg_check(r, st, "hist_colscan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
-        gs2m_launch_tile_scan(st, nv, r->d_tile_count, r->d_tile_start, tiles, gx, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
+        gs2m_launch_tile_scan(st, nvt, r->d_tile_count, r->d_tile_start, tiles, gx, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
     }
     if (dbg_check(r, st, "tile_scan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
-        if (gs2m_launch_scatter(nv, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
+        if (gs2m_launch_scatter(nv, pairs, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
                                 r->d_tilemask, r->d_keys, cap, cull_arg_s, g.ids, g.ids != nullptr))
             return 1;
     }
@@ -410,17 +417,17 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
         // class-grid hint: what the previous call on this handle (same image size and binning) found, as far as its status
         // copy has landed in the pinned mirror; -1 = no information (first call, other geometry)
         int hint[3] = {-1, -1, -1};
-        if (r->hint_valid && r->last_tiles == tiles && r->last_nv == nv) {
+        if (r->hint_valid && r->last_tiles == tiles && r->last_nv == nvt) {
             for (int c = 0; c < 3; ++c) {
                 unsigned m = 0;
-                for (int v = 0; v < nv; ++v) {
+                for (int v = 0; v < nvt; ++v) {
                     const unsigned x = r->h_status[1 + status_slot + v].n_class[c];
                     m = x > m ? x : m;
                 }
                 hint[c] = m > 0x3fffffffu ? -1 : (int)m;
             }
         }
-        gs2m_launch_sort_tiles(st, nv, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists, hint);
+        gs2m_launch_sort_tiles(st, nvt, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists, hint);
     }
     if (dbg_check(r, st, "sort_tiles")) return 1;
     // compositing on its own stream (gs2m_raster_set_blend_stream): binned -> [blend stream] -> blended -> back on `st`, so
@@ -434,9 +441,9 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     r->blend_pending = false;
     {
         StageTimer tm(r, bs, GS2M_STAGE_BLEND);
-        if (gs2m_launch_blend(bs, r->opt_blend, r->opt_tile_rows, nv, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
+        if (gs2m_launch_blend(bs, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
                               g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
-                              r->d_sort_lists + (size_t)nv * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_wg_per_cu))
+                              r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_wg_per_cu))
             return 1;
     }
     if (bs != st) {
@@ -450,7 +457,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int W, int H, flo
     r->last_P = g.P;
     r->hint_valid = true;
     r->last_packed = g.ids != nullptr;
-    r->last_nv = nv;
+    r->last_nv = nvt;
     r->last_tiles = tiles;
     r->last_cap = cap;
     return 0;
@@ -525,7 +532,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     if (debug) r->opt_debug = 1;
     gs2m_launch_pack_camera(st, r->d_cams, 0, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy,
                             width, height, 16 * r->opt_tile_rows);
-    int rc = run_views(r, g, 1, width, height, out_color, nullptr, radii, 0, st);
+    int rc = run_views(r, g, 1, 1, width, height, out_color, nullptr, radii, 0, st);
     r->opt_debug = saved_debug;
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * 2, hipMemcpyDeviceToHost, st));
@@ -613,10 +620,13 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     // views fused per pass: as many (<= GS2M_MAX_VIEWS) as the LDS tile cursors of the scatter allow
     int per = GS2M_MAX_VIEWS;
     while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 64) > 160 * 1024) per--;
-    for (int v0 = 0; v0 < n_views; v0 += per) {
+    for (int v0 = 0; v0 < n_views;) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
-        CamUniform cu[GS2M_MAX_VIEWS];
-        for (int k = 0; k < nv; ++k) {
+        // GS2M_OPT_PAIR_BATCH: two full groups (stereo pairs) per pass when the call has them
+        const int pairs = (r->opt_pair_batch && per == GS2M_MAX_VIEWS && n_views - v0 >= GS2M_MAX_PAIRS * per) ? GS2M_MAX_PAIRS : 1;
+        const int nvt = nv * pairs;
+        CamUniform cu[GS2M_MAX_PASS_VIEWS];
+        for (int k = 0; k < nvt; ++k) {
             const gs2m_camera& c = cams[v0 + k];
             CamUniform& u = cu[k];
             memcpy(u.view, c.viewmatrix, sizeof(u.view));
@@ -635,11 +645,12 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
             u.bg[2] = bg[2];
             u.th = 16 * r->opt_tile_rows;
         }
-        gs2m_launch_set_cameras(st, r->d_cams, nv, cu);  // one launch for the views of the pass
-        if (run_views(r, g, nv, W, H, out_color ? out_color + 3 * img * v0 : nullptr,
+        gs2m_launch_set_cameras(st, r->d_cams, nvt, cu);  // one launch for the views of the pass
+        if (run_views(r, g, nv, pairs, W, H, out_color ? out_color + 3 * img * v0 : nullptr,
                       out_rgb8 ? out_rgb8 + 3 * img * v0 : nullptr,
                       out_radii ? out_radii + (size_t)gs->P * v0 : nullptr, v0, st))
             return 1;
+        v0 += nvt;
     }
     HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * (n_views + 1), hipMemcpyDeviceToHost, st));
     return 0;

@@ -8,14 +8,14 @@
 struct CamUniformArg;
 
 size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads);
-void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
+void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
                          int exact_cull);
-int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull, int interleave);
 int gs2m_count_threads(int chunk);
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads);
-int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
                         const int* ids, int interleave);

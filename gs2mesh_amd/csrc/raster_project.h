@@ -335,6 +335,10 @@ GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // forcing 5 waves pe
 k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
           int exact_cull) {
     __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
+    // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH: two stereo pairs per launch)
+    cams += NV * blockIdx.y;
+    recs += (size_t)NV * blockIdx.y * g.P;
+    if (radii) radii += (size_t)NV * blockIdx.y * g.P;
     const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
     const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
     ProjView pv[NV];
@@ -493,6 +497,11 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     const int lane = tid & 63, wave = tid >> 6;
     const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
+    // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH): its own records, masks and histogram rows
+    cams += NV * blockIdx.y;
+    recs += (size_t)NV * blockIdx.y * P;
+    tilemask += (size_t)NV * blockIdx.y * P;
+    hist += (size_t)NV * blockIdx.y * n_wg * tiles;
     // workgroup-private tile histogram, two 16-bit counters per word (a workgroup owns `chunk` <= 65535
     // Gaussians and a Gaussian counts at most once per tile): half the LDS -> twice the resident waves
     const int nthreads = (int)blockDim.x;
@@ -588,6 +597,13 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
     const int nthreads = (int)blockDim.x;
     const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
+    // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH)
+    cams += NV * blockIdx.y;
+    recs += (size_t)NV * blockIdx.y * P;
+    tilemask += (size_t)NV * blockIdx.y * P;
+    hist += (size_t)NV * blockIdx.y * n_wg * tiles;
+    tile_start += (size_t)NV * blockIdx.y * (tiles + 1);
+    keys += (size_t)NV * blockIdx.y * cap;
     // Chunk (= histogram row = position of this workgroup's segment inside every tile's key range).  The workgroups of
     // one XCD own consecutive rows, so the segments an XCD writes into a tile are adjacent: its 8-B key stores fill
     // whole lines in ITS L2 instead of leaving 1/8-written lines in eight L2s (4x write amplification, PMC WRITE_SIZE).
@@ -820,7 +836,7 @@ GS2M_KERNEL void k_pack_camera(CamUniform* cams, int slot, const float* viewmatr
 // Same from HOST values carried in the kernel arguments (pipeline-level API): the launch
 // packet is the transport, so no pinned staging buffer / lifetime hazard.
 struct CamUniformArg {
-    CamUniform c[GS2M_MAX_VIEWS];
+    CamUniform c[GS2M_MAX_PASS_VIEWS];
 };
 GS2M_KERNEL void k_set_cameras(CamUniform* cams, int n, CamUniformArg a) {
     if ((int)threadIdx.x < n) cams[threadIdx.x] = a.c[threadIdx.x];

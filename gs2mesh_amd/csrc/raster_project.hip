@@ -17,10 +17,11 @@ size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads) {
     return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_SCATTER_STAGE_BYTES_PER_WAVE;
 }
 
-void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
+void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
                          int exact_cull) {
-    const unsigned n = (unsigned)((g.P + 255) / 256);
-    if (n == 0) return;
+    const unsigned nx = (unsigned)((g.P + 255) / 256);
+    if (nx == 0) return;
+    const dim3 n(nx, (unsigned)pairs);   // blockIdx.y = group of nv views (GS2M_OPT_PAIR_BATCH)
     // SH rows through LDS (k_project<.., true>): with the spatially ordered packed model (large models, where (almost) every
     // Gaussian is visible: C3 148 -> 136 us); a model that only has the packed SH copy keeps the register path, which reads
     // no row of a culled Gaussian and runs 16 instead of 12 waves per CU (C2: 28 vs 30 us)
@@ -29,15 +30,15 @@ void gs2m_launch_project(int nv, hipStream_t st, const GaussIn& g, const CamUnif
     // the colour pass streams the SH row three float4 at a time where the row is 16-B aligned (packed copy, [P,16,3]) or not
     // needed (precomputed colours); dc + rest split layouts / M != 16 keep the 48-register path (k_project<.., .., false>)
     const bool stream = g.colors_precomp != nullptr || g.shs_packed != nullptr || (g.shs_rest == nullptr && g.M == 16);
-    if (nv == 2 && dma) GS2M_LAUNCH((k_project<2, true>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (nv == 2 && stream) GS2M_LAUNCH((k_project<2, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (nv == 2) GS2M_LAUNCH((k_project<2, false, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (dma) GS2M_LAUNCH((k_project<1, true>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (stream) GS2M_LAUNCH((k_project<1, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else GS2M_LAUNCH((k_project<1, false, false>), dim3(n), dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    if (nv == 2 && dma) GS2M_LAUNCH((k_project<2, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (nv == 2 && stream) GS2M_LAUNCH((k_project<2, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (nv == 2) GS2M_LAUNCH((k_project<2, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (dma) GS2M_LAUNCH((k_project<1, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else if (stream) GS2M_LAUNCH((k_project<1, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    else GS2M_LAUNCH((k_project<1, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
 }
 
-int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull, int interleave) {
     if (lds_bytes > 64 * 1024) {
@@ -51,15 +52,15 @@ int gs2m_launch_count_tiles(int nv, int n_wg, int threads, size_t lds_bytes, hip
         }
     }
     if (nv == 2)
-        GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
+        GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
                     exact_cull, interleave);
     else
-        GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
+        GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
                     exact_cull, interleave);
     return 0;
 }
 
-int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
                         const int* ids, int interleave) {
@@ -74,10 +75,10 @@ int gs2m_launch_scatter(int nv, int n_wg, int threads, size_t lds_bytes, hipStre
         }
     }
     if (nv == 2)
-        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+        GS2M_LAUNCH((k_scatter<2>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
                     tile_start, tilemask, keys, cap, exact_cull, ids, interleave);
     else
-        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
+        GS2M_LAUNCH((k_scatter<1>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
                     tile_start, tilemask, keys, cap, exact_cull, ids, interleave);
     return 0;
 }
@@ -109,6 +110,6 @@ void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const f
 
 void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamUniform* c) {
     CamUniformArg a;
-    for (int k = 0; k < GS2M_MAX_VIEWS; ++k) a.c[k] = c[k < n ? k : 0];
+    for (int k = 0; k < GS2M_MAX_PASS_VIEWS; ++k) a.c[k] = c[k < n ? k : 0];
     GS2M_LAUNCH(k_set_cameras, dim3(1), dim3(64), 0, st, cams, n, a);
 }

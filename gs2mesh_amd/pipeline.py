@@ -30,7 +30,7 @@ class RenderFusePipeline:
                  exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
                  lib=None, fuse_batch: int = 1, spatial_order="auto", blend_cus: int = 0, blend_streams: int = 2,
                  bin_cus: str = "all", fuse_cus: str = "all", blend_wg_per_cu: int = 0, blend_stream_plain: bool = False,
-                 layout: str = "per_slot", bin_streams: int = 1):
+                 layout: str = "per_slot", bin_streams: int = 1, pairs_per_launch: int = 1):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
@@ -44,6 +44,12 @@ class RenderFusePipeline:
         self.W, self.H = int(width), int(height)
         self.volume, self.intrinsic = volume, intrinsic
         self.inflight = int(inflight)
+        # pairs_per_launch = 2 (GS2M_OPT_PAIR_BATCH): two consecutive stereo pairs go through ONE chain of launches (`submit`
+        # buffers the first, the second triggers the launch; `drain` flushes an odd one).  Batched fusion only.
+        self.ppl = int(pairs_per_launch) if self.inflight > 1 else 1
+        if self.ppl not in (1, 2):
+            raise ValueError("pairs_per_launch must be 1 or 2")
+        self._group = []
         self.device = int(device)
         self.bg = bg
         dev = torch.device(f"cuda:{device}")
@@ -56,10 +62,12 @@ class RenderFusePipeline:
                 r.set_option(_lib.OPT_BLEND_VARIANT, int(blend_variant))
             if blend_wg_per_cu:
                 r.set_option(_lib.OPT_BLEND_WG_PER_CU, int(blend_wg_per_cu))
+            if self.ppl > 1:
+                r.set_option(_lib.OPT_PAIR_BATCH, 1)
             self.rasterizers.append(r)
-            self.color.append(torch.empty((2, 3, self.H, self.W), dtype=torch.float32, device=dev))
+            self.color.append(torch.empty((2 * self.ppl, 3, self.H, self.W), dtype=torch.float32, device=dev))
             # rgb8[j] = where slot j's latest u8 pair lives (the slot's own buffer, or the pending view's batch buffer)
-            self._own8.append(torch.empty((2, self.H, self.W, 3), dtype=torch.uint8, device=dev))
+            self._own8.append(torch.empty((2 * self.ppl, self.H, self.W, 3), dtype=torch.uint8, device=dev))
             self.rgb8.append(self._own8[j])
         self._masked = []
         self.blend_cus = 0
@@ -127,7 +135,11 @@ class RenderFusePipeline:
         # two sets of image buffers: batch b + 1 is collected while batch b is still being integrated
         # (the u8 pair of a pending view is rendered straight into its buffer: no copy out of the slot)
         nb = self.fuse_batch if self.fuse_batch > 1 else 0
-        self._bpair = [[torch.empty((2, self.H, self.W, 3), dtype=torch.uint8, device=dev) for _ in range(nb)] for _ in range(2)]
+        # one flat buffer per set: the pairs of consecutive pending views are contiguous (pairs_per_launch = 2 renders two at once)
+        self._bflat = [torch.empty((2 * nb, self.H, self.W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._bpair = [[self._bflat[b][2 * k:2 * k + 2] for k in range(nb)] for b in range(2)]
+        if self.ppl > 1 and (self.fuse_batch < 2 or any(b % self.ppl for b in self._plan)):
+            raise ValueError("pairs_per_launch = 2 needs batched fusion with even sweep sizes (fuse_batch)")
         self._bcopied = [[torch.cuda.Event() for _ in range(nb)] for _ in range(2)]
         self._batch_done = [None, None]
         self._bset = 0
@@ -171,6 +183,14 @@ class RenderFusePipeline:
         """Enqueue: render the stereo pair ``cams`` and (if ``depth`` is given) integrate the LEFT image with
         ``depth`` [H,W] f32 (device) under ``extrinsic`` (world -> camera, 4x4).  Returns the slot index whose
         ``color[slot]`` / ``rgb8[slot]`` will hold the pair (valid after `wait_rendered(slot)` / `finish`)."""
+        if self.ppl > 1:
+            if depth is None:
+                raise ValueError("pairs_per_launch = 2: every view is fused (depth required)")
+            self._group.append((cams, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
+            j = self._n % self.inflight
+            if len(self._group) == self.ppl:
+                self._launch_group()
+            return j
         j = self._n % self.inflight
         self._n += 1
         r = self.rasterizers[j]
@@ -245,6 +265,41 @@ class RenderFusePipeline:
                 self._fused_on[j] = fs
         return j
 
+    def _launch_group(self):
+        """pairs_per_launch = 2: the buffered views (2, or 1 when `drain` flushes an odd one) through one chain of launches
+        on the next slot; their u8 pairs go straight into consecutive buffers of the pending batch."""
+        views, self._group = self._group, []
+        n = len(views)
+        j = self._n % self.inflight
+        self._n += 1
+        r = self.rasterizers[j]
+        cur = torch.cuda.current_stream(self.device)
+        rs = self.render_streams[j]
+        if not self._model_seen[j]:
+            rs.wait_stream(cur)
+            self._model_seen[j] = True
+        k0 = len(self._pending)
+        with torch.cuda.stream(rs):
+            if self._fused_on[j] is not rs:
+                rs.wait_event(self._fused[j])
+            if self._batch_done[self._bset] is not None:
+                rs.wait_event(self._batch_done[self._bset])
+            self.rgb8[j] = self._bflat[self._bset][2 * k0:2 * (k0 + n)]
+            r.render_views(self.g, [c for v in views for c in v[0]], bg=self.bg, out_color=self.color[j][:2 * n],
+                           out_rgb8=self.rgb8[j], sync=False)
+            self._rendered[j].record(rs)
+            for i in range(n):
+                self._bcopied[self._bset][k0 + i].record(rs)
+        for i, (_, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth) in enumerate(views):
+            for t in (depth, mask):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self.fuse_stream)
+            self._pending.append((k0 + i, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
+        self._fused[j].record(rs)
+        self._fused_on[j] = rs
+        if len(self._pending) >= self._plan[self._plan_i % len(self._plan)]:
+            self._flush_batch(cur)
+
     def _flush_batch(self, cur=None):
         """Integrate the pending views (in submission order) with one batch sweep."""
         if not self._pending:
@@ -282,6 +337,8 @@ class RenderFusePipeline:
     def drain(self):
         """Host waits for everything submitted so far (render + fuse streams; a partial batch is integrated first); no
         status query, no device-wide sync.  The batch plan starts over."""
+        if self._group:
+            self._launch_group()
         self._flush_batch(torch.cuda.current_stream(self.device) if self.inflight > 1 else None)
         self._plan_i = 0
         if self.inflight > 1:

@@ -83,6 +83,10 @@ enum {
     GS2M_OPT_BLEND_JOIN = 7,      /* with a compositing stream set: 1 (default) = the call's stream waits for the compositing
                                      before the call returns to it (everything ordered on the stream the caller passed);
                                      0 = it does not -- gs2m_raster_join orders a stream behind the handle's compositing.   */
+    GS2M_OPT_PAIR_BATCH = 8,      /* gs2m_render_views with >= 4 views: 1 = two stereo pairs share every launch (the projection /
+                                     counting / scatter workgroups of a pair are half as many, blockIdx.y picks the pair; scans,
+                                     per-tile sort and compositing take the four views in one grid): the per-launch and
+                                     per-workgroup fixed costs are paid once for two pairs.  Same results.  Default 0. */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and

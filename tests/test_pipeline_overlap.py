@@ -66,6 +66,56 @@ def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("n_views,fuse_batch", [(6, 6), (7, 4), (6, [4, 2])])
+def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch):
+    """RenderFusePipeline(pairs_per_launch=2): two consecutive stereo pairs per chain of launches (GS2M_OPT_PAIR_BATCH),
+    their u8 pairs rendered into consecutive buffers of the pending TSDF batch; an odd last view is flushed by `finish`.
+    Images and volume are bit-identical to the serial order."""
+    import torch
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    from gs2mesh_amd.rasterizer import camera_from
+    ref = _run(1, n_views=n_views)
+    cfg = synthetic.CONFIGS["C1"]
+    dev = torch.device("cuda:0")
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+    gd["raw"] = True
+    W, H = cfg.width, cfg.height
+    poses = synthetic.ring_poses(n_views, cfg.ring_radius, 0, n_views)
+    intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
+    vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=3, device=0, fuse_batch=fuse_batch, pairs_per_launch=2)
+    cams, depths, Es = [], [], []
+    for p in poses:
+        l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
+        cams.append([camera_from(l), camera_from(r)])
+        depths.append(synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2, H / 2, cfg.sphere_radius, dev))
+        E = np.eye(4)
+        E[:3] = p
+        Es.append(E)
+    pipe.prepare(cams[0])
+    images = []
+    for i in range(n_views):
+        slot = pipe.submit(cams[i], depths[i], Es[i], depth_trunc=cfg.baseline * 20, min_depth=cfg.baseline * 4)
+        if i % 2 == 1:                                     # the group of views i - 1, i has been launched on `slot`
+            pipe.wait_rendered(slot)
+            c, u = pipe.color[slot].cpu().numpy(), pipe.rgb8[slot].cpu().numpy()
+            images += [(c[0:2].copy(), u[0:2].copy()), (c[2:4].copy(), u[2:4].copy())]
+    pipe.finish()                                          # flushes an odd last view
+    if n_views % 2:
+        c, u = pipe.color[slot].cpu().numpy(), pipe.rgb8[slot].cpu().numpy()
+        images.append((c[0:2].copy(), u[0:2].copy()))
+    keys, tsdf, weight, rgb = vol.download()
+    pipe.close()
+    order = np.lexsort(keys.T[::-1])
+    for (c0, u0), (c1, u1) in zip(ref[0], images):
+        assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
+    assert len(images) == n_views
+    for a, b in zip(ref[1:], (keys[order], tsdf[order], weight[order], rgb[order])):
+        assert np.array_equal(a, b)
+
+
 def test_model_updated_orders_the_render_streams_after_the_callers_stream():
     """The render streams wait for the caller's stream once per slot, not per step (pipeline.py): a model changed in place on
     the caller's stream needs `model_updated()` -- packed copies dropped, every render stream re-armed -- and the next renders

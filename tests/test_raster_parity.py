@@ -382,6 +382,52 @@ def test_sort_geometry_knobs_do_not_change_results(env):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("rows,cull,packed,n_views", [(1, 0, False, 4), (2, 1, False, 4), (2, 1, True, 4), (2, 1, False, 5), (2, 1, False, 6)])
+def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, rows, cull, packed, n_views):
+    """GS2M_OPT_PAIR_BATCH: the projection / counting / scatter kernels take two stereo pairs per launch (blockIdx.y picks
+    the pair, half the workgroups per pair), scans / per-tile sort / compositing the four views in one grid.  Everything a
+    call returns or leaves behind is identical to one pair per launch: images, u8 images, radii, instance counts, and --
+    per view -- the projected records and the instance lists.  5 views: one batched pass + one single view; 6: a batched
+    pass + a plain pair."""
+    W, H, f = 176, 112, 150.0
+    g, s, q, o, shs, left, right = scene(2600, 33, W, H, f, log_s=math.log(0.05))
+    *_rest, left2, right2 = scene(10, 34, W, H, f, az=0.9)       # a second pair of cameras
+    be = backend
+    P = g["xyz"].shape[0]
+    cams = [camera_from(c) for c in (left, right, left2, right2, right, left2)][:n_views]
+    gd = dict(xyz=be.dev(g["xyz"]), scaling=be.dev(g["scaling"]), rotation=be.dev(g["rotation"]),
+              opacity=be.dev(g["opacity"]), features_dc=be.dev(g["features_dc"]), features_rest=be.dev(g["features_rest"]),
+              raw=True, sh_degree=3)
+    tiles = ((W + 15) // 16) * (((H + 15) // 16 + rows - 1) // rows)
+    outs = []
+    for batch in (0, 1):
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+        r.set_option(_lib.OPT_TILE_ROWS, rows)
+        r.set_option(_lib.OPT_PAIR_BATCH, batch)
+        if packed:
+            r.pack_model(gd)
+        for rep in range(2):          # second call: class hints of the sort come from the first
+            res = r.render_views(gd, cams, want_radii=True, want_rgb8=True)
+        nr = list(res["num_rendered"])
+        outs.append((be.host(res["color"]).copy(), be.host(res["rgb8"]).copy(), be.host(res["radii"]).copy(), nr, r))
+    a, b = outs
+    assert a[3] == b[3] and min(a[3]) > 1000
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    if n_views == 4:
+        # one pair per launch leaves views 2, 3 in the arenas (as views 0, 1 of its last pass); two pairs per launch all four
+        ra, rb = a[4], b[4]
+        for v in range(2):
+            ga, gb = ra.download_geometry(v, P), rb.download_geometry(2 + v, P)
+            for k in ga:
+                np.testing.assert_array_equal(ga[k], gb[k], err_msg=k)
+            la, lb = ra.download_binning(v, a[3][2 + v], tiles), rb.download_binning(2 + v, b[3][2 + v], tiles)
+            np.testing.assert_array_equal(la[0], lb[0])
+            np.testing.assert_array_equal(la[1], lb[1])
+
+
 def test_arena_overflow_is_detected_and_retried(backend):
     W, H, f = 96, 80, 90.0
     g, s, q, o, shs, left, _ = scene(2000, 8, W, H, f, log_s=math.log(0.08))
