@@ -253,6 +253,7 @@ def main():
                               pairs_per_launch=(args.pairs_per_launch if args.inflight > 1 else 1))
     spatial_order_used = int(pipe.spatial_order)
     pipe_blend_cus = int(pipe.blend_cus)
+    pairs_per_launch_used = int(pipe.ppl)     # (the pipeline object is gone by the time the line is assembled)
     R = pipe.rasterizers[0]
     color, rgb8 = pipe.color[0][:2], pipe._own8[0][:2]     # one pair's worth of slot 0's buffers: the serial / parity passes
 
@@ -542,7 +543,7 @@ def main():
             config=dict(workload=f"{args.config}: {cfg.P} synth_v1 Gaussians (SH deg 3), {K} stereo pairs/GPU at "
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
-                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight, pairs_per_launch=int(pipe.ppl),
+                        exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight, pairs_per_launch=pairs_per_launch_used,
                         tsdf_fuse_batch=(fuse_plan if fuse_plan else args.fuse_batch), cu_partition=dict(blend_cus=pipe_blend_cus, blend_streams=args.blend_streams,
                                                                            bin_cus=args.bin_cus, fuse_cus=args.fuse_cus),
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
