@@ -64,6 +64,18 @@ def single_process_reference(with_mesh=False, n_frames=5):
     return vol.download()
 
 
+
+def assert_same_triangles(got, ref, atol=2e-6):
+    """The sharded tsdf differs from the single-process one by the order of the sums (<= 1e-5), so the triangles [n,3,3] are
+    matched by nearest neighbour in the 9-D space of their three vertices (emission order of the vertices is the same on both
+    sides; a sort on rounded coordinates is not stable against that noise): the match must be a bijection and every vertex
+    within `atol`."""
+    from scipy.spatial import cKDTree
+    a, b = got.reshape(len(got), 9), ref.reshape(len(ref), 9)
+    _, nn = cKDTree(b).query(a, k=1)
+    assert len(np.unique(nn)) == len(b)
+    np.testing.assert_allclose(a, b[nn], atol=atol, rtol=0)
+
 @pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "reduce_scatter"), (3, "allreduce"),
                                         (2, "reduce_scatter:f32"), (3, "reduce_scatter:packed:direct"),
                                         (2, "reduce_scatter:f32:direct"), (2, "allreduce:f32")])
@@ -114,14 +126,7 @@ def test_eight_ranks_reduce_scatter_direct_and_owner_side_mesh(tmp_path):
     assert owned_all == set(ref)
     got = np.concatenate(parts, axis=0)
     assert got.shape == tri_ref.shape and len(got) > 1000
-    # the sharded tsdf differs from the single-process one by the order of the sums (<= 1e-5): the triangles are matched by
-    # nearest neighbour in the 9-D space of their three vertices (emission order of the vertices is the same on both sides);
-    # the match must be a bijection and every vertex within 2e-6
-    from scipy.spatial import cKDTree
-    a, b = got.reshape(len(got), 9), tri_ref.reshape(len(tri_ref), 9)
-    dist, nn = cKDTree(b).query(a, k=1)
-    assert len(np.unique(nn)) == len(b)
-    np.testing.assert_allclose(a, b[nn], atol=2e-6, rtol=0)
+    assert_same_triangles(got, tri_ref)
 
 
 def test_halo_copies_are_not_exchanged_twice(tmp_path):
@@ -160,8 +165,4 @@ def test_owner_side_mesh_extraction_with_halo_blocks(tmp_path, world):
     got = np.concatenate(parts, axis=0)
     assert got.shape == tri_ref.shape and len(got) > 1000
 
-    def canon(t):      # order-independent: sort triangles by their (rounded) centroid + first vertex
-        key = np.round(np.concatenate([t.mean(axis=1), t[:, 0]], axis=1) * 1e5).astype(np.int64)
-        return t[np.lexsort(key.T[::-1])]
-
-    np.testing.assert_allclose(canon(got), canon(tri_ref), atol=2e-6, rtol=0)
+    assert_same_triangles(got, tri_ref)
