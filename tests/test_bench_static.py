@@ -1,0 +1,41 @@
+"""Static checks of bench.py that run without a GPU.  The driver's command is the one run nobody re-checks by hand: a name
+released with `del` and read again further down (round 3: the pipeline object, read while assembling the JSON line) only shows
+up at the very end of a several-minute GPU run."""
+import ast
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _functions(tree):
+    return [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef))]
+
+
+def test_no_name_is_read_after_it_was_deleted():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    problems = []
+    for fn in _functions(tree):
+        deleted = {}      # name -> line of the `del`
+        events = []
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Name):
+                events.append((node.lineno, node.col_offset, type(node.ctx).__name__, node.id))
+        for line, col, ctx, name in sorted(events):
+            if ctx == "Del":
+                deleted[name] = line
+            elif ctx == "Store":
+                deleted.pop(name, None)
+            elif ctx == "Load" and name in deleted and line > deleted[name]:
+                problems.append(f"{fn.name}: `{name}` deleted at line {deleted[name]}, read at line {line}")
+    assert not problems, "\n".join(problems)
+
+
+def test_the_json_line_carries_the_contract_fields():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("metric=", "value=", "unit=", "n_gpus=", "steps=", "warmup=", "ms_per_step=", "higher_is_better=", "scaling=",
+                "vs_baseline=", "dtype=", "data=", "config=", "roofline=", "cpu_baseline="):
+        assert key in src, key
+    # roofline / cpu_baseline objects: the fields the contract names
+    for key in ("bound=", "achieved=", "peak=", "frac=", "traffic=", "cores=", "kind=", "sample="):
+        assert key in src, key
