@@ -555,8 +555,9 @@ def main():
             tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, parity=par, cpu_baseline=cpu,
             c3=c3, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
             note_stages="`stages` / `roofline` / `instrumented_ms_per_step`: second pass, serial on one stream with hipEvents "
-                        "around every launch (kernels in isolation); `value`: timed pass with `pairs_in_flight` pairs "
-                        "overlapped on separate streams")
+                        "around every launch, ONE stereo pair per launch (kernels in isolation); `value`: timed pass with "
+                        "`pairs_in_flight` slots overlapped on separate streams and `pairs_per_launch` stereo pairs per chain "
+                        "of launches (a compositing launch of the timed pass covers 2 x pairs_per_launch views)")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
