@@ -382,19 +382,20 @@ def test_sort_geometry_knobs_do_not_change_results(env):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("rows,cull,packed,n_views", [(1, 0, False, 4), (2, 1, False, 4), (2, 1, True, 4), (2, 1, False, 5), (2, 1, False, 6)])
+@pytest.mark.parametrize("rows,cull,packed,n_views", [(1, 0, False, 4), (2, 1, False, 4), (2, 1, True, 4), (2, 1, False, 5), (2, 1, False, 6),
+                                                      (2, 1, False, 8)])
 def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, rows, cull, packed, n_views):
     """GS2M_OPT_PAIR_BATCH: the projection / counting / scatter kernels take two stereo pairs per launch (blockIdx.y picks
     the pair, half the workgroups per pair), scans / per-tile sort / compositing the four views in one grid.  Everything a
     call returns or leaves behind is identical to one pair per launch: images, u8 images, radii, instance counts, and --
     per view -- the projected records and the instance lists.  5 views: one batched pass + one single view; 6: a batched
-    pass + a plain pair."""
+    pass + a plain pair; 8: two batched passes."""
     W, H, f = 176, 112, 150.0
     g, s, q, o, shs, left, right = scene(2600, 33, W, H, f, log_s=math.log(0.05))
     *_rest, left2, right2 = scene(10, 34, W, H, f, az=0.9)       # a second pair of cameras
     be = backend
     P = g["xyz"].shape[0]
-    cams = [camera_from(c) for c in (left, right, left2, right2, right, left2)][:n_views]
+    cams = [camera_from(c) for c in (left, right, left2, right2, right, left2, right2, left)][:n_views]
     gd = dict(xyz=be.dev(g["xyz"]), scaling=be.dev(g["scaling"]), rotation=be.dev(g["rotation"]),
               opacity=be.dev(g["opacity"]), features_dc=be.dev(g["features_dc"]), features_rest=be.dev(g["features_rest"]),
               raw=True, sh_degree=3)
