@@ -113,7 +113,9 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye)
     tr = committed_traffic(cfg_name)
     stages = {k: dict(avg_us=round(1e3 * ms / max(c, 1), 2), frac_hbm=round(alg[k] / max(1e-9, 1e-3 * ms / max(c, 1)) / HBM_PEAK, 4),
-                      alg_bytes=int(alg[k]), traffic=(tr.get(k, {}).get("hbm_bytes_per_launch") if tr.get(k, {}).get("cull") == args.cull else None))
+                      alg_bytes=int(alg[k]),
+                      traffic=(int(tr[k]["hbm_bytes_per_launch"] / max(1, int(tr[k].get("pairs_per_launch", 1))))   # per stereo pair
+                               if tr.get(k, {}).get("cull") == args.cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
               for k, (ms, c) in st.items()}
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
     return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {len(cams)} pairs, "
@@ -145,6 +147,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default, the driver's contract): --steps views per GPU; strong: --steps views IN TOTAL, sharded "
                          "contiguously over the GPUs (BASELINE config C4: --config C4 --steps 300 --scaling strong)")
+    ap.add_argument("--always-collective", action="store_true",
+                    help="issue the key all_gather + the RCCL reduction of the TSDF accumulators (inside the timed region) even at "
+                         "world size 1: times the local part of the exchange (key union, pack, RCCL self-copy, unpack) on one GPU")
     ap.add_argument("--tile-rows", type=int, default=int(os.environ.get("GS2M_BENCH_TILE_ROWS", "2")), choices=[1, 2],
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "6")),
@@ -155,13 +160,6 @@ def main():
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
-    ap.add_argument("--blend-cus", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND_CUS", "0")),
-                    help="CU partition (gs2mesh_amd/streams.py): compositing launches on streams masked to this many CUs "
-                         "(a multiple of 32 below the CU count; 0 = no partition)")
-    ap.add_argument("--blend-streams", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND_STREAMS", "2")))
-    ap.add_argument("--bin-cus", default=os.environ.get("GS2M_BENCH_BIN_CUS", "all"), choices=["all", "rest", "blend", "own"],
-                    help="with --blend-cus: binning chains on unmasked streams (all) or on the CUs the compositing leaves (rest)")
-    ap.add_argument("--fuse-cus", default=os.environ.get("GS2M_BENCH_FUSE_CUS", "all"), choices=["all", "rest", "blend", "own"])
     ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "2")), choices=[1, 2],
                     help="2 (default) = two consecutive stereo pairs share every launch of the binning chain and the compositing "
                          "(GS2M_OPT_PAIR_BATCH; same images and volume; C2 0.315 -> 0.305 ms per step); 1 = one pair per launch")
@@ -175,6 +173,30 @@ def main():
     ap.add_argument("--no-steady-state", action="store_true", help="skip the 2K-step job of the steady-state probe")
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks of the job.  Under the driver's launcher (torch.distributed.run) WORLD_SIZE says the same;
+    # started plainly with --gpus N > 1 the script re-executes itself under that launcher (one rank per GPU, rendezvous on
+    # 127.0.0.1); anything else -- fewer visible GPUs than ranks, a launcher world that differs from --gpus -- is an error, not
+    # a silent one-GPU run that reports n_gpus: 1.
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        import socket
+        import torch
+        n_vis = torch.cuda.device_count()
+        if n_vis < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_vis} GPU(s) are visible on this node")
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    if int(world_env or "1") != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env or 1} rank(s); "
+                         "they must agree (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)")
+
     import torch
     import torch.distributed as dist
     from gs2mesh_amd import _lib, synthetic
@@ -183,13 +205,21 @@ def main():
     from gs2mesh_amd.rasterizer import camera_from
     from gs2mesh_amd.pipeline import RenderFusePipeline
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(f"cuda:{local_rank}"))
+    elif args.always_collective:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device(f"cuda:{local_rank}"))
+    exchange = world > 1 or args.always_collective      # the TSDF reduction is part of the timed job
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     K_total = args.steps * world if args.scaling == "weak" else args.steps
@@ -212,7 +242,7 @@ def main():
     if args.pairs_per_launch > 1:
         # two pairs per launch render into consecutive buffers of the pending sweep: even sweep sizes (an odd last view is
         # flushed on its own); nothing to pair up in a one-view job or without the pipeline
-        if args.fuse_batch < 2 or args.inflight < 2 or K < 2:
+        if args.fuse_batch < 2 or K < 2:
             args.pairs_per_launch = 1
         else:
             args.fuse_batch += args.fuse_batch % 2
@@ -246,13 +276,11 @@ def main():
     # `inflight` stereo pairs in flight on separate streams (own rasteriser handle + images each), integration
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
-                              exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows,
+                              raster_options=dict(exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows),
                               fuse_batch=(fuse_plan if fuse_plan and len(fuse_plan) > 1 else args.fuse_batch),
                               spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)),
-                              blend_cus=args.blend_cus, blend_streams=args.blend_streams, bin_cus=args.bin_cus, fuse_cus=args.fuse_cus,
-                              pairs_per_launch=(args.pairs_per_launch if args.inflight > 1 else 1))
+                              pairs_per_launch=args.pairs_per_launch)
     spatial_order_used = int(pipe.spatial_order)
-    pipe_blend_cus = int(pipe.blend_cus)
     pairs_per_launch_used = int(pipe.ppl)     # (the pipeline object is gone by the time the line is assembled)
     R = pipe.rasterizers[0]
     color, rgb8 = pipe.color[0][:2], pipe._own8[0][:2]     # one pair's worth of slot 0's buffers: the serial / parity passes
@@ -271,16 +299,21 @@ def main():
                                 min_depth=min_depth)
             serial_pending.clear()
 
-    def step_serial(i):
-        R.render_views(gd, cams[i], out_color=color, out_rgb8=rgb8, sync=False)
-        if args.fuse_batch > 1:
-            serial_imgs[len(serial_pending)].copy_(rgb8[0], non_blocking=True)
-            serial_pending.append(i)
-            if len(serial_pending) == args.fuse_batch:
-                serial_flush()
-        else:
-            vol.integrate(RGBDImage(rgb8[0], depths[i], depth_scale=1.0, depth_trunc=depth_trunc), intr, Es[i],
-                          min_depth=min_depth)
+    def step_serial(i0, n):
+        """instrumented pass: views i0 .. i0 + n - 1 through ONE chain of launches (n = pairs_per_launch: the launch shapes of
+        the timed pass), serial on the current stream"""
+        R.render_views(gd, [c for i in range(i0, i0 + n) for c in cams[i]], out_color=pipe.color[0][:2 * n],
+                       out_rgb8=pipe._own8[0][:2 * n], sync=False)
+        for k in range(n):
+            left8 = pipe._own8[0][2 * k]
+            if args.fuse_batch > 1:
+                serial_imgs[len(serial_pending)].copy_(left8, non_blocking=True)
+                serial_pending.append(i0 + k)
+                if len(serial_pending) == args.fuse_batch:
+                    serial_flush()
+            else:
+                vol.integrate(RGBDImage(left8, depths[i0 + k], depth_scale=1.0, depth_trunc=depth_trunc), intr, Es[i0 + k],
+                              min_depth=min_depth)
 
     def barrier():
         torch.cuda.synchronize()
@@ -297,8 +330,9 @@ def main():
     for i in range(Wm):
         step(i)
     pipe.finish()                                 # drain the pipeline's streams before touching the volume
-    if world > 1:
-        reduce_volume(vol, mode=args.reduce, payload=args.payload, algo=args.reduce_algo)      # warm the RCCL communicator + size the exchange buffers
+    if exchange:
+        reduce_volume(vol, mode=args.reduce, payload=args.payload, algo=args.reduce_algo,
+                      always_collective=args.always_collective)      # warm the RCCL communicator + size the exchange buffers
     vol.status()
     vol.reset()
     torch.cuda.synchronize()
@@ -314,9 +348,10 @@ def main():
             step(i)
         enq.append(time.perf_counter() - t0)      # host time to enqueue the K steps (no synchronisation yet)
         pipe.drain()                              # integrates the last (partial) TSDF batch, then waits for the pipeline's streams
-        if world > 1:
+        if exchange:
             t_red0 = time.perf_counter()
-            red = reduce_volume(vol, mode=args.reduce, payload=args.payload, algo=args.reduce_algo)
+            red = reduce_volume(vol, mode=args.reduce, payload=args.payload, algo=args.reduce_algo,
+                                always_collective=args.always_collective)
             torch.cuda.synchronize()
             reds.append(time.perf_counter() - t_red0)
         barrier()
@@ -331,6 +366,12 @@ def main():
             break
     dt = statistics.median(dts)
     t_red = statistics.median(reds) if reds else None
+    halo_blocks = None
+    if red is not None:
+        # owner-side finalisation step that follows a reduce-scatter (outside the timed job: mesh extraction is not part of
+        # the metric); at world size 1 this is its empty path
+        from gs2mesh_amd.parallel import exchange_halo
+        halo_blocks = int(exchange_halo(vol, red))
 
     # ---- steady state vs fill / drain: the same job with 2K steps, timed the same way; slope between the two job lengths
     steady = None
@@ -360,8 +401,9 @@ def main():
     vol.set_stage_timing(True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for i in range(Wm, Wm + K):
-        step_serial(i)
+    ppl = pairs_per_launch_used
+    for i in range(Wm, Wm + K, ppl):
+        step_serial(i, min(ppl, Wm + K - i))
     serial_flush()
     torch.cuda.synchronize()
     dt_instr = time.perf_counter() - t1
@@ -370,7 +412,10 @@ def main():
     R.set_option(_lib.OPT_STAGE_TIMING, 0)
     vol.set_stage_timing(False)
     n_blocks, block_updates, _ = vol.status()
-    stages = {k: dict(avg_us=1e3 * ms / max(c, 1), launches=int(c)) for k, (ms, c) in {**st_r, **st_t}.items()}
+    # raster stages: a launch covers `ppl` stereo pairs -> avg_us is quoted per PAIR (the unit of the algorithmic bytes) next to
+    # the launch duration itself; TSDF stages: a sweep counts as its frames (gs2m_tsdf_stage_times), avg_us is per frame
+    stages = {k: dict(avg_us=1e3 * ms / max(c, 1) / ppl, launch_us=1e3 * ms / max(c, 1), launches=int(c)) for k, (ms, c) in st_r.items()}
+    stages.update({k: dict(avg_us=1e3 * ms / max(c, 1), launch_us=None, launches=int(c)) for k, (ms, c) in st_t.items()})
     # voxels that actually updated (pass sdf > -trunc): every update adds 1 to the voxel's weight
     keys_h, tsdf_h, weight_h, _ = vol.download()
     U_total = float(weight_h.sum())
@@ -382,8 +427,10 @@ def main():
     alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye, U_frame)
     t_raster = sum(stages[k]["avg_us"] for k in _lib.RASTER_STAGES) * 1e-6
     t_tsdf = sum(stages[k]["avg_us"] for k in _lib.TSDF_STAGES) * 1e-6
-    dom = max(stages, key=lambda k: stages[k]["avg_us"] * stages[k]["launches"])
-    achieved = alg[dom] / (stages[dom]["avg_us"] * 1e-6)
+    dom = max(stages, key=lambda k: stages[k]["avg_us"] * stages[k]["launches"] * (ppl if stages[k]["launch_us"] else 1))
+    upl = ppl if stages[dom]["launch_us"] else 1        # units (stereo pairs) one launch of the dominant kernel covers
+    t_launch = (stages[dom]["launch_us"] or stages[dom]["avg_us"]) * 1e-6
+    achieved = alg[dom] * upl / t_launch               # algorithmic bytes per launch / live launch duration
     traffic, traffic_source, valu = None, None, None
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
@@ -391,41 +438,78 @@ def main():
             tr = json.load(open(prof))
             ent = tr.get(args.config, {}).get(dom)
             if ent and ent.get("cull") == args.cull and ent.get("blend_variant", 4) == args.blend:
-                traffic = ent["hbm_bytes_per_launch"]
+                # the committed counters are per launch of the PROFILED command (its launches cover `pairs_per_launch` pairs,
+                # 1 in the entries of round 3): scaled to the launches of this run
+                scale = upl / max(1, int(ent.get("pairs_per_launch", 1)))
+                traffic = int(ent["hbm_bytes_per_launch"] * scale)
                 traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 2')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                  f"passes of this command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')}; "
+                                  f"passes of tools/profile_round.sh, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')} "
+                                  f"({ent.get('pairs_per_launch', 1)} stereo pair(s) per launch there, {upl} here); "
                                   "committed profile, not measured in this run")
                 if ent.get("valu_insts_per_launch"):
                     # the dominant kernel is VALU-bound: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC
                     # pass) / live launch time, against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
-                    rate = ent["valu_insts_per_launch"] / (stages[dom]["avg_us"] * 1e-6)
-                    valu = dict(insts_per_launch=ent["valu_insts_per_launch"], achieved_Ginst_s=round(rate / 1e9, 1),
+                    n_valu = ent["valu_insts_per_launch"] * scale
+                    rate = n_valu / t_launch
+                    valu = dict(insts_per_launch=int(n_valu), achieved_Ginst_s=round(rate / 1e9, 1),
                                 peak_Ginst_s=1228.8, frac=round(rate / 1228.8e9, 4),
                                 measured_plain_fp32_Ginst_s=1010.0,
                                 note="tools/ubench/valu_rates.hip on this chip, 7 waves/SIMD: plain fp32 VALU op 2.4 cycles per "
                                      "wave64 instruction per SIMD (1010 G inst/s), v_exp_f32 8.1, v_cmp / v_cndmask through a lane "
                                      "mask ~4, v_pk_fma_f32 7.0")
+                    for name in ("salu_insts_per_launch", "branch_insts_per_launch"):
+                        if ent.get(name):
+                            valu[name] = int(ent[name] * scale)
+                    if ent.get("salu_insts_per_launch") and ent.get("branch_insts_per_launch"):
+                        valu["scalar_plus_branch_per_valu"] = round((ent["salu_insts_per_launch"] + ent["branch_insts_per_launch"]) /
+                                                                    ent["valu_insts_per_launch"], 3)
                     if ent.get("valu_trans_per_launch"):
                         # lower bound of the VALU issue time of this instruction mix: transcendental ops at 8.1 cycles,
                         # everything else priced as a plain op (the lane-mask compares / selects cost more)
-                        tr_n = ent["valu_trans_per_launch"]
-                        cyc = 8.1 * tr_n + 2.4 * (ent["valu_insts_per_launch"] - tr_n)
-                        valu["trans_insts_per_launch"] = tr_n
+                        tr_n = ent["valu_trans_per_launch"] * scale
+                        cyc = 8.1 * tr_n + 2.4 * (n_valu - tr_n)
+                        valu["trans_insts_per_launch"] = int(tr_n)
                         valu["issue_bound_us_at_2p4GHz"] = round(cyc / 1024 / 2.4e3, 1)
-                        valu["frac_of_issue_bound"] = round(valu["issue_bound_us_at_2p4GHz"] / stages[dom]["avg_us"], 3)
+                        valu["frac_of_issue_bound"] = round(valu["issue_bound_us_at_2p4GHz"] / (t_launch * 1e6), 3)
         except Exception:
             traffic = None
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
                     frac=round(achieved / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_source,
-                    algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_us=round(stages[dom]["avg_us"], 2), valu=valu,
-                    note="blend is VALU-bound (exp + 10 VALU ops per contributing pixel x instance, data served from LDS / "
-                         "the matrix cores); HBM fraction reported as the contract asks, see DESIGN.md")
+                    traffic_over_algorithmic=(round(traffic / (alg[dom] * upl), 3) if traffic else None),
+                    algorithmic_bytes_per_launch=int(alg[dom] * upl), avg_launch_us=round(t_launch * 1e6, 2),
+                    stereo_pairs_per_launch=upl, valu=valu,
+                    note="blend is VALU-bound (exp + 10 VALU ops per contributing pixel x instance, data served from LDS); "
+                         "HBM fraction reported as the contract asks, see DESIGN.md")
     tr_all = committed_traffic(args.config)
-    per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launches=v["launches"],
+    def stage_traffic(k):
+        """committed PMC traffic of stage k, per unit of `avg_us` (a stereo pair; a FRAME for the TSDF stages, whose launches
+        cover `frames_per_launch` frames)"""
+        ent = tr_all.get(k, {})
+        if ent.get("cull") != args.cull or ent.get("hbm_bytes_per_launch") is None:
+            return None
+        return int(ent["hbm_bytes_per_launch"] / max(1, int(ent.get("frames_per_launch", ent.get("pairs_per_launch", 1)))))
+
+    per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launch_us=(round(v["launch_us"], 2) if v["launch_us"] else None), launches=v["launches"],
                           alg_GBps=round(alg[k] / max(v["avg_us"], 1e-9) / 1e3, 1),
                           frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4),
-                          traffic=(tr_all.get(k, {}).get("hbm_bytes_per_launch") if tr_all.get(k, {}).get("cull") == args.cull else None))
+                          traffic=stage_traffic(k))
                   for k, v in stages.items()}
+    if "tsdf_integrate" in per_kernel:
+        # SURVEY.md 8(d) asks for BOTH byte models of the TSDF: the per-frame streaming model (what Open3D does: state read +
+        # written per frame, 40 B x updated voxels + 7 B x pixels) and the job-level lower bound (state of every touched voxel
+        # read + written ONCE per job, 20 B x voxels of the touched blocks, + the 7 B x pixels of every frame).  The
+        # voxel-stationary sweep moves the state once per sweep, so it is priced against the second; the first says what the
+        # frame-by-frame algorithm would have to move.
+        e = per_kernel["tsdf_integrate"]
+        t_frame = max(e["avg_us"], 1e-9) * 1e-6
+        B_frame = alg["tsdf_integrate"]
+        B_job_frame = (20.0 * n_blocks * 4096 + 7.0 * Wd * Ht * K) / max(K, 1)
+        e.update(frac_hbm_frame_model=round(B_frame / t_frame / HBM_PEAK, 4), alg_bytes_frame_model=int(B_frame),
+                 frac_hbm_job_bound=round(B_job_frame / t_frame / HBM_PEAK, 4), alg_bytes_job_bound_per_frame=int(B_job_frame),
+                 traffic_over_job_bound=(round(e["traffic"] / B_job_frame, 2) if e.get("traffic") else None),
+                 note="per FRAME: frame model = 40 B x updated voxels + 7 B x pixels (Open3D's per-frame streaming); job bound = "
+                      "(20 B x voxels of the touched blocks + 7 B x pixels x frames) / frames; traffic = committed PMC bytes of "
+                      "a sweep / its frames")
     raster_roofline = dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
                            achieved_GBps=round(B_pair / t_raster / 1e9, 1), frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4),
                            frac_of_6p29TBps=round(B_pair / t_raster / 6.29e12, 4),
@@ -439,7 +523,8 @@ def main():
         tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
                               union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),
                               collectives=int(red.get("collectives", 0)), payload=red.get("payload"), algo=red.get("algo"),
-                              frames_total=int(red.get("frames_total", 0)),
+                              frames_total=int(red.get("frames_total", 0)), halo_blocks_after=halo_blocks,
+                              world=world, always_collective=bool(args.always_collective),
                               note="bytes_per_rank = packed union blocks one rank contributes (12 B / voxel packed, 20 B / voxel f32); "
                                    "a reduce-scatter moves (N-1)/N of it over xGMI")
 
@@ -544,8 +629,7 @@ def main():
                                  f"{Wd}x{Ht}, TSDF {cfg.tsdf_n}^3 (voxel {cfg.voxel_length:g}, trunc {cfg.sdf_trunc}), "
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
                         exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight, pairs_per_launch=pairs_per_launch_used,
-                        tsdf_fuse_batch=(fuse_plan if fuse_plan else args.fuse_batch), cu_partition=dict(blend_cus=pipe_blend_cus, blend_streams=args.blend_streams,
-                                                                           bin_cus=args.bin_cus, fuse_cus=args.fuse_cus),
+                        tsdf_fuse_batch=(fuse_plan if fuse_plan else args.fuse_batch),
                         parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
             steady_state=steady,
             timing=dict(repeats=len(dts), timed_region_s=round(sum(dts), 4), statistic="median over repeats of the K-step job",
@@ -555,11 +639,11 @@ def main():
             tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, parity=par, cpu_baseline=cpu,
             c3=c3, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
             note_stages="`stages` / `roofline` / `instrumented_ms_per_step`: second pass, serial on one stream with hipEvents "
-                        "around every launch, ONE stereo pair per launch (kernels in isolation); `value`: timed pass with "
-                        "`pairs_in_flight` slots overlapped on separate streams and `pairs_per_launch` stereo pairs per chain "
-                        "of launches (a compositing launch of the timed pass covers 2 x pairs_per_launch views)")
+                        "around every launch, `pairs_per_launch` stereo pairs per chain of launches = the launch shapes of the "
+                        "timed pass (kernels in isolation; raster `avg_us` = launch_us / pairs_per_launch, TSDF `avg_us` per frame); "
+                        "`value`: timed pass with `pairs_in_flight` slots overlapped on separate streams")
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

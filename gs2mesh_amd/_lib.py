@@ -31,13 +31,14 @@ class Gaussians(C.Structure):
                 ("xyz", vp), ("scales", vp), ("rotations", vp), ("opacities", vp), ("shs", vp), ("shs_rest", vp)]
 
 
-ABI_VERSION = 301   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
+ABI_VERSION = 401   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
 OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
-OPT_BLEND_WG_PER_CU = 6
-OPT_BLEND_JOIN = 7
 OPT_PAIR_BATCH = 8
+OPT_BIN_WORKGROUPS = 9      # tuning options: results never change
+OPT_BIN_WG_THREADS = 10
+OPT_BLEND_MODE = 11
 XFORM_SUM_F32, XFORM_RAW_F32, XFORM_SUM_PACKED = 0, 1, 2
 XFORM_PACKED_MAX_FRAMES = 1023
 OPT_DEBUG_SYNC = 3
@@ -48,10 +49,6 @@ TSDF_STAGES = ("tsdf_touch", "tsdf_integrate")
 _PROTOS = {
     "gs2m_version": (i32, []),
     "gs2m_last_error": (C.c_char_p, []),
-    "gs2m_stream_create": (i32, [C.POINTER(vp), i32, C.POINTER(C.c_uint32), i32]),
-    "gs2m_stream_destroy": (i32, [vp]),
-    "gs2m_raster_set_blend_stream": (i32, [vp, vp]),
-    "gs2m_raster_join": (i32, [vp, vp]),
     "gs2m_raster_create": (i32, [C.POINTER(vp), i32]),
     "gs2m_raster_destroy": (i32, [vp]),
     "gs2m_raster_set_option": (i32, [vp, i32, i32]),

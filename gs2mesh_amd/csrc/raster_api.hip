@@ -39,8 +39,8 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 
 struct gs2m_raster {
     int device = 0;
-    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_blend_wg_per_cu = 0, opt_blend_join = 1, opt_pair_batch = 0;
-    bool blend_pending = false;   // a compositing launch sits on blend_stream and the call's stream has not waited for it
+    int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_pair_batch = 0;
+    int opt_bin_workgroups = 256, opt_bin_wg_threads = 1024, opt_blend_mode = 0;   // tuning options (gs2m_raster_set_option)
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -48,6 +48,7 @@ struct gs2m_raster {
     std::vector<EvPair> ev_live;        // recorded, not yet read
     std::vector<hipEvent_t> ev_free;    // recycled events
     CamUniform* d_cams = nullptr;  // [GS2M_MAX_PASS_VIEWS]
+    unsigned* d_done = nullptr;    // [GS2M_MAX_PASS_VIEWS] tickets of k_hist_colscan's workgroups (zero between passes)
     GeomRec* d_recs = nullptr;
     size_t recs_cap = 0;  // records
     unsigned long long* d_tilemask = nullptr;
@@ -89,10 +90,6 @@ struct gs2m_raster {
     // last call
     int last_P = 0, last_nv = 0, last_tiles = 0, last_views_total = 0;
     unsigned last_cap = 0;
-    // gs2m_raster_set_blend_stream: the compositing launch goes to this stream (e.g. one created with a CU mask), ordered
-    // against the call's stream by the two events below; null = everything on the call's stream
-    hipStream_t blend_stream = nullptr;
-    hipEvent_t ev_binned = nullptr, ev_blended = nullptr;
 };
 
 template <typename T>
@@ -118,6 +115,8 @@ extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
     gs2m_raster* r = new gs2m_raster();
     r->device = device;
     if (hipMalloc((void**)&r->d_cams, sizeof(CamUniform) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
+        hipMalloc((void**)&r->d_done, sizeof(unsigned) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
+        hipMemset(r->d_done, 0, sizeof(unsigned) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
         hipMalloc((void**)&r->d_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
         hipHostMalloc((void**)&r->h_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
         hipMemset(r->d_status, 0, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess) {
@@ -133,6 +132,7 @@ extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
 extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     if (!r) return 0;
     (void)hipFree(r->d_cams);
+    (void)hipFree(r->d_done);
     (void)hipFree(r->d_recs);
     (void)hipFree(r->d_tilemask);
     (void)hipFree(r->d_shpack);
@@ -155,8 +155,6 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
         (void)hipEventDestroy(p.b);
     }
     for (auto e : r->ev_free) (void)hipEventDestroy(e);
-    if (r->ev_binned) (void)hipEventDestroy(r->ev_binned);
-    if (r->ev_blended) (void)hipEventDestroy(r->ev_blended);
     delete r;
     return 0;
 }
@@ -182,71 +180,32 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             }
             r->opt_tile_rows = value;
             return 0;
-        case GS2M_OPT_BLEND_WG_PER_CU:
-            if (value < 0 || value > 8) {
-                gs2m_set_error("GS2M_OPT_BLEND_WG_PER_CU must be 0 (no cap) .. 8");
-                return 1;
-            }
-            r->opt_blend_wg_per_cu = value;
-            return 0;
-        case GS2M_OPT_BLEND_JOIN: r->opt_blend_join = value != 0; return 0;
         case GS2M_OPT_PAIR_BATCH: r->opt_pair_batch = value != 0; return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
         case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
+        case GS2M_OPT_BIN_WORKGROUPS:
+            if (value < 0 || value > 4096) {
+                gs2m_set_error("GS2M_OPT_BIN_WORKGROUPS must be 0 (default) .. 4096");
+                return 1;
+            }
+            r->opt_bin_workgroups = value ? value : 256;
+            return 0;
+        case GS2M_OPT_BIN_WG_THREADS:
+            if (value < 0 || value > 1024 || value % 64) {
+                gs2m_set_error("GS2M_OPT_BIN_WG_THREADS must be 0 (default) or a multiple of 64 up to 1024");
+                return 1;
+            }
+            r->opt_bin_wg_threads = value ? value : 1024;
+            return 0;
+        case GS2M_OPT_BLEND_MODE:
+            if (value != 0 && value != 1) {
+                gs2m_set_error("GS2M_OPT_BLEND_MODE must be 0 or 1");
+                return 1;
+            }
+            r->opt_blend_mode = value;
+            return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
     }
-}
-
-extern "C" int gs2m_stream_create(gs2m_stream* out, int device, const uint32_t* cu_mask, int n_words) {
-    if (!out) {
-        gs2m_set_error("gs2m_stream_create: out is NULL");
-        return 1;
-    }
-    HIPCHK(hipSetDevice(device));
-    hipStream_t s = nullptr;
-    if (cu_mask && n_words > 0) {
-        bool any = false;
-        for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0u;
-        if (!any) {
-            gs2m_set_error("gs2m_stream_create: empty CU mask");
-            return 1;
-        }
-        HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
-    } else {
-        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    }
-    *out = (gs2m_stream)s;
-    return 0;
-}
-
-extern "C" int gs2m_stream_destroy(gs2m_stream s) {
-    if (s) HIPCHK(hipStreamDestroy((hipStream_t)s));
-    return 0;
-}
-
-extern "C" int gs2m_raster_join(gs2m_raster* r, gs2m_stream stream) {
-    if (!r) {
-        gs2m_set_error("null handle");
-        return 1;
-    }
-    // always enqueued when a compositing stream is set: the event is re-recorded by every call, waiting for the latest
-    // record is what a consumer of the image / a re-user of the arenas needs, whichever stream asks
-    if (r->blend_stream && r->ev_blended && r->last_P > 0) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, r->ev_blended, 0));
-    return 0;
-}
-
-extern "C" int gs2m_raster_set_blend_stream(gs2m_raster* r, gs2m_stream s) {
-    if (!r) {
-        gs2m_set_error("null handle");
-        return 1;
-    }
-    HIPCHK(hipSetDevice(r->device));
-    if (s && !r->ev_binned) {
-        HIPCHK(hipEventCreateWithFlags(&r->ev_binned, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&r->ev_blended, hipEventDisableTiming));
-    }
-    r->blend_stream = (hipStream_t)s;
-    return 0;
 }
 
 // tiles of the binning grid: 16 x (16 * rows) pixels
@@ -255,15 +214,10 @@ static int binning_tiles(const gs2m_raster* r, int W, int H) {
     return gx * ((gy + r->opt_tile_rows - 1) / r->opt_tile_rows);
 }
 
-static void geometry(int P, int* chunk, int* n_wg, int pairs = 1) {
+static void geometry(const gs2m_raster* r, int P, int* chunk, int* n_wg, int pairs = 1) {
     // ~256 workgroups (one per CU: the per-workgroup tile histogram rows / cursors scale with their number;
-    // measured optimum on C2/C3), chunks a multiple of 256 Gaussians
-    static int target = 0;
-    if (!target) {
-        const char* e = getenv("GS2M_NWG_TARGET");  // tuning knob
-        target = e ? atoi(e) : 256;
-        if (target < 1) target = 256;
-    }
+    // measured optimum on C2/C3; GS2M_OPT_BIN_WORKGROUPS), chunks a multiple of 256 Gaussians
+    const int target = r->opt_bin_workgroups > 0 ? r->opt_bin_workgroups : 256;
     // `pairs` groups of views share a launch (blockIdx.y): the workgroups of a group are target / pairs, the launch still
     // fills the chip, and what a workgroup pays once (LDS clear, its histogram row, cursor set-up) is paid half as often
     const int tgt = target / pairs > 0 ? target / pairs : 1;
@@ -285,7 +239,7 @@ extern "C" int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, in
     const int nv = n_views < GS2M_MAX_PASS_VIEWS ? (n_views < 1 ? 1 : n_views) : GS2M_MAX_PASS_VIEWS;
     const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
     int chunk, n_wg;
-    geometry(P, &chunk, &n_wg);
+    geometry(r, P, &chunk, &n_wg);
     if (ensure(&r->d_recs, &r->recs_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
     if (ensure(&r->d_tilemask, &r->mask_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
     if (ensure(&r->d_hist, &r->hist_cap, (size_t)nv * n_wg * tiles)) return 1;
@@ -349,20 +303,21 @@ struct StageTimer {  // RAII: a rocTX range (GS2M_ROCTX=1) and, when timing is o
     }
 };
 
-// One fused pass over `pairs` groups of nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams.
+// One fused pass over `pairs` groups of nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams (host_cams ==
+// null) or travel with the projection launch (host_cams = the nv * pairs host-side uniforms).
 // A group is what one projection / counting / scatter workgroup handles (a stereo pair: parameters and Sigma once for both
 // eyes); with pairs = 2 (GS2M_OPT_PAIR_BATCH) two groups share every launch (blockIdx.y), each with half the workgroups.
 static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W, int H, float* out_color,
-                     unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st) {
+                     unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st, const CamUniform* host_cams) {
     const int nvt = nv * pairs;   // views of the pass: the scans, the per-tile sort and the compositing take them all (grid.y)
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
     const int gys = (gy + r->opt_tile_rows - 1) / r->opt_tile_rows;  // binning rows (tiles of 16 x 16*rows pixels)
     const int tiles = gx * gys;
     int chunk, n_wg;
-    geometry(g.P, &chunk, &n_wg, pairs);
+    geometry(r, g.P, &chunk, &n_wg, pairs);
     // threads per counting / scatter workgroup: the chunk (<= 1024), halved until the wave staging fits next to the
     // tile cursors in the 160 KiB LDS (large images)
-    int wg_threads = (gs2m_count_threads(chunk) + 63) / 64 * 64;
+    int wg_threads = (gs2m_count_threads(chunk, r->opt_bin_wg_threads) + 63) / 64 * 64;
     while (wg_threads > 64 && gs2m_scatter_lds_bytes(nv, tiles, wg_threads) > 160 * 1024)
         wg_threads = (wg_threads / 2 + 63) / 64 * 64;  // stays a whole number of waves: the size checked is the size launched
     const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, wg_threads);    // scatter: u32 cursors + wave staging
@@ -385,7 +340,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     // its own LDS atomics and tile tests, not by re-reading the records; 128 VGPRs for 1024-thread workgroups.  Not kept.)
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
-        gs2m_launch_project(nv, pairs, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p);
+        gs2m_launch_project(nv, pairs, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p, host_cams);
     }
     if (dbg_check(r, st, "project")) return 1;
     {
@@ -396,15 +351,13 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     }
     if (dbg_check(r, st, "count_tiles")) return 1;
     {
+        // column scan + (its last workgroup per view) the tile scan: one launch (round 3: two, GS2M_STAGE_TILESCAN is not
+        // launched any more and reports 0)
         StageTimer tm(r, st, GS2M_STAGE_COLSCAN);
-        gs2m_launch_hist_colscan(st, nvt, r->d_hist, n_wg, tiles, r->d_tile_count);
+        gs2m_launch_hist_colscan(st, nvt, r->d_hist, n_wg, tiles, r->d_tile_count, r->d_done, r->d_tile_start, gx,
+                                 r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
     }
-    if (dbg_check(r, st, "hist_colscan")) return 1;
-    {
-        StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
-        gs2m_launch_tile_scan(st, nvt, r->d_tile_count, r->d_tile_start, tiles, gx, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
-    }
-    if (dbg_check(r, st, "tile_scan")) return 1;
+    if (dbg_check(r, st, "hist_colscan + tile_scan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
         if (gs2m_launch_scatter(nv, pairs, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
@@ -430,28 +383,12 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
         gs2m_launch_sort_tiles(st, nvt, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists, hint);
     }
     if (dbg_check(r, st, "sort_tiles")) return 1;
-    // compositing on its own stream (gs2m_raster_set_blend_stream): binned -> [blend stream] -> blended -> back on `st`, so
-    // that for the caller everything is still ordered on `st`
-    hipStream_t bs = st;
-    if (r->blend_stream && r->blend_stream != st) {
-        bs = r->blend_stream;
-        HIPCHK(hipEventRecord(r->ev_binned, st));
-        HIPCHK(hipStreamWaitEvent(bs, r->ev_binned, 0));
-    }
-    r->blend_pending = false;
     {
-        StageTimer tm(r, bs, GS2M_STAGE_BLEND);
-        if (gs2m_launch_blend(bs, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
+        StageTimer tm(r, st, GS2M_STAGE_BLEND);
+        if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
                               g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
-                              r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_wg_per_cu))
+                              r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_mode))
             return 1;
-    }
-    if (bs != st) {
-        HIPCHK(hipEventRecord(r->ev_blended, bs));
-        // GS2M_OPT_BLEND_JOIN 0: the call's stream goes on without waiting for the compositing (the next view's binning
-        // chain can follow at once); whoever needs the image, or re-uses this handle, calls gs2m_raster_join first
-        if (r->opt_blend_join || r->opt_debug) HIPCHK(hipStreamWaitEvent(st, r->ev_blended, 0));
-        else r->blend_pending = true;
     }
     if (dbg_check(r, st, "blend")) return 1;
     r->last_P = g.P;
@@ -532,7 +469,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     if (debug) r->opt_debug = 1;
     gs2m_launch_pack_camera(st, r->d_cams, 0, viewmatrix, projmatrix, cam_pos, background, tan_fovx, tan_fovy,
                             width, height, 16 * r->opt_tile_rows);
-    int rc = run_views(r, g, 1, 1, width, height, out_color, nullptr, radii, 0, st);
+    int rc = run_views(r, g, 1, 1, width, height, out_color, nullptr, radii, 0, st, nullptr);
     r->opt_debug = saved_debug;
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * 2, hipMemcpyDeviceToHost, st));
@@ -645,10 +582,9 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
             u.bg[2] = bg[2];
             u.th = 16 * r->opt_tile_rows;
         }
-        gs2m_launch_set_cameras(st, r->d_cams, nvt, cu);  // one launch for the views of the pass
         if (run_views(r, g, nv, pairs, W, H, out_color ? out_color + 3 * img * v0 : nullptr,
                       out_rgb8 ? out_rgb8 + 3 * img * v0 : nullptr,
-                      out_radii ? out_radii + (size_t)gs->P * v0 : nullptr, v0, st))
+                      out_radii ? out_radii + (size_t)gs->P * v0 : nullptr, v0, st, cu))   // the uniforms travel with k_project
             return 1;
         v0 += nvt;
     }
@@ -738,7 +674,6 @@ extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_view
         return 1;
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    if (r->blend_stream && r->blend_stream != (hipStream_t)stream) HIPCHK(hipStreamSynchronize(r->blend_stream));
     HIPCHK(hipGetLastError());
     // slot 0 is sticky: an overflow in ANY call since the last query is reported (a later call on the same handle that
     // fits does not erase it), with the largest instance count any of those calls needed

@@ -1,14 +1,13 @@
 // raster_bin.hip -- tile offsets + per-tile depth sort (integer work).
-#include <cstdlib>
 #include "raster_sort.h"
 #include "raster_internal.h"
 
-void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count) {
-    GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(64 * GS2M_COLSCAN_SEGS), 0, st, hist, n_wg, tiles, tile_count);
-}
-void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles, int gx,
-                           ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {
-    GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, gx, status, sticky, cap, sort_lists);
+void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count, unsigned* done,
+                              unsigned* tile_start, int gx, ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {
+    // column scan of the per-workgroup histogram rows; the last workgroup of a view to finish runs the view's tile scan
+    // (tile offsets, status words, size-class work lists of the sort, compositing schedule) in the same launch
+    GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(64 * GS2M_COLSCAN_SEGS), 0, st, hist, n_wg, tiles, tile_count, done,
+                tile_start, gx, status, sticky, cap, sort_lists);
 }
 size_t gs2m_sort_lists_words(int nv, int tiles) { return (size_t)nv * (GS2M_SORT_CLASSES * (tiles + 1) + tiles); }  // class lists + schedule
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
@@ -19,14 +18,10 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
     // possibly stale): the class kernels walk their lists grid-stride, so any grid >= 1 is correct -- the hint only keeps a
     // class that is (almost) empty from launching hundreds of workgroups of 40-80 KiB LDS that wait for CU space just to
     // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
-    static const int wave_bucket = getenv("GS2M_SORT_WAVE_BUCKET") ? atoi(getenv("GS2M_SORT_WAVE_BUCKET")) : 1;   // 0 = bitonic only
-    static const int small_wpb = getenv("GS2M_SORT_SMALL_WPB") ? atoi(getenv("GS2M_SORT_SMALL_WPB")) : 4;       // development A/B knob
-    if (small_wpb == 1) GS2M_LAUNCH(k_sort_tiles_small<1>, dim3(tiles, nv), dim3(64), 0, st, keys, tile_start, tiles, cap, wave_bucket);
-    else if (small_wpb == 2) GS2M_LAUNCH(k_sort_tiles_small<2>, dim3((tiles + 1) / 2, nv), dim3(128), 0, st, keys, tile_start, tiles, cap, wave_bucket);
-    else GS2M_LAUNCH(k_sort_tiles_small<4>, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, tiles, cap, wave_bucket);
-    static const int light = getenv("GS2M_SORT_LIGHT") ? atoi(getenv("GS2M_SORT_LIGHT")) : 1;   // development A/B knob
-    if (light && class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0) {
-        // every size class was empty last time: ONE LDS-free launch that still sorts whatever it finds (k_sort_tiles_rank)
+    GS2M_LAUNCH(k_sort_tiles_small<4>, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, tiles, cap);
+    if (class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0) {
+        // every size class was empty last time: ONE LDS-free launch that still sorts whatever it finds, exactly and in bounded
+        // time even when the hint is stale (k_sort_tiles_rank: rank-sorted runs of 256 + rank merges)
         GS2M_LAUNCH(k_sort_tiles_rank, dim3(32, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
         return;
     }
@@ -40,13 +35,7 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
         }
         if (g[c] < 1) g[c] = 1;
     }
-    static const int keys_per_thread = getenv("GS2M_SORT_KEYS_PER_THREAD") ? atoi(getenv("GS2M_SORT_KEYS_PER_THREAD")) : 8;   // A/B knob: 16 = round 2
-    if (keys_per_thread == 16) {
-        GS2M_LAUNCH(k_sort_tiles_bucket_4096x16, dim3(g[0], nv), dim3(256), 0, st, keys, tile_start, tiles, cap, sort_lists);
-        GS2M_LAUNCH(k_sort_tiles_bucket_8192x16, dim3(g[1], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    } else {
-        GS2M_LAUNCH(k_sort_tiles_bucket_4096x8, dim3(g[0], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
-        GS2M_LAUNCH(k_sort_tiles_bucket_8192x8, dim3(g[1], nv), dim3(1024), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    }
+    GS2M_LAUNCH(k_sort_tiles_bucket_4096x8, dim3(g[0], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH(k_sort_tiles_bucket_8192x8, dim3(g[1], nv), dim3(1024), 0, st, keys, tile_start, tiles, cap, sort_lists);
     GS2M_LAUNCH(k_sort_tiles, dim3(g[2], nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
 }

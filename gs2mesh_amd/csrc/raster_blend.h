@@ -123,7 +123,7 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
 //     one L2) ranked by descending weight and dealt to the XCDs round-robin (block b runs on XCD b % 8, blocks are
 //     dispatched in order) -- a wave lives ~100 us and a launch has ~2 generations of them, so the kernel used to end on
 //     whatever long lists came last and on the XCD that owned the densest part of the image (C2 238 -> 218 us, C3 320 ->
-//     277 us).  Without `order` (GS2M_BLEND_LPT=0): one contiguous run of tiles per XCD.
+//     277 us).
 // Decisions are the reference's (same thresholds, same order); roundings of ~1 ulp in q (|q| <= 8) -> relative 1e-6 in alpha.
 // LROWS = reference tiles per instance list (GS2M_OPT_TILE_ROWS): with 2 the binning stages handle ~30 % fewer
 // (Gaussian, tile) instances; two waves walk the same 16 x 32 list, each compositing its own 16 x 16 half (instances that
@@ -162,11 +162,10 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     const int v = (int)blockIdx.y;
     const CamUniform& cam = cams[v];
     const int W = cam.W, H = cam.H, gx = cam.gx;
-    const int tiles = gx * cam.gy;                              // tiles composited by waves
     const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);    // instance lists
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned bid = blockIdx.x;
     int tx, ty;
-    if (order) {
+    {
         // k_tile_scan's schedule: chunks of GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring lists ranked by descending weight; rank p is
         // the (p / 8)-th chunk of XCD p % 8.  Wave slot j of XCD x (= bid % 8) takes half (j % LROWS) of list (j / LROWS) %
         // CHUNK of that XCD's (j / (CHUNK * LROWS))-th chunk.
@@ -184,13 +183,6 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         tx = lx;
         ty = ly * LROWS + j % LROWS;
         if (ty >= cam.gy) return;
-    } else {
-        const unsigned qq = nwg / 8u, rr = nwg % 8u, xcd = bid % 8u, idx = bid / 8u;
-        const unsigned grp = (xcd < rr ? xcd * (qq + 1u) : rr * (qq + 1u) + (xcd - rr) * qq) + idx;
-        const int tile = gs2m_uniform((int)(grp * (unsigned)WPB) + wave);
-        if (tile >= tiles) return;
-        tx = tile % gx;
-        ty = tile / gx;
     }
     const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
     float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
@@ -339,7 +331,6 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         // constants are in flight while instance j is composited (no LDS wait on the critical path).
         auto step_body = [&](auto gen_tag, const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
             constexpr int GTAG = (int)decltype(gen_tag)::value;   // 0 / 1: compile-time, 2: the instance's flag (bit 8 of qmf)
-            constexpr bool GENERAL = GTAG == 1;
             int qm = qmf & (int)lq;
             GS2M_OPAQUE_SGPR(qm);   // one s_and per instance, then s_bitcmp per quadrant (not an s_and + s_cmp per quadrant)
             {

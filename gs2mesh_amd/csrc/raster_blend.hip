@@ -1,5 +1,4 @@
 // raster_blend.hip -- compositing stage (default FMA contraction; VALU-bound inner loop).
-#include <cstdlib>
 #include "raster_blend.h"
 #include "raster_internal.h"
 
@@ -8,35 +7,20 @@
 //   0: the reference's structure (256-thread workgroup per tile, 1 pixel per lane; 16 x 16 lists only)
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P, unsigned cap,
-                      float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order, int wg_per_cu) {
-    const int tiles = gx * gy;
-    // GS2M_OPT_BLEND_WG_PER_CU: cap the resident compositing workgroups per CU by padding the launch with unused dynamic
-    // LDS (static: 22 848 B per 4-wave workgroup = 7 per CU).  The compositing kernel is issue-bound and loses little
-    // below 7 waves per SIMD, while the wave slots and the LDS it leaves free on EVERY CU let the 1024-thread binning /
-    // TSDF workgroups of the next views start at once instead of waiting for its tail (spatial sharing inside the CUs).
-    size_t pad = 0;
-    if (wg_per_cu > 0 && wg_per_cu < 7) pad = ((size_t)(160 * 1024) / (size_t)wg_per_cu - 22848) & ~(size_t)255;
-    const dim3 grid((tiles + 3) / 4, nv), block(256);
+                      float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order, int mode) {
+    const dim3 block(256);
     if (variant == 4) {
-        static const int lpt = getenv("GS2M_BLEND_LPT") ? atoi(getenv("GS2M_BLEND_LPT")) : 1;  // tuning knob: 0 = XCD-contiguous tile ranges
-        const unsigned* ord = lpt ? order : nullptr;
         const int ltiles = gx * ((gy + tile_rows - 1) / tile_rows);
         // schedule: ceil(chunks / 8) chunks per XCD, GS2M_SCHED_CHUNK lists per chunk, tile_rows waves per list, 4 waves per workgroup
         const int nch = ((gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW) * ((ltiles / gx + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
-        const dim3 g2(ord ? 8u * ((unsigned)(((nch + 7) / 8) * GS2M_SCHED_CHUNK * tile_rows + 3) / 4u) : grid.x, nv);
-        static const int mode = getenv("GS2M_BLEND_MODE") ? atoi(getenv("GS2M_BLEND_MODE")) : 0;   // development A/B knob
-        if (mode == 2) {   // MODE 1 at 6 waves per SIMD (80 VGPRs)
-            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 6, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
-            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 6, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+        const dim3 g2(8u * ((unsigned)(((nch + 7) / 8) * GS2M_SCHED_CHUNK * tile_rows + 3) / 4u), nv);
+        if (mode == 1) {   // GS2M_OPT_BLEND_MODE 1: execution-mask form of the loop
+            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 1>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
+            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 1>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
             return 0;
         }
-        if (mode == 1) {
-            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
-            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 1>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
-            return 0;
-        }
-        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
-        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), g2, block, pad, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, ord);
+        if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
+        else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
         return 0;
     }
     if (variant == 0 && tile_rows == 1) {

@@ -5,15 +5,15 @@
 #pragma once
 #include "raster_common.h"
 
-struct CamUniformArg;
-
 size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads);
-void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
-                         int exact_cull);
+// host_cams: null (the uniforms are already in `cams`, device memory) or the nv * pairs host-side uniforms of the pass (carried in
+// the launch packet; the kernel also stores them to `cams`)
+void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRec* recs, int* radii,
+                         int exact_cull, const CamUniform* host_cams);
 int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull, int interleave);
-int gs2m_count_threads(int chunk);
+int gs2m_count_threads(int chunk, int max_threads);
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads);
 int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
@@ -28,18 +28,16 @@ void gs2m_launch_mark_visible(hipStream_t st, int P, const float* xyz, const flo
 void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const float* viewmatrix,
                              const float* projmatrix, const float* campos, const float* bg, float tanfovx,
                              float tanfovy, int W, int H, int th);
-void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamUniform* c);
 
-void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count);
-void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles, int gx,
-                           ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists);
+void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count, unsigned* done,
+                              unsigned* tile_start, int gx, ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists);
 size_t gs2m_sort_lists_words(int nv, int tiles);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint);
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
                       unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order,
-                      int wg_per_cu);
+                      int mode);
 
 // error plumbing (common_api.hip)
 void gs2m_set_error(const char* fmt, ...);

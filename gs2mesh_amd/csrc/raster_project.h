@@ -325,18 +325,32 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
     }
 }
 
+// Per-view uniforms from HOST values carried in the kernel arguments (pipeline-level API): the launch packet is the
+// transport, so no pinned staging buffer / lifetime hazard.  Round 4: the packet is k_project's own (its workgroups read the
+// uniforms of their views straight from the kernel-argument segment -- scalar loads -- and workgroup 0 of every group of views
+// stores them to `cams_out` for the later kernels of the pass): one launch less on the critical chain of every pass (round 3:
+// k_set_cameras, 4.5 us + a launch gap).
+struct CamUniformArg {
+    CamUniform c[GS2M_MAX_PASS_VIEWS];
+};
+
 // Projection + colour, one thread per Gaussian -- a streaming kernel (no loop): see project_gaussian.
 // Packed SH copy (DMA_SH): the 192-B row of every Gaussian of the wave goes straight from HBM into LDS (global_load_lds, 12 x
 // 1 KiB per wave), issued BEFORE the parameter loads and the projection: one memory round trip per thread instead of two in
 // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.  The
 // colour pass then reads the 16 coefficients of one channel at a time back from LDS.
-template <int NV, bool DMA_SH, bool STREAM = true>
-GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // forcing 5 waves per SIMD on the round-2 kernel (96 VGPRs, spills): C2 30 -> 36 us, C3 149 -> 204
-k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
-          int exact_cull) {
+template <int NV, bool DMA_SH, bool STREAM, bool HOSTCAMS>
+GS2M_DEVICE void project_kernel_body(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs,
+                                     int* __restrict__ radii, int exact_cull, CamUniform* __restrict__ cams_out) {
     __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
     // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH: two stereo pairs per launch)
     cams += NV * blockIdx.y;
+    if (HOSTCAMS && blockIdx.x == 0) {
+        // the uniforms of this group of views -> device memory, for the later kernels of the pass (dword copy)
+        const unsigned* src = reinterpret_cast<const unsigned*>(cams);
+        unsigned* dst = reinterpret_cast<unsigned*>(cams_out + NV * blockIdx.y);
+        for (unsigned i = threadIdx.x; i < NV * sizeof(CamUniform) / 4u; i += GS2M_PROJECT_THREADS) dst[i] = src[i];
+    }
     recs += (size_t)NV * blockIdx.y * g.P;
     if (radii) radii += (size_t)NV * blockIdx.y * g.P;
     const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
@@ -344,6 +358,20 @@ k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ 
     ProjView pv[NV];
     float op, thr;
     project_gaussian<NV, DMA_SH, STREAM>(g, cams, recs, radii, exact_cull, gi, gi < g.P, &s_sh[DMA_SH ? wave_id : 0][0][0], lane_id, pv, op, thr);
+}
+// uniforms in device memory (operator-level API: the caller's matrices are device tensors, k_pack_camera)
+template <int NV, bool DMA_SH, bool STREAM = true>
+GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // forcing 5 waves per SIMD on the round-2 kernel (96 VGPRs, spills): C2 30 -> 36 us, C3 149 -> 204
+k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
+          int exact_cull) {
+    project_kernel_body<NV, DMA_SH, STREAM, false>(g, cams, recs, radii, exact_cull, nullptr);
+}
+// uniforms in the kernel arguments (pipeline-level API, host-side cameras)
+template <int NV, bool DMA_SH, bool STREAM = true>
+GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
+k_project_hc(GaussIn g, CamUniformArg hc, CamUniform* __restrict__ cams_out, GeomRec* __restrict__ recs, int* __restrict__ radii,
+             int exact_cull) {
+    project_kernel_body<NV, DMA_SH, STREAM, true>(g, &hc.c[0], recs, radii, exact_cull, cams_out);
 }
 
 // Gaussian -> workgroup assignment of the counting sort (k_count_tiles and k_scatter must agree: the histogram row of a
@@ -831,13 +859,4 @@ GS2M_KERNEL void k_pack_camera(CamUniform* cams, int slot, const float* viewmatr
         c->gy = (H + GS2M_TILE - 1) / GS2M_TILE;
         c->th = th;
     }
-}
-
-// Same from HOST values carried in the kernel arguments (pipeline-level API): the launch
-// packet is the transport, so no pinned staging buffer / lifetime hazard.
-struct CamUniformArg {
-    CamUniform c[GS2M_MAX_PASS_VIEWS];
-};
-GS2M_KERNEL void k_set_cameras(CamUniform* cams, int n, CamUniformArg a) {
-    if ((int)threadIdx.x < n) cams[threadIdx.x] = a.c[threadIdx.x];
 }

@@ -1,11 +1,10 @@
 // raster_project.hip -- projection / counting / scatter stage (compiled with -ffp-contract=off).
-#include <cstdlib>
 #include "raster_project.h"
 #include "raster_internal.h"
 
 // k_count_tiles: threads per workgroup = the workgroup's chunk of Gaussians, at most 1024
-int gs2m_count_threads(int chunk) {
-    static const int cap = getenv("GS2M_MAX_WG_THREADS") ? atoi(getenv("GS2M_MAX_WG_THREADS")) : 1024;  // tuning knob
+int gs2m_count_threads(int chunk, int max_threads) {
+    const int cap = max_threads >= 64 && max_threads <= 1024 ? max_threads : 1024;   // GS2M_OPT_BIN_WG_THREADS
     const int t = chunk < cap ? (chunk + 63) / 64 * 64 : cap;
     return t < 64 ? 64 : t;
 }
@@ -17,23 +16,34 @@ size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads) {
     return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_SCATTER_STAGE_BYTES_PER_WAVE;
 }
 
-void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, const CamUniform* cams, GeomRec* recs, int* radii,
-                         int exact_cull) {
+void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRec* recs, int* radii,
+                         int exact_cull, const CamUniform* host_cams) {
     const unsigned nx = (unsigned)((g.P + 255) / 256);
     if (nx == 0) return;
     const dim3 n(nx, (unsigned)pairs);   // blockIdx.y = group of nv views (GS2M_OPT_PAIR_BATCH)
     // SH rows through LDS (k_project<.., true>): with the spatially ordered packed model (large models, where (almost) every
     // Gaussian is visible: C3 148 -> 136 us); a model that only has the packed SH copy keeps the register path, which reads
     // no row of a culled Gaussian and runs 16 instead of 12 waves per CU (C2: 28 vs 30 us)
-    static const int dma_knob = getenv("GS2M_PROJECT_DMA") ? atoi(getenv("GS2M_PROJECT_DMA")) : 1;  // tuning knob
-    const bool dma = dma_knob && g.shs_packed != nullptr && g.colors_precomp == nullptr && g.ids != nullptr;
+    const bool dma = g.shs_packed != nullptr && g.colors_precomp == nullptr && g.ids != nullptr;
     // the colour pass streams the SH row three float4 at a time where the row is 16-B aligned (packed copy, [P,16,3]) or not
     // needed (precomputed colours); dc + rest split layouts / M != 16 keep the 48-register path (k_project<.., .., false>)
     const bool stream = g.colors_precomp != nullptr || g.shs_packed != nullptr || (g.shs_rest == nullptr && g.M == 16);
-    if (nv == 2 && dma) GS2M_LAUNCH((k_project<2, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (nv == 2 && stream) GS2M_LAUNCH((k_project<2, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (nv == 2) GS2M_LAUNCH((k_project<2, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (dma) GS2M_LAUNCH((k_project<1, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    if (host_cams) {
+        // pipeline-level API: the uniforms of the nv * pairs views travel in the launch packet (k_project_hc stores them to
+        // `cams` for the later kernels of the pass)
+        CamUniformArg a;
+        const int n_views = nv * pairs;
+        for (int k = 0; k < GS2M_MAX_PASS_VIEWS; ++k) a.c[k] = host_cams[k < n_views ? k : 0];
+        if (nv == 2 && dma) GS2M_LAUNCH((k_project_hc<2, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        else if (nv == 2 && stream) GS2M_LAUNCH((k_project_hc<2, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        else if (nv == 2) GS2M_LAUNCH((k_project_hc<2, false, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        else if (dma) GS2M_LAUNCH((k_project_hc<1, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        else if (stream) GS2M_LAUNCH((k_project_hc<1, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        else GS2M_LAUNCH((k_project_hc<1, false, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        return;
+    }
+    // operator-level API (one view, uniforms written to `cams` by k_pack_camera from the caller's device tensors)
+    if (dma) GS2M_LAUNCH((k_project<1, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
     else if (stream) GS2M_LAUNCH((k_project<1, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
     else GS2M_LAUNCH((k_project<1, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
 }
@@ -106,10 +116,4 @@ void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const f
                              float tanfovy, int W, int H, int th) {
     GS2M_LAUNCH(k_pack_camera, dim3(1), dim3(64), 0, st, cams, slot, viewmatrix, projmatrix, campos, bg, tanfovx,
                 tanfovy, W, H, th);
-}
-
-void gs2m_launch_set_cameras(hipStream_t st, CamUniform* cams, int n, const CamUniform* c) {
-    CamUniformArg a;
-    for (int k = 0; k < GS2M_MAX_PASS_VIEWS; ++k) a.c[k] = c[k < n ? k : 0];
-    GS2M_LAUNCH(k_set_cameras, dim3(1), dim3(64), 0, st, cams, n, a);
 }

@@ -19,69 +19,17 @@
 // (L2-resident) and writes the running prefix.  16 segments: a thread's dependent chain is ~15 rows for the usual
 // ~256-row matrix (4 segments of 256-thread workgroups left the kernel latency-bound at 120 workgroups).
 #define GS2M_COLSCAN_SEGS 16
-GS2M_KERNEL void __launch_bounds__(64 * GS2M_COLSCAN_SEGS)
-k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count) {
-    __shared__ unsigned seg_sum[GS2M_COLSCAN_SEGS][64];
-    const int lane = (int)(threadIdx.x & 63u), seg = (int)(threadIdx.x >> 6);
-    const int t = (int)blockIdx.x * 64 + lane;
-    const int v = (int)blockIdx.y;
-    const int per = (n_wg + GS2M_COLSCAN_SEGS - 1) / GS2M_COLSCAN_SEGS;
-    const int w0 = seg * per < n_wg ? seg * per : n_wg;
-    const int w1 = w0 + per < n_wg ? w0 + per : n_wg;
-    unsigned* col = hist + (size_t)v * n_wg * tiles + t;
-    unsigned s = 0;
-    if (t < tiles) {
-        int w = w0;
-        for (; w + 8 <= w1; w += 8) {
-            unsigned x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(w + u) * tiles];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += x[u];
-        }
-        for (; w < w1; ++w) s += col[(size_t)w * tiles];
-    }
-    seg_sum[seg][lane] = s;
-    __syncthreads();
-    if (t < tiles) {
-        unsigned run = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < GS2M_COLSCAN_SEGS; ++k) {
-            const unsigned x = seg_sum[k][lane];
-            run += k < seg ? x : 0u;
-            total += x;
-        }
-        int w = w0;
-        for (; w + 8 <= w1; w += 8) {
-            unsigned x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(w + u) * tiles];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                col[(size_t)(w + u) * tiles] = run;
-                run += x[u];
-            }
-        }
-        for (; w < w1; ++w) {
-            const unsigned x = col[(size_t)w * tiles];
-            col[(size_t)w * tiles] = run;
-            run += x;
-        }
-        if (seg == 0) tile_count[(size_t)v * tiles + t] = total;
-    }
-}
-
-// Exclusive scan of tile_count over tiles: one 1024-thread workgroup per view.
+// Exclusive scan of tile_count over tiles of view v by ONE 1024-thread workgroup (every thread of it calls this).
 // tile_start[v][0..tiles]; status[v] = {N, N > cap}; sticky = {max N, any N > cap} since the last status query.
-GS2M_KERNEL void __launch_bounds__(1024)
-k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles, int gx,
-            ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap, unsigned* __restrict__ sort_lists) {
+// Round 4: no launch of its own any more -- the LAST workgroup of k_hist_colscan to finish a view runs it (below).
+GS2M_DEVICE void tile_scan_view(const int v, const int n_views, const unsigned* tile_count, unsigned* __restrict__ tile_start,
+                                int tiles, int gx, ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap,
+                                unsigned* __restrict__ sort_lists) {
     __shared__ unsigned part[16];    // wave totals of the scan
     __shared__ unsigned n_class[GS2M_SORT_CLASSES];
     __shared__ unsigned w_pos[64];   // compositing schedule: 64 weight buckets of the list chunks
     __shared__ unsigned w_max;       // heaviest chunk of the view
     const int tid = (int)threadIdx.x;
-    const int v = (int)blockIdx.x;
     const unsigned* cnt = tile_count + (size_t)v * tiles;
     unsigned* start = tile_start + (size_t)v * (tiles + 1);
     const int per = (tiles + 1023) / 1024;
@@ -131,7 +79,7 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
     // share Gaussians: one L2), the chunks are ranked by descending weight (64 buckets up to the heaviest) and dealt to the
     // XCDs round-robin: rank p goes to XCD p % 8 as its (p / 8)-th chunk (block b runs on XCD b % 8 and blocks are
     // dispatched in order) -- every XCD gets the same share of heavy chunks and ends on its lightest ones.
-    unsigned* order = sort_lists + (size_t)gridDim.x * GS2M_SORT_CLASSES * (tiles + 1) + (size_t)v * tiles;
+    unsigned* order = sort_lists + (size_t)n_views * GS2M_SORT_CLASSES * (tiles + 1) + (size_t)v * tiles;
     const int lrows = tiles / gx;                                               // rows of lists
     const int cpr = (gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW;                   // chunks per chunk row
     const int nch = cpr * ((lrows + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);       // chunks
@@ -177,17 +125,83 @@ k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile
         for (int c = tid + 2048; c < nch; c += 1024) order[c] = (unsigned)c;
     if (tid < GS2M_SORT_CLASSES) {   // complete: every thread passed the scan's barriers
         lists[tid * (tiles + 1)] = n_class[tid];
-        status[v].n_class[tid] = n_class[tid];   // read back with the status: sizes the next call's class grids (a hint)
+        status->n_class[tid] = n_class[tid];   // read back with the status: sizes the next call's class grids (a hint)
     }
     if (tid == 1023) {
         const unsigned total = total_all;
         start[tiles] = total;
-        status[v].num_rendered = total;
-        status[v].overflow = total > cap ? 1u : 0u;
+        status->num_rendered = total;
+        status->overflow = total > cap ? 1u : 0u;
         // sticky word of the handle: survives later calls until gs2m_raster_status consumes it
         if (total > cap) atomicOr(&sticky->overflow, 1u);
         atomicMax(&sticky->num_rendered, total);
     }
+}
+
+GS2M_KERNEL void __launch_bounds__(64 * GS2M_COLSCAN_SEGS)
+k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count, unsigned* __restrict__ done,
+               unsigned* __restrict__ tile_start, int gx, ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap,
+               unsigned* __restrict__ sort_lists) {
+    __shared__ unsigned seg_sum[GS2M_COLSCAN_SEGS][64];
+    __shared__ unsigned s_last;
+    const int lane = (int)(threadIdx.x & 63u), seg = (int)(threadIdx.x >> 6);
+    const int t = (int)blockIdx.x * 64 + lane;
+    const int v = (int)blockIdx.y;
+    const int per = (n_wg + GS2M_COLSCAN_SEGS - 1) / GS2M_COLSCAN_SEGS;
+    const int w0 = seg * per < n_wg ? seg * per : n_wg;
+    const int w1 = w0 + per < n_wg ? w0 + per : n_wg;
+    unsigned* col = hist + (size_t)v * n_wg * tiles + t;
+    unsigned s = 0;
+    if (t < tiles) {
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            unsigned x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(w + u) * tiles];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += x[u];
+        }
+        for (; w < w1; ++w) s += col[(size_t)w * tiles];
+    }
+    seg_sum[seg][lane] = s;
+    __syncthreads();
+    if (t < tiles) {
+        unsigned run = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < GS2M_COLSCAN_SEGS; ++k) {
+            const unsigned x = seg_sum[k][lane];
+            run += k < seg ? x : 0u;
+            total += x;
+        }
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            unsigned x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = col[(size_t)(w + u) * tiles];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                col[(size_t)(w + u) * tiles] = run;
+                run += x[u];
+            }
+        }
+        for (; w < w1; ++w) {
+            const unsigned x = col[(size_t)w * tiles];
+            col[(size_t)w * tiles] = run;
+            run += x;
+        }
+        if (seg == 0) tile_count[(size_t)v * tiles + t] = total;
+    }
+    // The tile scan of a view needs every column total of it: the workgroup that finishes the view LAST runs it (release:
+    // the totals of this workgroup are visible device-wide before its ticket; acquire: the last one sees all of them).  One
+    // launch and one launch gap less on the critical chain of every pass (round 3: k_tile_scan 10.6 us + the gap).
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&done[v], 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0u) return;
+    __threadfence();
+    if (threadIdx.x == 0) done[v] = 0u;   // ready for the next pass on this handle
+    tile_scan_view(v, (int)gridDim.y, tile_count, tile_start, tiles, gx, status + v, sticky, cap, sort_lists);
 }
 
 // ---- register-blocked bitonic sort -----------------------------------------------------------
@@ -438,7 +452,7 @@ GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int
 template <int WPB>
 GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
-                   unsigned cap, int bucket) {
+                   unsigned cap) {
     __shared__ unsigned long long s_key_all[WPB][GS2M_SORT_WAVE];
     __shared__ unsigned s_cnt_all[WPB][GS2M_SORT_WAVE / 2 + 2];
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -455,11 +469,11 @@ k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __rest
     unsigned long long* kv = keys + (size_t)v * cap + b;
     if (n <= 64) sort_wave_regs<1>(kv, n, lane);
     else if (n <= 128) {
-        if (!(bucket && sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<2>(kv, n, lane);
+        if (!(sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<2>(kv, n, lane);
     } else if (n <= 256) {
-        if (!(bucket && sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<4>(kv, n, lane);
+        if (!(sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<4>(kv, n, lane);
     } else {
-        if (!(bucket && sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<8>(kv, n, lane);
+        if (!(sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<8>(kv, n, lane);
     }
 }
 
@@ -686,16 +700,14 @@ GS2M_DEVICE void sort_tiles_bucket_body(unsigned long long* __restrict__ keys, c
     }
 }
 // The occupancy attribute (a literal: it takes no template argument) makes the residency the LDS allows real: 4 workgroups
-// of the <4096> class, 2 of the <8192> class per CU = 4 waves per SIMD with 16 keys per thread (128 registers), 8 with 8 keys
-// per thread (64 registers).
+// of the <4096> class, 2 of the <8192> class per CU = 8 waves per SIMD with 8 keys per thread (64 registers; 16 keys per
+// thread = 4 waves per SIMD measured slower in round 3 and was removed).
 #define GS2M_SORT_BUCKET_KERNEL(NAME, CAP, THREADS, CLS, WAVES)                                                           \
     GS2M_KERNEL void __launch_bounds__(THREADS) GS2M_WAVES_PER_SIMD(WAVES)                                                      \
     NAME(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles, unsigned cap,        \
          const unsigned* __restrict__ sort_lists) {                                                                      \
         sort_tiles_bucket_body<CAP, THREADS, CLS>(keys, tile_start, tiles, cap, sort_lists);                              \
     }
-GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_4096x16, 4096, 256, 0, 4)
-GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_8192x16, 8192, 512, 1, 4)
 GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_4096x8, 4096, 512, 0, 8)
 GS2M_SORT_BUCKET_KERNEL(k_sort_tiles_bucket_8192x8, 8192, 1024, 1, 8)
 
@@ -774,9 +786,12 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
 // kernels carry 40-80 KiB of static LDS per workgroup; under the pipelined load (a compositing grid of another stream holds
 // 157 of the 160 KiB of every CU) even their EMPTY launches waited 30-40 us each for a CU with room -- three times per view
 // on the critical chain of its slot (kernel trace, round 3).  This kernel needs no LDS, so its 256-thread workgroups are
-// placed at once.  It is not a hint-dependent shortcut: if the view DOES have larger lists it sorts them, slowly but
-// exactly -- rank sort through `tmp` (keys are unique: rank = number of smaller keys = final position; the list is
-// L1 / L2 resident and a workgroup only re-reads what its own threads wrote, visible after the workgroup barrier).
+// placed at once.  It is not a hint-dependent shortcut: the hint may be stale (scene or camera change, status copy not yet
+// landed), so if the view DOES have larger lists it sorts them, exactly and in bounded time -- runs of 256 keys by rank
+// (keys are unique: rank = number of smaller keys of the run = position in the run), then rank-merge passes between `keys`
+// and `tmp` as in k_sort_tiles: O(256 n + n log^2 n) instead of the O(n^2) of a rank sort over the whole list (a stale hint
+// on a C3-like view used to cost milliseconds).  The lists are L1 / L2 resident and a workgroup only re-reads what its own
+// threads wrote, visible after the workgroup barrier.
 GS2M_KERNEL void __launch_bounds__(256)
 k_sort_tiles_rank(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
                   const unsigned* __restrict__ tile_start, int tiles, unsigned cap, const unsigned* __restrict__ sort_lists) {
@@ -794,14 +809,52 @@ k_sort_tiles_rank(unsigned long long* __restrict__ keys, unsigned long long* __r
             const int n = (int)(e - b);
             unsigned long long* kv = keys + (size_t)v * cap + b;
             unsigned long long* tv = tmp + (size_t)v * cap + b;
-            for (int i = tid; i < n; i += 256) {
-                const unsigned long long key = kv[i];
-                int rank = 0;
-                for (int j = 0; j < n; ++j) rank += kv[j] < key ? 1 : 0;
-                tv[rank] = key;
+            // runs of 256 keys, each sorted by rank into tmp
+            for (int r0 = 0; r0 < n; r0 += 256) {
+                const int rn = n - r0 < 256 ? n - r0 : 256;
+                if (tid < rn) {
+                    const unsigned long long key = kv[r0 + tid];
+                    int rank = 0;
+                    for (int j = 0; j < rn; ++j) rank += kv[r0 + j] < key ? 1 : 0;
+                    tv[r0 + rank] = key;
+                }
             }
             __syncthreads();
-            for (int i = tid; i < n; i += 256) kv[i] = tv[i];
+            unsigned long long* src = tv;
+            unsigned long long* dst = kv;
+            for (int w = 256; w < n; w <<= 1) {
+                for (int i = tid; i < n; i += 256) {
+                    const int blk = i / (2 * w);
+                    const int a0 = blk * 2 * w;
+                    const int a1 = a0 + w < n ? a0 + w : n;            // A = [a0,a1)
+                    const int b1 = a0 + 2 * w < n ? a0 + 2 * w : n;    // B = [a1,b1)
+                    const unsigned long long key = src[i];
+                    int lo, hi, base;
+                    if (i < a1) {  // element of A: count of B elements smaller than key
+                        lo = a1;
+                        hi = b1;
+                        base = i - a0;
+                    } else {
+                        lo = a0;
+                        hi = a1;
+                        base = i - a1;
+                    }
+                    const int lo0 = lo;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (src[mid] < key) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    dst[a0 + base + (lo - lo0)] = key;
+                }
+                __syncthreads();
+                unsigned long long* x = src;
+                src = dst;
+                dst = x;
+            }
+            if (src != kv) {
+                for (int i = tid; i < n; i += 256) kv[i] = src[i];
+            }
             __syncthreads();
         }
     }

@@ -365,7 +365,7 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
 }
 
 // k_tsdf_integrate_batch: the frames of a batch in ONE sweep over the touched blocks, voxel-stationary (SURVEY.md 7,
-// step 6 iii).  A 1024-thread workgroup owns a block; thread (zq, x, y) keeps the state of the 4 voxels
+// step 6 iii).  A 256-thread workgroup owns a z-quarter zq of a block; thread (x, y) keeps the state of the 4 voxels
 // (x, y, 4 zq .. 4 zq + 3) in registers (20 words), walks the frames that touched the block IN FRAME ORDER (bit f of the
 // block's frame mask; Open3D integrates a block for a frame only if that frame's points touch it) and applies exactly the
 // per-frame update (same fp32 sequence, same incremental z chain: a thread replays the 4 zq steps below its run once per
@@ -373,21 +373,19 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
 // per-frame kernel: the voxel state is read and written once per batch instead of once per frame (40 B x updated voxels
 // x frames -> 20 B x voxels of touched blocks), 4.5 instead of ~22 replayed additions per voxel and frame, the distance
 // multiplier (a correctly rounded sqrt) only where a depth sample exists, frame uniforms by scalar loads.
-// NZQ = z-quarters of a block per workgroup: 4 = one 1024-thread workgroup per block (94 VGPRs: one 16-wave workgroup per
-// CU = 4 waves per SIMD); 1 (default since round 3) = one 256-thread workgroup per (block, quarter): 88 VGPRs admit 5 such
-// workgroups per CU, the work items are four times finer for the dynamic hand-out, zq (and with it the replay loop of the z
-// chain) is wave-uniform, and the block's frame mask is cleared by k_tsdf_clear_fmask afterwards (the four quarters of a block
-// run on different workgroups).  C2: 39.2 -> 32.7 us per frame in sweeps of 10, 36.9 -> 29.7 in sweeps of 24; forcing 6 / 7
-// waves per SIMD (80 / 72 VGPRs, spills) gains nothing (32.9 / 35.7).  Same arithmetic per voxel: bit-identical.
-template <int NZQ>
-GS2M_KERNEL void __launch_bounds__(256 * NZQ)
+// One 256-thread workgroup per (block, z-quarter) (round 3; the round-2 form, one 1024-thread workgroup per block at 94 VGPRs =
+// 4 waves per SIMD, was removed in round 4): 88 VGPRs admit 5 such workgroups per CU, the work items are four times finer for
+// the dynamic hand-out, zq (and with it the replay loop of the z chain) is wave-uniform, and the block's frame mask is cleared
+// by k_tsdf_clear_fmask afterwards (the four quarters of a block run on different workgroups).  C2: 39.2 -> 32.7 us per frame
+// in sweeps of 10, 36.9 -> 29.7 in sweeps of 24; forcing 6 / 7 waves per SIMD (80 / 72 VGPRs, spills) gains nothing (32.9 /
+// 35.7).  Same arithmetic per voxel: bit-identical.
+GS2M_KERNEL void __launch_bounds__(256)
 k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) {
     __shared__ float s_p0[16], s_p1[16];
     const int tid = (int)threadIdx.x;
-    int zq = tid >> 8;
     const int x = (tid >> 4) & 15, y = tid & 15;
     __shared__ unsigned s_it;
-    const unsigned n_touched = V.counters[1] * (NZQ == 4 ? 1u : 4u);   // work items
+    const unsigned n_touched = V.counters[1] * 4u;   // work items: (block, z-quarter)
     const TsdfFrame& f0 = frames[0].f;   // volume constants (voxel length, truncation) are the same in every frame
     for (;;) {
         // blocks are handed out dynamically (counters[3], zeroed before the launch): a block costs as many frame passes as
@@ -397,15 +395,12 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
         __syncthreads();
         const unsigned it = s_it;
         if (it >= n_touched) break;
-        if (NZQ != 4) zq = (int)(it & 3u);
-        const unsigned h = V.touched[NZQ == 4 ? it : it >> 2];
+        const int zq = (int)(it & 3u);
+        const unsigned h = V.touched[it >> 2];
         const unsigned long long key = V.hash_keys[h];
         const int slot = V.hash_vals[h];
         const unsigned long long fm = V.fmask[h];
-        if (slot < 0) {   // pool overflow (flagged); uniform across the workgroup
-            if (NZQ == 4 && tid == 0) V.fmask[h] = 0ull;
-            continue;
-        }
+        if (slot < 0) continue;   // pool overflow (flagged); uniform across the workgroup
         const int bx = (int)((key >> 42) & 0x1fffffull) - GS2M_TSDF_KEY_BIAS;
         const int by = (int)((key >> 21) & 0x1fffffull) - GS2M_TSDF_KEY_BIAS;
         const int bz = (int)(key & 0x1fffffull) - GS2M_TSDF_KEY_BIAS;
@@ -562,10 +557,7 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                 bc[2 * GS2M_TSDF_VOX + vi0 + 16 * j] = c2[j];
             }
         }
-        if (tid == 0 && (NZQ == 4 || zq == 0)) {
-            atomicAdd(&V.totals[0], (unsigned long long)gs2m_popc64(fm));   // block updates = sum over frames of touched blocks
-            if (NZQ == 4) V.fmask[h] = 0ull;                                 // ready for the next batch
-        }
+        if (tid == 0 && zq == 0) atomicAdd(&V.totals[0], (unsigned long long)gs2m_popc64(fm));   // block updates = sum over frames of touched blocks
     }
 }
 
@@ -635,6 +627,10 @@ k_tsdf_pack(TsdfVolume V, const int* __restrict__ keys, float* __restrict__ buf,
         }
         o[i] = t;
         if (FORM == GS2M_XF_SUM_PACKED) {
+            // the fields only stay apart under an integer SUM while w < 2^10 and the colour sums < 2^18 IN THE RESULT; a
+            // local value that already exceeds its field is flagged (status bit 8): the caller's frame bound was wrong
+            // (state injected through unpack, C-API users) -- checked by gs2mesh_amd.parallel after the exchange
+            if (w > 1023.0f || ((c0 | c1 | c2) >> 18) != 0u) atomicOr(&V.counters[2], 8u);
             ibuf[b * GS2M_TSDF_VOX + i] = (long long)((unsigned long long)(unsigned)w | ((unsigned long long)c0 << 10) |
                                                       ((unsigned long long)c1 << 28) | ((unsigned long long)c2 << 46));
         } else {

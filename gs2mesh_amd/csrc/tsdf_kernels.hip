@@ -3,7 +3,6 @@
 #include "tsdf_extract.h"
 #include "tsdf_internal.h"
 #include <math.h>
-#include <cstdlib>
 
 void gs2m_launch_tsdf_touch(hipStream_t st, const TsdfVolume& V, const TsdfFrame& f, const float* depth,
                             const unsigned char* mask) {
@@ -22,13 +21,8 @@ void gs2m_launch_tsdf_touch_batch(hipStream_t st, const TsdfVolume& V, const Tsd
     GS2M_LAUNCH(k_tsdf_compact, dim3((V.hash_cap + 1023u) / 1024u), dim3(1024), 0, st, V, 0u);
 }
 void gs2m_launch_tsdf_integrate_batch(hipStream_t st, int n_cu, const TsdfVolume& V, const TsdfBatchFrame* frames) {
-    static const int quarter = getenv("GS2M_TSDF_QUARTER") ? atoi(getenv("GS2M_TSDF_QUARTER")) : 1;   // 0 = the 1024-thread kernel of round 2
-    if (quarter) {
-        GS2M_LAUNCH((k_tsdf_integrate_batch<1>), dim3(n_cu * 6), dim3(256), 0, st, V, frames);
-        GS2M_LAUNCH(k_tsdf_clear_fmask, dim3(16), dim3(256), 0, st, V);
-    } else {
-        GS2M_LAUNCH((k_tsdf_integrate_batch<4>), dim3(n_cu * 2), dim3(1024), 0, st, V, frames);
-    }
+    GS2M_LAUNCH(k_tsdf_integrate_batch, dim3(n_cu * 6), dim3(256), 0, st, V, frames);
+    GS2M_LAUNCH(k_tsdf_clear_fmask, dim3(16), dim3(256), 0, st, V);
 }
 void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V) {
     GS2M_LAUNCH(k_tsdf_clear_used, dim3(2048), dim3(256), 0, st, V);

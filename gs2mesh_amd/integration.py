@@ -92,7 +92,11 @@ class ScalableTSDFVolume:
                                               self.max_blocks, int(device)), self._lib)
         self._h = h
         self._keep = []  # uploaded frames stay alive until the next synchronising call
-        self.frames_integrated = 0   # frames this volume's state carries (bounds every weight: the packed exchange form needs it)
+        # frames this volume's state carries = an upper bound of every voxel weight (the packed exchange form needs it):
+        # `frames_base` = bound inherited from a reduction / injected state, `frames_local` = frames integrated here since
+        self.frames_base = 0
+        self.frames_local = 0
+        self.replicated = False      # the state is the all-reduced volume (every rank holds it: summing it again would count it R times)
         self._xbuf = {}              # persistent, grow-only exchange buffers (gs2mesh_amd.parallel)
 
     def close(self):
@@ -108,7 +112,12 @@ class ScalableTSDFVolume:
 
     def reset(self, stream=None):
         _lib.check(self._lib.gs2m_tsdf_reset(self._h, stream or C.c_void_p(0)), self._lib)
-        self.frames_integrated = 0
+        self.frames_base = self.frames_local = 0
+        self.replicated = False
+
+    @property
+    def frames_integrated(self):
+        return self.frames_base + self.frames_local
 
     def exchange_buffer(self, name, shape, dtype, device):
         """A persistent, grow-only device buffer owned by the volume (the multi-GPU reduction re-uses its pack / receive
@@ -163,7 +172,7 @@ class ScalableTSDFVolume:
             self._h, _ptr(depth), _ptr(color), _ptr(msk), W, H, intrinsic.fx, intrinsic.fy, intrinsic.cx,
             intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)), float(image.depth_scale),
             float(image.depth_trunc), float(min_depth), st), self._lib)
-        self.frames_integrated += 1
+        self.frames_local += 1
         if ours:
             self._keep.append(ours)
             if len(self._keep) > 64:
@@ -202,7 +211,7 @@ class ScalableTSDFVolume:
             self._h, n, dp, cp if has_color else None, mp if masks is not None else None, intrinsic.width, intrinsic.height,
             intrinsic.fx, intrinsic.fy, intrinsic.cx, intrinsic.cy, E.ctypes.data_as(C.POINTER(C.c_double)),
             float(images[0].depth_scale), float(images[0].depth_trunc), float(min_depth), st), self._lib)
-        self.frames_integrated += n
+        self.frames_local += n
         self._keep.append(keep)      # the frames stay alive until the next synchronising call
         if len(self._keep) > 64:
             self.status(stream)
@@ -216,7 +225,8 @@ class ScalableTSDFVolume:
         self._keep.clear()
         if ov.value and raise_on_overflow:
             what = [n for b, n in ((1, "block pool exhausted (raise max_blocks)"), (2, "hash table full"),
-                                   (4, "block index out of the +-2^20 range")) if ov.value & b]
+                                   (4, "block index out of the +-2^20 range"),
+                                   (8, "a voxel did not fit the packed exchange form (weight > 1023: use payload='f32')")) if ov.value & b]
             raise RuntimeError("TSDF volume overflow: " + ", ".join(what))
         return int(nb.value), int(bu.value), int(ov.value)
 
@@ -295,20 +305,31 @@ class ScalableTSDFVolume:
         _lib.check(self._lib.gs2m_tsdf_pack(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
                                             _stream_of(keys, stream)), self._lib)
 
-    def unpack(self, keys, form, buf_f32, buf_i64=None, halo=False, stream=None):
-        """``gs2m_tsdf_unpack``: replace the state of the blocks ``keys`` from buffers in exchange form ``form``."""
+    def unpack(self, keys, form, buf_f32, buf_i64=None, halo=False, stream=None, frames=None):
+        """``gs2m_tsdf_unpack``: replace the state of the blocks ``keys`` from buffers in exchange form ``form``.
+        ``frames`` = upper bound of the weights being injected (the number of frames that state carries); without it the
+        volume no longer qualifies for the packed exchange form (the bound is unknown), halo copies excepted (they are
+        never summed)."""
         n = int(keys.shape[0])
         _lib.check(self._lib.gs2m_tsdf_unpack(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
                                               int(bool(halo)), _stream_of(keys, stream)), self._lib)
+        if not halo:
+            self._inherit(frames)
+
+    def _inherit(self, frames):
+        bound = int(frames) if frames is not None else _lib.XFORM_PACKED_MAX_FRAMES + 1
+        self.frames_base = max(self.frames_base, bound)
 
     def pack_sum(self, keys, buf, stream=None):
         """``gs2m_tsdf_pack_sum``: accumulators of the blocks ``keys`` [n,3] in sum form -> ``buf`` [n,5,4096] f32."""
         n = int(keys.shape[0])
         _lib.check(self._lib.gs2m_tsdf_pack_sum(self._h, _ptr(keys), n, _ptr(buf), _stream_of(keys, stream)), self._lib)
 
-    def unpack_sum(self, keys, buf, halo=False, stream=None):
+    def unpack_sum(self, keys, buf, halo=False, stream=None, frames=None):
         """``gs2m_tsdf_unpack_sum``: replace the state of the blocks ``keys`` by ``buf`` (tsdf = wsum / weight);
-        ``halo`` = neighbour-only blocks (read by the mesh extraction, never the base of a cube)."""
+        ``halo`` = neighbour-only blocks (read by the mesh extraction, never the base of a cube); ``frames`` as in `unpack`."""
         n = int(keys.shape[0])
         _lib.check(self._lib.gs2m_tsdf_unpack_sum(self._h, _ptr(keys), n, _ptr(buf), int(bool(halo)),
                                                   _stream_of(keys, stream)), self._lib)
+        if not halo:
+            self._inherit(frames)

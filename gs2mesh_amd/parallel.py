@@ -38,7 +38,8 @@ import torch.distributed as dist
 
 _SENTINEL = (1 << 20) - 1          # block index nobody owns (outside the +-2^20 key range of the volume)
 _OVERFLOW_TEXT = ((1, "block pool exhausted (raise max_blocks)"), (2, "hash table full"),
-                  (4, "block index out of the +-2^20 range"))
+                  (4, "block index out of the +-2^20 range"),
+                  (8, "a voxel did not fit the packed exchange form (weight > 1023 or colour sum >= 2^18)"))
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -73,14 +74,18 @@ def _as_tensor(keys):
 
 def canonical_keys(volume, group=None, always_collective: bool = False):
     """Union of the block keys of all ranks in canonical order, on the local device, + the OR of the ranks'
-    overflow flags + the number of frames all ranks integrated.  One fixed-size all_gather (persistent buffers);
-    one host read (of the gathered header rows).  Halo copies held by a volume are not its blocks (sentinel keys)."""
+    overflow flags + an upper bound of every voxel weight of the SUM over the ranks + whether any rank holds an already
+    all-reduced (replicated) state.  One fixed-size all_gather (persistent buffers); one host read (of the gathered header
+    rows).  Halo copies held by a volume are not its blocks (sentinel keys).
+    Weight bound: a rank's state = a part it inherited (`frames_base`: a reduce-scatter leaves the ranks with DISJOINT parts
+    of one reduced volume, so across ranks the inherited bounds do not add up -- their maximum holds) + the frames it
+    integrated since (`frames_local`: these do add up)."""
     keys = _as_tensor(volume.block_keys(raise_on_overflow=False))
     _, _, ov = volume.status(raise_on_overflow=False)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     collective = world > 1 or (always_collective and dist.is_initialized())
     if not collective:
-        return _lex_unique(keys[keys[:, 0] != _SENTINEL]), int(ov), 0, int(volume.frames_integrated)
+        return _lex_unique(keys[keys[:, 0] != _SENTINEL]), int(ov), 0, int(volume.frames_integrated), False
     K = int(volume.max_blocks)
     n_local = int(keys.shape[0])
     buf = volume.exchange_buffer("keys_send", (K + 2, 3), torch.int32, keys.device)
@@ -89,7 +94,9 @@ def canonical_keys(volume, group=None, always_collective: bool = False):
     buf[K, 0] = n_local
     buf[K, 1] = int(ov)
     buf[K, 2] = K
-    buf[K + 1, 0] = int(volume.frames_integrated)
+    buf[K + 1, 0] = int(volume.frames_local)
+    buf[K + 1, 1] = int(volume.frames_base)
+    buf[K + 1, 2] = int(bool(volume.replicated))
     gathered = volume.exchange_buffer("keys_recv", (world * (K + 2), 3), torch.int32, keys.device)
     dist.all_gather_into_tensor(gathered, buf, group=group)
     g = gathered.view(world, K + 2, 3)
@@ -99,10 +106,11 @@ def canonical_keys(volume, group=None, always_collective: bool = False):
     ov_any = 0
     for f in head[:, 0, 1].tolist():
         ov_any |= int(f)
-    frames_total = int(head[:, 1, 0].sum())
+    frames_total = int(head[:, 1, 0].sum()) + int(head[:, 1, 1].max())
+    replicated = bool(int(head[:, 1, 2].max())) and world > 1
     body = g[:, :K, :].reshape(-1, 3)
     valid = body[:, 0] != _SENTINEL
-    return _lex_unique(body[valid]), ov_any, 1, frames_total
+    return _lex_unique(body[valid]), ov_any, 1, frames_total, replicated
 
 
 def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_collective: bool = False,
@@ -123,7 +131,11 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if mode not in ("reduce_scatter", "allreduce") or payload not in ("auto", "packed", "f32") or algo not in ("rccl", "direct"):
         raise ValueError((mode, payload, algo))
-    keys, ov_any, n_coll, frames_total = canonical_keys(volume, group, always_collective)
+    keys, ov_any, n_coll, frames_total, replicated = canonical_keys(volume, group, always_collective)
+    if replicated:
+        # identical on every rank (it travelled in the gathered header): all of them raise
+        raise RuntimeError("reduce_volume: a rank holds an all-reduced (replicated) volume -- summing it again would count its "
+                           "frames once per rank; reset() it, or reduce with mode='reduce_scatter' between rounds")
     if ov_any:
         # every rank sees the same flags after the key exchange: all of them raise, nobody waits in a collective
         what = [n for b, n in _OVERFLOW_TEXT if ov_any & b]
@@ -182,13 +194,21 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
             if packed:
                 dist.all_reduce(ibuf, op=dist.ReduceOp.SUM, group=group)
                 n_coll += 1
+    if packed:
+        # device-side check of the packed form (k_tsdf_pack): a local weight / colour sum that did not fit its field means the
+        # frame bound was wrong (state injected through the C API).  Checked AFTER the collectives, so that a rank that
+        # raises leaves nobody waiting in one.
+        _, _, ov_pack = volume.status(raise_on_overflow=False)
+        if ov_pack & 8:
+            raise RuntimeError("reduce_volume: " + _OVERFLOW_TEXT[3][1] + " -- the reduced buffers are invalid; use payload='f32'")
     # replace the local state by the reduced blocks (reset only clears the slots in use)
     volume.reset()
     cnt = max(0, hi - lo)
     if cnt:
-        volume.unpack(kpad[:cnt].contiguous(), form, fbuf[:cnt], ibuf[:cnt] if packed else None)
+        volume.unpack(kpad[:cnt].contiguous(), form, fbuf[:cnt], ibuf[:cnt] if packed else None, frames=frames_total)
     volume.status()
-    volume.frames_integrated = frames_total          # every weight of the reduced state is bounded by the total
+    volume.frames_base, volume.frames_local = frames_total, 0     # every weight of the reduced state is bounded by the total
+    volume.replicated = collective and not scatter and world > 1
     return dict(n_blocks_union=n, bytes_per_rank=nbytes, keys=keys, owned=(lo, hi), collectives=n_coll, mode=mode,
                 per=(n_pad // world if scatter else n), seconds=time.perf_counter() - t0,
                 payload=("packed" if packed else "f32"), algo=(algo if scatter else "rccl"), frames_total=frames_total)

@@ -25,12 +25,16 @@ from .rasterizer import Rasterizer
 
 
 class RenderFusePipeline:
-    def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None,
-                 intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0,
-                 exact_tile_cull: int = 1, blend_variant: int | None = None, tile_rows: int = 2, bg=(0.0, 0.0, 0.0),
-                 lib=None, fuse_batch: int = 1, spatial_order="auto", blend_cus: int = 0, blend_streams: int = 2,
-                 bin_cus: str = "all", fuse_cus: str = "all", blend_wg_per_cu: int = 0, blend_stream_plain: bool = False,
-                 layout: str = "per_slot", bin_streams: int = 1, pairs_per_launch: int = 1):
+    """``raster_options``: ``gs2m_raster_set_option`` values of every slot's handle, by name -- ``exact_tile_cull`` (default 1),
+    ``tile_rows`` (default 2: 16 x 32 binning tiles, same image, fewer instances), ``blend_variant``."""
+
+    RASTER_OPTION_IDS = dict(exact_tile_cull=_lib.OPT_EXACT_TILE_CULL, tile_rows=_lib.OPT_TILE_ROWS,
+                             blend_variant=_lib.OPT_BLEND_VARIANT, blend_mode=_lib.OPT_BLEND_MODE,
+                             bin_workgroups=_lib.OPT_BIN_WORKGROUPS, bin_wg_threads=_lib.OPT_BIN_WG_THREADS)
+
+    def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None = None,
+                 intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0, fuse_batch=1,
+                 pairs_per_launch: int = 1, spatial_order="auto", bg=(0.0, 0.0, 0.0), raster_options: dict | None = None):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
         self.g = gaussians
@@ -46,22 +50,24 @@ class RenderFusePipeline:
         self.inflight = int(inflight)
         # pairs_per_launch = 2 (GS2M_OPT_PAIR_BATCH): two consecutive stereo pairs go through ONE chain of launches (`submit`
         # buffers the first, the second triggers the launch; `drain` flushes an odd one).  Batched fusion only.
-        self.ppl = int(pairs_per_launch) if self.inflight > 1 else 1
+        self.ppl = int(pairs_per_launch)
         if self.ppl not in (1, 2):
             raise ValueError("pairs_per_launch must be 1 or 2")
         self._group = []
         self.device = int(device)
         self.bg = bg
+        opts = dict(exact_tile_cull=1, tile_rows=2)
+        opts.update(raster_options or {})
+        unknown = set(opts) - set(self.RASTER_OPTION_IDS)
+        if unknown:
+            raise ValueError(f"unknown raster_options {sorted(unknown)}; known: {sorted(self.RASTER_OPTION_IDS)}")
         dev = torch.device(f"cuda:{device}")
         self.rasterizers, self.color, self.rgb8, self._own8 = [], [], [], []
         for j in range(self.inflight):
-            r = Rasterizer(device, lib=lib)
-            r.set_option(_lib.OPT_EXACT_TILE_CULL, int(exact_tile_cull))
-            r.set_option(_lib.OPT_TILE_ROWS, int(tile_rows))   # 2 = 16 x 32 binning tiles (same image, fewer instances)
-            if blend_variant is not None:
-                r.set_option(_lib.OPT_BLEND_VARIANT, int(blend_variant))
-            if blend_wg_per_cu:
-                r.set_option(_lib.OPT_BLEND_WG_PER_CU, int(blend_wg_per_cu))
+            r = Rasterizer(device)
+            for name, value in opts.items():
+                if value is not None:
+                    r.set_option(self.RASTER_OPTION_IDS[name], int(value))
             if self.ppl > 1:
                 r.set_option(_lib.OPT_PAIR_BATCH, 1)
             self.rasterizers.append(r)
@@ -69,57 +75,15 @@ class RenderFusePipeline:
             # rgb8[j] = where slot j's latest u8 pair lives (the slot's own buffer, or the pending view's batch buffer)
             self._own8.append(torch.empty((2 * self.ppl, self.H, self.W, 3), dtype=torch.uint8, device=dev))
             self.rgb8.append(self._own8[j])
-        self._masked = []
-        self.blend_cus = 0
-        self.layout = layout if self.inflight > 1 else "per_slot"
-        self._blend_torch = None
-        if self.layout not in ("per_slot", "two_stage"):
-            raise ValueError("layout must be 'per_slot' or 'two_stage'")
         if self.inflight == 1:
             # serial mode: everything on the caller's current stream
             self.render_streams, self.fuse_stream = [None], None
         else:
-            # CU partition (gs2mesh_amd/streams.py): with blend_cus = N (a multiple of 32, < the CU count) the compositing
-            # launches go to `blend_streams` streams masked to CUs [0, N); "rest" puts the binning chains / the TSDF sweeps
-            # on streams masked to the other CUs, "all" leaves them unmasked (they may also use what the compositing
-            # leaves free), fuse_cus = "blend" masks the TSDF stream like the compositing.
-            from .streams import acquire
-            total = torch.cuda.get_device_properties(dev).multi_processor_count
-            self.blend_cus = int(blend_cus) if blend_cus and 0 < int(blend_cus) < total else 0
-            rest = (self.blend_cus, total - self.blend_cus)
-
-            def make(kind):
-                if kind == "all" or (not self.blend_cus and kind != "own"):
-                    return torch.cuda.Stream(device=dev)
-                # "own": every CU, but a stream of its own kind: HIP multiplexes ordinary streams onto GPU_MAX_HW_QUEUES (4)
-                # hardware queues, and a cross-stream wait parked in a shared hardware queue blocks every stream mapped
-                # to it; a CU-masked stream always gets a hardware queue of its own
-                m = acquire(device, {"rest": rest, "own": (0, total)}.get(kind, (0, self.blend_cus)), total, lib=lib)
-                self._masked.append(m)
-                return m.torch
-
-            if self.layout == "two_stage":
-                # TWO-STAGE layout: every binning chain on `bin_streams` shared streams, every compositing launch on ONE
-                # further stream, without the join back (GS2M_OPT_BLEND_JOIN 0): the binning of view i + 1 follows the
-                # binning of view i at once and the compositing stream always has its next launch queued.  Three or four
-                # streams in all = no two of them share one of the 4 hardware queues (cf. per_slot: 6 render streams).
-                bins = [acquire(device, None, total, lib=lib) for _ in range(max(1, int(bin_streams)))]
-                blend = acquire(device, None, total, lib=lib)
-                self._masked += bins + [blend]
-                self.render_streams = [bins[j % len(bins)].torch for j in range(self.inflight)]
-                self._blend_torch = blend.torch
-                for r in self.rasterizers:
-                    r.set_blend_stream(blend.handle)
-                    r.set_option(_lib.OPT_BLEND_JOIN, 0)
-            else:
-                self.render_streams = [make(bin_cus) for _ in range(self.inflight)]
-            self.fuse_stream = make(fuse_cus)
-            if self.layout == "per_slot" and (self.blend_cus or blend_stream_plain):
-                bl = [acquire(device, (0, self.blend_cus) if self.blend_cus else None, total, lib=lib)
-                      for _ in range(max(1, int(blend_streams)))]
-                self._masked += bl
-                for j, r in enumerate(self.rasterizers):
-                    r.set_blend_stream(bl[j % len(bl)].handle)
+            # plain streams: every variant that gave the binning / TSDF kernels CUs, hardware queues or CU-internal room of
+            # their own (CU-masked streams, a separate compositing stream, workgroup caps) was measured slower in round 3
+            # (profiles/r3_partition_sweeps.txt, r3_experiments.txt) and removed in round 4
+            self.render_streams = [torch.cuda.Stream(device=dev) for _ in range(self.inflight)]
+            self.fuse_stream = torch.cuda.Stream(device=dev)
         # fuse_batch > 1: the views are integrated `fuse_batch` at a time by the voxel-stationary batch kernel
         # (gs2m_tsdf_integrate_batch: same result as view by view, one voxel-state read + write per batch).  The left
         # image of every pending view is kept in its own buffer (a slot's image is re-rendered before the batch runs).
@@ -147,6 +111,7 @@ class RenderFusePipeline:
         self._fused = [torch.cuda.Event() for _ in range(self.inflight)]
         self._fused_on = [None] * self.inflight        # the stream _fused[j] was last recorded on
         self._model_seen = [False] * self.inflight     # slot's render stream has waited for the stream the model was produced on
+        self._released = [None] * self.inflight        # `release(slot)`: event after the caller's last read of the slot's images
         self._n = 0
 
     # -- set-up ------------------------------------------------------------------------------------
@@ -162,9 +127,15 @@ class RenderFusePipeline:
                 order = r.pack_model(self.g, order=order)
             else:
                 r.pack_sh(self.g)
-            res = r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j],
+            res = r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j][:2], out_rgb8=self.rgb8[j][:2],
                                  want_radii=(j == 0))
-            r.reserve(int(self.g["xyz"].shape[0]), 2, self.W, self.H, int(max(res["num_rendered"]) * headroom))
+            # every view of a pass gets its own key range: reserve for the 2 * pairs_per_launch views of a launch, and run
+            # one launch of that shape now (the first batched call would otherwise grow keys / records / histogram rows with
+            # hipMalloc + hipFree -- a device-wide sync -- inside the pipelined loop)
+            r.reserve(int(self.g["xyz"].shape[0]), 2 * self.ppl, self.W, self.H, int(max(res["num_rendered"]) * headroom))
+            if self.ppl > 1:
+                r.render_views(self.g, list(cams) * self.ppl, bg=self.bg, out_color=self.color[j], out_rgb8=self._own8[j],
+                               sync=False)
             if j == 0:
                 first = res
         torch.cuda.synchronize(self.device)
@@ -226,8 +197,7 @@ class RenderFusePipeline:
         with torch.cuda.stream(rs):
             if self._fused_on[j] is not rs:
                 rs.wait_event(self._fused[j])      # the view that last used this slot's images is integrated (same-stream order otherwise)
-            if self._blend_torch is not None:
-                r.join(rs.cuda_stream)             # two-stage layout: the slot's previous compositing has read its arenas
+            self._wait_released(j, rs)
             batched = depth is not None and self.fuse_batch > 1
             self.rgb8[j] = self._own8[j]   # fuse-less / view-by-view: the slot's own buffer (ordered by _fused[j] above)
             if batched:
@@ -238,10 +208,9 @@ class RenderFusePipeline:
                     rs.wait_event(self._batch_done[self._bset])
                 self.rgb8[j] = self._bpair[self._bset][k]
             r.render_views(self.g, cams, bg=self.bg, out_color=self.color[j], out_rgb8=self.rgb8[j], sync=False)
-            done_on = self._blend_torch if self._blend_torch is not None else rs      # the stream the images are complete on
-            self._rendered[j].record(done_on)
+            self._rendered[j].record(rs)
             if batched:
-                self._bcopied[self._bset][k].record(done_on)
+                self._bcopied[self._bset][k].record(rs)
         if depth is not None and self.fuse_batch > 1:
             for t in (depth, mask):
                 if torch.is_tensor(t) and t.is_cuda:
@@ -273,6 +242,17 @@ class RenderFusePipeline:
         j = self._n % self.inflight
         self._n += 1
         r = self.rasterizers[j]
+        if self.inflight == 1:
+            # serial mode: the same launches on the caller's current stream
+            k0 = len(self._pending)
+            self.rgb8[0] = self._bflat[self._bset][2 * k0:2 * (k0 + n)]
+            r.render_views(self.g, [c for v in views for c in v[0]], bg=self.bg, out_color=self.color[0][:2 * n],
+                           out_rgb8=self.rgb8[0], sync=False)
+            for i, (_, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth) in enumerate(views):
+                self._pending.append((k0 + i, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
+            if len(self._pending) >= self._plan[self._plan_i % len(self._plan)]:
+                self._flush_batch()
+            return
         cur = torch.cuda.current_stream(self.device)
         rs = self.render_streams[j]
         if not self._model_seen[j]:
@@ -282,6 +262,7 @@ class RenderFusePipeline:
         with torch.cuda.stream(rs):
             if self._fused_on[j] is not rs:
                 rs.wait_event(self._fused[j])
+            self._wait_released(j, rs)
             if self._batch_done[self._bset] is not None:
                 rs.wait_event(self._batch_done[self._bset])
             self.rgb8[j] = self._bflat[self._bset][2 * k0:2 * (k0 + n)]
@@ -328,11 +309,31 @@ class RenderFusePipeline:
             self._batch_done[bset] = torch.cuda.Event()
             self._batch_done[bset].record(fs)
 
-    def wait_rendered(self, slot: int):
+    def wait_rendered(self, slot: int, stream_only: bool = False):
+        """The slot's images are complete: the HOST waits (default), or -- ``stream_only`` -- only the caller's current
+        stream does (work enqueued on it afterwards reads finished images; no host synchronisation)."""
         if self.inflight > 1:
-            self._rendered[slot].synchronize()
-        else:
+            if stream_only:
+                torch.cuda.current_stream(self.device).wait_event(self._rendered[slot])
+            else:
+                self._rendered[slot].synchronize()
+        elif not stream_only:
             torch.cuda.current_stream(self.device).synchronize()
+
+    def release(self, slot: int):
+        """Consumer fence of a slot's output buffers: call on the stream that READ ``color[slot]`` / ``rgb8[slot]`` (e.g. the
+        stereo network consuming the rendered pair) after enqueueing those reads.  The slot is not re-rendered before that
+        stream reaches this point.  Without it the contract is the one INTEGRATION.md states: reads of a slot's images must
+        have completed (host-side) before the slot is submitted again, ``inflight`` submits later."""
+        if self.inflight > 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._released[slot] = ev
+
+    def _wait_released(self, j, rs):
+        if self._released[j] is not None:
+            rs.wait_event(self._released[j])
+            self._released[j] = None
 
     def drain(self):
         """Host waits for everything submitted so far (render + fuse streams; a partial batch is integrated first); no
@@ -344,8 +345,6 @@ class RenderFusePipeline:
         if self.inflight > 1:
             for s in self.render_streams:
                 s.synchronize()
-            if self._blend_torch is not None:
-                self._blend_torch.synchronize()
             self.fuse_stream.synchronize()
         else:
             torch.cuda.current_stream(self.device).synchronize()
@@ -364,21 +363,8 @@ class RenderFusePipeline:
                                    f"per view)")
 
     def close(self):
-        """Drain and release the masked streams (the handles' compositing goes back to the call's stream)."""
-        if getattr(self, "_masked", None):
-            self.drain()
-            for r in self.rasterizers:
-                r.set_blend_stream(None)
-                r.set_option(_lib.OPT_BLEND_JOIN, 1)
-            for m in self._masked:
-                m.close()
-            self._masked = []
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """Drain the pipeline's streams."""
+        self.drain()
 
     def set_stage_timing(self, enable: bool):
         for r in self.rasterizers:

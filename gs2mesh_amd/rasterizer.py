@@ -255,15 +255,6 @@ class Rasterizer:
         pointer only -- call after an in-place update of the Gaussians, or pack again)."""
         _lib.check(self._lib.gs2m_raster_pack_invalidate(self._h), self._lib)
 
-    def set_blend_stream(self, stream):
-        """``gs2m_raster_set_blend_stream``: compositing launches go to ``stream`` (int handle / None), ordered against
-        the call's stream inside the library."""
-        _lib.check(self._lib.gs2m_raster_set_blend_stream(self._h, C.c_void_p(int(stream)) if stream else None), self._lib)
-
-    def join(self, stream):
-        """``gs2m_raster_join``: ``stream`` (int handle) waits for the handle's latest compositing launch."""
-        _lib.check(self._lib.gs2m_raster_join(self._h, C.c_void_p(int(stream))), self._lib)
-
     def render_views(self, gaussians: dict, cams, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, want_color=True,
                      want_rgb8=False, want_radii=False, out_color=None, out_rgb8=None, stream=None, sync=True):
         """``gs2m_render_views``.  ``gaussians``: dict with xyz[P,3], scaling[P,3], rotation[P,4],

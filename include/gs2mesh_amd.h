@@ -31,8 +31,8 @@
 extern "C" {
 #endif
 
-#define GS2M_VERSION 301 /* 0.3.0: round-3 ABI (sum-form exchange buffers, sticky overflow word, masked streams);
-                            the Python binding checks it at load time */
+#define GS2M_VERSION 401 /* 0.4.0: round-4 ABI (masked streams / compositing stream / workgroup cap removed, tuning knobs
+                            as options, pack overflow status); the Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
 
@@ -43,17 +43,6 @@ typedef void* gs2m_stream; /* hipStream_t */
 int gs2m_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* gs2m_last_error(void);
-
-/*
- * Streams with a compute-unit mask (hipExtStreamCreateWithCUMask): work enqueued on such a stream only runs on the CUs
- * whose bit is set.  cu_mask[n_words] (HOST): bit i of the array = CU i in the driver's enumeration, which interleaves
- * the 8 XCDs (bit i belongs to XCD i % 8, then round-robin over that XCD's shader engines): the low N bits, N a
- * multiple of 32, are an XCD- and SE-symmetric set of N CUs.  cu_mask == NULL: a plain non-blocking stream.  New: the
- * reference launches everything on the null stream (DGR/rasterize_points.cu); here the VALU-bound compositing grid is
- * kept off a few CUs so that the latency-bound binning / TSDF kernels of the next views always find a free CU.
- */
-int gs2m_stream_create(gs2m_stream* out, int device, const uint32_t* cu_mask /* host */, int n_words);
-int gs2m_stream_destroy(gs2m_stream s);
 
 /* ------------------------------------------------------------------------------------ */
 /* rasteriser                                                                           */
@@ -76,17 +65,16 @@ enum {
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4,    /* 1 = bracket every stage launch with hipEvents on the
                                      work stream (read with gs2m_raster_stage_times)      */
-    GS2M_OPT_BLEND_WG_PER_CU = 6, /* cap on the compositing workgroups (4 waves each) resident per CU, 1..6; 0 = no cap (7).
-                                     The compositing grid otherwise refills every slot a retiring workgroup frees, and the
-                                     1024-thread binning / TSDF workgroups of the NEXT views (other streams) only get placed
-                                     in its tail; with a cap every CU keeps wave slots and LDS free for them.  Same image. */
-    GS2M_OPT_BLEND_JOIN = 7,      /* with a compositing stream set: 1 (default) = the call's stream waits for the compositing
-                                     before the call returns to it (everything ordered on the stream the caller passed);
-                                     0 = it does not -- gs2m_raster_join orders a stream behind the handle's compositing.   */
     GS2M_OPT_PAIR_BATCH = 8,      /* gs2m_render_views with >= 4 views: 1 = two stereo pairs share every launch (the projection /
                                      counting / scatter workgroups of a pair are half as many, blockIdx.y picks the pair; scans,
                                      per-tile sort and compositing take the four views in one grid): the per-launch and
                                      per-workgroup fixed costs are paid once for two pairs.  Same results.  Default 0. */
+    /* Tuning options (results never change; defaults are the measured optima, profiles/r3_experiments.txt): */
+    GS2M_OPT_BIN_WORKGROUPS = 9,  /* workgroups of the counting / scatter kernels per stereo pair (default 0 = 256, one per CU: the
+                                     per-workgroup histogram rows / cursors scale with their number) */
+    GS2M_OPT_BIN_WG_THREADS = 10, /* upper bound of their threads per workgroup, a multiple of 64 (default 0 = 1024) */
+    GS2M_OPT_BLEND_MODE = 11,     /* compositing loop of variant 4: 0 (default) = per-pixel decisions as lane masks in scalar
+                                     registers; 1 = execution-mask form (fewer scalar instructions, same time: DESIGN.md 3) */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and
@@ -99,7 +87,7 @@ enum {
 enum {
     GS2M_STAGE_PROJECT = 0, /* k_project       */
     GS2M_STAGE_COLSCAN = 1, /* k_hist_colscan  */
-    GS2M_STAGE_TILESCAN = 2,/* k_tile_scan     */
+    GS2M_STAGE_TILESCAN = 2,/* (round 4: fused into k_hist_colscan -- its last workgroup per view; always 0 launches) */
     GS2M_STAGE_SCATTER = 3, /* k_scatter       */
     GS2M_STAGE_SORT = 4,    /* k_sort_tiles    */
     GS2M_STAGE_BLEND = 5,   /* k_blend_*       */
@@ -110,15 +98,6 @@ enum {
 int gs2m_raster_create(gs2m_raster** out, int device);
 int gs2m_raster_destroy(gs2m_raster* r);
 int gs2m_raster_set_option(gs2m_raster* r, int option, int value);
-
-/* Launch the compositing kernel of every later forward / render_views call on `blend_stream` instead of the call's
- * stream (NULL = back to the call's stream).  The library orders it with two events (binning -> compositing -> back),
- * so for the caller all work of a call is still ordered on the stream it passed. */
-int gs2m_raster_set_blend_stream(gs2m_raster* r, gs2m_stream blend_stream);
-
-/* Makes `stream` wait for the latest compositing launch of the handle (no-op without a compositing stream).  Needed with
- * GS2M_OPT_BLEND_JOIN 0 before anything reads the images of the last call or re-uses the handle. */
-int gs2m_raster_join(gs2m_raster* r, gs2m_stream stream);
 
 /* Pre-size the arenas (optional; every forward grows them on demand).
  * P Gaussians, n_views views of W x H rendered per call, `instances` (Gaussian,tile)
@@ -321,7 +300,9 @@ int gs2m_tsdf_set_stage_timing(gs2m_tsdf* t, int enable);   /* a batch counts as
 int gs2m_tsdf_stage_times(gs2m_tsdf* t, gs2m_stream stream, double* total_ms, int64_t* launches);
 
 /* Synchronises; n_blocks = allocated blocks, block_updates = sum over frames of blocks
- * integrated (x 4096 = voxel-updates), overflow != 0 if the block pool or hash was full. */
+ * integrated (x 4096 = voxel-updates), overflow = flag bits (0 = fine): 1 block pool exhausted, 2 hash table full,
+ * 4 block index outside the +-2^20 key range, 8 a voxel handed to gs2m_tsdf_pack(GS2M_XFORM_SUM_PACKED) did not fit the
+ * packed fields (weight > 1023 or a colour sum >= 2^18: the summed exchange buffers are invalid, use SUM_F32). */
 int gs2m_tsdf_status(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_blocks,
                      int64_t* block_updates, int* overflow);
 
@@ -356,7 +337,8 @@ int gs2m_tsdf_unpack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, const flo
  *   GS2M_XFORM_SUM_PACKED  buf_f32[n,4096] = wsum, buf_i64[n,4096] = weight | sum r << 10 | sum g << 28 | sum b << 46: an fp32 SUM
  *                          and an int64 SUM collective, 12 instead of 20 bytes per voxel.  Only valid while the volumes being
  *                          summed have integrated <= 1023 frames IN TOTAL (weight < 2^10, colour sums < 2^18: no carry between
- *                          the fields); the caller checks that bound (gs2mesh_amd.parallel does, and falls back to SUM_F32).
+ *                          the fields); the caller checks that bound (gs2mesh_amd.parallel does, and falls back to SUM_F32);
+ *                          a LOCAL value that does not fit its field raises status bit 8 (gs2m_tsdf_status).
  * Halo copies held by the volume are packed as zeros in the SUM forms (they are another rank's blocks). */
 enum { GS2M_XFORM_SUM_F32 = 0, GS2M_XFORM_RAW_F32 = 1, GS2M_XFORM_SUM_PACKED = 2 };
 int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, float* buf_f32, int64_t* buf_i64,

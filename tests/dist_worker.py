@@ -28,6 +28,7 @@ def main():
     payload = parts[1] if len(parts) > 1 else "auto"
     algo = parts[2] if len(parts) > 2 else "rccl"
     n_frames = int(parts[3]) if len(parts) > 3 else 5
+    fake = int(parts[4]) if len(parts) > 4 else 0      # pretend every rank integrated this many more frames (weight bound only)
     frs, K = frames(n_frames, 128, 96, 140.0)
     W, H, fx, fy, cx, cy = K
     lo, hi = shard_range(len(frs), rank, world)
@@ -37,10 +38,25 @@ def main():
         vol.integrate(RGBDImage(c, d), intr, E)
     again = mode.endswith("+again")
     mode = mode.replace("+again", "")
+    twice = mode.endswith("+twice")
+    mode = mode.replace("+twice", "")
     mesh_mode = mode.endswith("+mesh")
+    vol.frames_local += fake
+    total = n_frames + fake * world
+    if payload == "packed" and total > 1023:
+        # the bound travels in the gathered header: EVERY rank takes the same decision and raises (nobody waits in a collective)
+        try:
+            reduce_volume(vol, mode=mode.replace("+mesh", ""), payload=payload, algo=algo)
+            raise SystemExit("reduce_volume(payload='packed') accepted %d frames" % total)
+        except RuntimeError as e:
+            assert "1023" in str(e), e
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), refused=1)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     info = reduce_volume(vol, mode=mode.replace("+mesh", ""), payload=payload, algo=algo)
-    assert info["payload"] == ("f32" if payload == "f32" else "packed") and info["frames_total"] == n_frames
-    assert vol.frames_integrated == n_frames
+    assert info["payload"] == ("f32" if payload == "f32" or total > 1023 else "packed") and info["frames_total"] == total
+    assert vol.frames_integrated == total
     # a second reduction must be able to re-use the persistent exchange buffers (same objects, no growth)
     ids = {k: v.data_ptr() for k, v in vol._xbuf.items()}
     extra = {}
@@ -53,6 +69,13 @@ def main():
         extra["owned_keys"] = owned_keys
         assert info["collectives"] == (2 if info["payload"] == "f32" else 3)
         assert all(vol._xbuf[k].data_ptr() == p for k, p in ids.items())
+    if twice:
+        try:
+            reduce_volume(vol, mode=mode, payload=payload, algo=algo)
+            raise SystemExit("a replicated volume was summed again")
+        except RuntimeError as e:
+            assert "replicated" in str(e), e
+        extra["refused_second"] = 1
     if again:
         # second reduction on volumes that now hold halo copies of the other rank's blocks
         info2 = reduce_volume(vol, mode="reduce_scatter", payload=payload, algo=algo)

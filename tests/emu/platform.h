@@ -78,7 +78,7 @@ void wave_gather(const void* mine, size_t bytes, void* all);
     ::emu::launch(grid, block, lds_bytes, [=]() { kernel(__VA_ARGS__); })
 
 static inline void __syncthreads() { ::emu::sync_block(); }
-static inline void __threadfence() {}
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() {}
 static inline int gs2m_syncthreads_count(int pred) { return ::emu::sync_count(pred); }
 static inline unsigned long long gs2m_ballot(int pred) { return ::emu::ballot(pred); }
@@ -206,8 +206,6 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std:
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 #define hipStreamNonBlocking 1
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = malloc(1); return hipSuccess; }
-static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = malloc(1); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();

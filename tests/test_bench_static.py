@@ -39,3 +39,23 @@ def test_the_json_line_carries_the_contract_fields():
     # roofline / cpu_baseline objects: the fields the contract names
     for key in ("bound=", "achieved=", "peak=", "frac=", "traffic=", "cores=", "kind=", "sample="):
         assert key in src, key
+
+
+def _run_bench(args, env=None, timeout=300):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_gpus_flag_and_launcher_world_must_agree():
+    """`bench.py --gpus N` started without a launcher used to run one rank and report n_gpus: 1.  Now a launcher
+    world that differs from --gpus is an error, and --gpus N > 1 without a launcher re-executes under torch.distributed.run --
+    or fails loudly when the node has fewer GPUs (here: none)."""
+    r = _run_bench(["--gpus", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in r.stderr, r.stderr[-500:]
+    r = _run_bench(["--gpus", "4"])
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr, r.stderr[-500:]

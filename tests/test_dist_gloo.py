@@ -132,6 +132,39 @@ def test_eight_ranks_reduce_scatter_direct_and_owner_side_mesh(tmp_path):
     assert_same_triangles(got, tri_ref)
 
 
+def test_eight_ranks_fall_back_to_the_f32_payload_beyond_1023_frames(tmp_path):
+    """with more than 1023 frames in total (here 8 ranks x (2 real + 200 pretended) frames) the int64 packed
+    payload could carry between its fields: payload='auto' must pick the five fp32 planes ON EVERY RANK ALIKE (the bound travels
+    in the gathered header) and still give the single-process volume; payload='packed' must be refused on every rank."""
+    world, n_frames = 8, 16
+    run_world(tmp_path, world, f"reduce_scatter:auto:rccl:{n_frames}:200")
+    kf, tf, wf, cf = single_process_reference(n_frames=n_frames)
+    ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
+    seen = set()
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        keys = list(map(tuple, z["keys"].tolist()))
+        assert not (set(keys) & seen)
+        seen |= set(keys)
+        idx = np.array([ref[k] for k in keys], dtype=int)
+        np.testing.assert_array_equal(z["weight"], wf[idx])
+        np.testing.assert_array_equal(z["rgb"], cf[idx])
+        np.testing.assert_allclose(z["tsdf"], tf[idx], atol=1e-5, rtol=0)
+    assert seen == set(ref)
+    run_world(tmp_path, world, f"reduce_scatter:packed:direct:{n_frames}:200")
+    for rank in range(world):
+        assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
+
+
+def test_a_replicated_volume_is_not_summed_again(tmp_path):
+    """After mode='allreduce' every rank holds the whole fused volume: a second reduction would count it once per rank.
+    reduce_volume refuses (on every rank: the flag travels in the header); after a reduce-scatter a second reduction is fine
+    (test_halo_copies_are_not_exchanged_twice)."""
+    run_world(tmp_path, 2, "allreduce+twice")
+    for rank in range(2):
+        assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused_second"]) == 1
+
+
 def test_halo_copies_are_not_exchanged_twice(tmp_path):
     """A volume that holds halo copies (after exchange_halo) reports them as sentinel keys and packs them as zeros: a
     second reduction does not count another rank's blocks twice."""

@@ -161,7 +161,7 @@ def test_bench_configuration_full_size_vs_oracle(cfg_name, blend):
     dev = torch.device("cuda:0")
     intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2.0, H / 2.0)
     vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=16384, device=0)
-    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=4, device=0, exact_tile_cull=1, tile_rows=2, blend_variant=blend)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=4, device=0, raster_options=dict(exact_tile_cull=1, tile_rows=2, blend_variant=blend))
     ccams = [[camera_from(l), camera_from(r)] for l, r in cams]
     first = pipe.prepare(ccams[0], headroom=2.0)
     radii0 = first["radii"].cpu().numpy()
@@ -213,6 +213,129 @@ def test_bench_configuration_full_size_vs_oracle(cfg_name, blend):
         assert worst["flips_ok"] == 1 and worst["unexplained_pixels"] == 0 and worst["max_abs_clean"] <= 2e-4, worst
 
 
+# BASELINE configs C4 (Truck-like: 2.5 M Gaussians, 1920 x 1080, the only config with a 64^3-block key space) and C5
+# (MobileBrick-like: 500 k Gaussians, 1920 x 1440 = 10 800 binning tiles with 2 views in the LDS cursors, 14 % baseline),
+# through the bench's DEFAULT launch shapes: two stereo pairs per launch.  Bounds <= 2x the values
+# measured on MI355X in round 4 (profiles/r4_parity_C4.json / r4_parity_C5.json).
+BENCH_PARITY_BOUNDS_PPL2 = {
+    "C4": dict(max_abs=8e-4, mean_abs=8e-8, psnr_db=125.0, frac_gt_1e5=4e-6, u8_flipped_pixels=80, radii_mismatches=4),
+    "C5": dict(max_abs=6e-3, mean_abs=1.2e-7, psnr_db=109.0, frac_gt_1e5=2e-5, u8_flipped_pixels=200, radii_mismatches=4),
+}
+
+
+@pytest.mark.parametrize("cfg_name", ["C4", "C5"])
+def test_c4_c5_pair_batched_pipeline_full_size_vs_reference_kernels(cfg_name):
+    """One stereo pair of C4 / C5 out of a pair-batched pipelined job (RenderFusePipeline: 16 x 32 binning tiles, exact tile
+    cull, fused raw activations, packed -- C4: Morton-ordered -- model, pairs_per_launch = 2, TSDF sweeps on the fuse stream)
+    against the reference's own kernels (oracle/_ref) with the checked flip attribution."""
+    import json
+    import os
+    import torch
+    from oracle import parity
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    cfg, g, gd, poses, cams, Rasterizer, camera_from = _setup(cfg_name, n_pairs=4)
+    W, H = cfg.width, cfg.height
+    dev = torch.device("cuda:0")
+    intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2.0, H / 2.0)
+    vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=65536, device=0)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=2, device=0, fuse_batch=4, pairs_per_launch=2)
+    assert pipe.spatial_order == (cfg.P >= 1_000_000)
+    ccams = [[camera_from(l), camera_from(r)] for l, r in cams]
+    first = pipe.prepare(ccams[0], headroom=2.0)
+    radii0 = first["radii"].cpu().numpy()
+    slots = []
+    for i, p in enumerate(poses):
+        d = synthetic.sphere_depth_torch(p, W, H, cfg.focal, cfg.focal, W / 2.0, H / 2.0, cfg.sphere_radius, dev)
+        E = np.eye(4)
+        E[:3] = p
+        slots.append(pipe.submit(ccams[i], d, E, depth_trunc=cfg.baseline * 20, min_depth=cfg.baseline * 4))
+    pipe.finish()
+    assert vol.status()[0] > 100
+    # views 2, 3 went through the second launch (slot of view 3); its images are [pair 2 | pair 3]
+    slot = slots[3]
+    color = pipe.color[slot].cpu().numpy()
+    rgb8 = pipe.rgb8[slot].cpu().numpy()
+    m = parity.pair_parity(g, cams[3], W, H, color[2:4], rgb8[2:4], None, flips=True)
+    m["view"] = 3
+    o0 = [parity.oracle_eye(g, c, W, H) for c in cams[0]]
+    m["radii_mismatches"] = int(max((radii0[v] != o0[v]["radii"]).sum() for v in range(2)))
+    m["num_rendered_reference_lists"] = [o["num_rendered"] for o in o0]
+    m["num_rendered"] = [int(x) for x in first["num_rendered"]]
+    m["pairs_per_launch"], m["spatial_order"] = 2, int(pipe.spatial_order)
+    # the first pair of the same launch against the serial single-pair render of the same handle: bit-identical
+    R = Rasterizer(0)
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
+    R.set_option(_lib.OPT_TILE_ROWS, 2)
+    R.pack_sh(gd)
+    single = R.render_views(gd, ccams[2], want_rgb8=True)
+    assert np.array_equal(single["color"].cpu().numpy(), color[0:2]) and np.array_equal(single["rgb8"].cpu().numpy(), rgb8[0:2])
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"parity_{cfg_name}_ppl2.json"), "w") as fh:
+        json.dump(m, fh, indent=1, default=str)
+    print("PARITY", cfg_name, "ppl2", json.dumps(m, default=str))
+    b = BENCH_PARITY_BOUNDS_PPL2[cfg_name]
+    assert m["flips_ok"] == 1 and m["unexplained_pixels"] == 0 and m["max_abs_clean"] <= 2e-4, m
+    assert m["max_abs"] <= b["max_abs"] and m["mean_abs"] <= b["mean_abs"] and m["psnr_db"] >= b["psnr_db"], m
+    assert m["frac_gt_1e5"] <= b["frac_gt_1e5"] and m["u8_flipped_pixels"] <= b["u8_flipped_pixels"] and m["u8_max_lsb"] <= 1, m
+    assert m["radii_mismatches"] <= b["radii_mismatches"], m
+
+
+def test_c4_tsdf_frames_1024_cubed_vs_oracle_and_batch_sweep():
+    """C4's fuse half at full size: voxel 4/1024 (a 64^3-block key space), sphere of radius 1.2, 1920 x 1080 frames,
+    max_blocks = 64^3.  Three frames view by view against the restated Open3D oracle (block sets, block updates, weights and
+    tsdf bit for bit, colour means to 1e-9), and the voxel-stationary batch sweep of the same frames == view by view."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from gs2mesh_amd.integration import PinholeCameraIntrinsic, RGBDImage, ScalableTSDFVolume
+    cfg = synthetic.CONFIGS["C4"]
+    W, H, f = cfg.width, cfg.height, cfg.focal
+    poses = synthetic.ring_poses(3, cfg.ring_radius, 0, cfg.n_pairs)
+    col = synthetic.color_pattern(W, H)
+    intr = PinholeCameraIntrinsic(W, H, f, f, W / 2.0, H / 2.0)
+    trunc, mind = cfg.baseline * 20, cfg.baseline * 4
+    frames = []
+    for p in poses:
+        E = np.eye(4)
+        E[:3] = p
+        frames.append((synthetic.sphere_depth(p, W, H, f, f, W / 2.0, H / 2.0, cfg.sphere_radius), E))
+    n_dense = (cfg.tsdf_n // 16) ** 3
+    assert n_dense == 262144
+    vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=n_dense)
+    for d, E in frames:
+        vol.integrate(RGBDImage(col, d, depth_scale=1.0, depth_trunc=trunc), intr, E, min_depth=mind)
+    updates = vol.status()[1]
+    keys, tsdf, weight, rgb = vol.download()
+    ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
+    ref.set_threads(16)
+    n_ref = 0
+    for d, E in frames:
+        dd = np.where(d < np.float32(mind), 0, d).astype(np.float32)
+        n_ref += ref.integrate(oracle.ScalableTSDFVolume.convert_depth(dd, 1.0, trunc), col, W, H, f, f, W / 2.0, H / 2.0, E)
+    assert updates == n_ref and n_ref > 10000
+    rk, rt, rw, rc = ref.export()
+    assert np.abs(rk).max() <= 32                      # the blocks of a 4-unit cube: indices inside the 64^3 key space
+    got = {tuple(k): i for i, k in enumerate(keys.tolist())}
+    assert set(got) == set(map(tuple, rk.tolist()))
+    order = np.array([got[tuple(k)] for k in rk.tolist()])
+    assert np.array_equal(weight[order], rw)
+    assert np.array_equal(tsdf[order], rt)
+    mean = rgb[order].astype(np.float64) / np.maximum(weight[order], 1)[..., None]
+    assert np.abs(mean - rc).max() < 1e-9
+    del tsdf, weight, rgb, mean
+    vol.reset()
+    vol.integrate_batch([RGBDImage(col, d, depth_scale=1.0, depth_trunc=trunc) for d, _ in frames], intr, [E for _, E in frames],
+                        min_depth=mind)
+    assert vol.status()[1] == n_ref
+    kb, tb, wb, cb = vol.download()
+    ib = {tuple(k): i for i, k in enumerate(kb.tolist())}
+    assert set(ib) == set(map(tuple, rk.tolist()))
+    ob = np.array([ib[tuple(k)] for k in rk.tolist()])
+    assert np.array_equal(wb[ob], rw) and np.array_equal(tb[ob], rt)
+    assert np.abs(cb[ob].astype(np.float64) / np.maximum(wb[ob], 1)[..., None] - rc).max() < 1e-9
+
+
 def test_trained_like_splats_full_size_vs_reference_kernels():
     """C2-sized `synthetic.trained_like` model (anisotropy 10-100 : 1, 30 % of the opacities at the 0.99 cap, 0.1 % splats
     wider than 300 px, depth ties) through the bench's configuration -- RenderFusePipeline, 16 x 32 binning tiles, exact
@@ -234,7 +357,7 @@ def test_trained_like_splats_full_size_vs_reference_kernels():
     gd["raw"] = True
     poses = synthetic.ring_poses(2, cfg.ring_radius, 3, cfg.n_pairs)
     cams = [synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline) for p in poses]
-    pipe = RenderFusePipeline(gd, W, H, None, None, inflight=2, device=0, exact_tile_cull=1, tile_rows=2)
+    pipe = RenderFusePipeline(gd, W, H, None, None, inflight=2, device=0)
     ccams = [[camera_from(l), camera_from(r)] for l, r in cams]
     first = pipe.prepare(ccams[0], headroom=2.0)
     radii0 = first["radii"].cpu().numpy()
@@ -279,7 +402,9 @@ def test_trained_like_splats_full_size_vs_reference_kernels():
     print("PARITY trained_like", json.dumps(m, default=str))
     assert all(c["ok"] and c["unexplained_pixels"] == 0 and c["max_abs_clean"] <= 2e-4 for c in comp), comp
     assert m["psnr_db"] >= 100.0 and m["u8_max_lsb"] <= 1 and m["radii_mismatches"] <= 4, m
-    assert m["raw_path_conic_rel_diff"]["median"] < 1e-6 and m["raw_path_conic_rel_diff"]["max"] < 5e-2, m
+    # measured (profiles/r3_parity_C2_trained_like.json): median 0, p99.9 2.6e-5, max 2.2e-4 -> bounds <= 2x measured
+    assert m["raw_path_conic_rel_diff"]["median"] < 1e-6 and m["raw_path_conic_rel_diff"]["p999"] < 5.2e-5, m
+    assert m["raw_path_conic_rel_diff"]["max"] < 4.4e-4, m
 
 
 def test_c2_tile_rows_2_is_bit_identical_to_tile_rows_1():

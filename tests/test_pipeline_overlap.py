@@ -66,16 +66,12 @@ def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("n_views,fuse_batch", [(6, 6), (7, 4), (6, [4, 2])])
-def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch):
-    """RenderFusePipeline(pairs_per_launch=2): two consecutive stereo pairs per chain of launches (GS2M_OPT_PAIR_BATCH),
-    their u8 pairs rendered into consecutive buffers of the pending TSDF batch; an odd last view is flushed by `finish`.
-    Images and volume are bit-identical to the serial order."""
+def _run_grouped(inflight, n_views, fuse_batch):
+    """pairs_per_launch = 2: the same job as `_run`, two consecutive stereo pairs per chain of launches."""
     import torch
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
     from gs2mesh_amd.pipeline import RenderFusePipeline
     from gs2mesh_amd.rasterizer import camera_from
-    ref = _run(1, n_views=n_views)
     cfg = synthetic.CONFIGS["C1"]
     dev = torch.device("cuda:0")
     g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
@@ -85,7 +81,7 @@ def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch):
     poses = synthetic.ring_poses(n_views, cfg.ring_radius, 0, n_views)
     intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
     vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
-    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=3, device=0, fuse_batch=fuse_batch, pairs_per_launch=2)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0, fuse_batch=fuse_batch, pairs_per_launch=2)
     cams, depths, Es = [], [], []
     for p in poses:
         l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
@@ -109,10 +105,20 @@ def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch):
     keys, tsdf, weight, rgb = vol.download()
     pipe.close()
     order = np.lexsort(keys.T[::-1])
-    for (c0, u0), (c1, u1) in zip(ref[0], images):
-        assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
     assert len(images) == n_views
-    for a, b in zip(ref[1:], (keys[order], tsdf[order], weight[order], rgb[order])):
+    return images, keys[order], tsdf[order], weight[order], rgb[order]
+
+
+@pytest.mark.parametrize("n_views,fuse_batch", [(6, 6), (7, 4), (6, [4, 2])])
+def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch):
+    """RenderFusePipeline(pairs_per_launch=2): two consecutive stereo pairs per chain of launches (GS2M_OPT_PAIR_BATCH),
+    their u8 pairs rendered into consecutive buffers of the pending TSDF batch; an odd last view is flushed by `finish`.
+    Images and volume are bit-identical to the serial order."""
+    ref = _run(1, n_views=n_views)
+    got = _run_grouped(3, n_views, fuse_batch)
+    for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
+        assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
+    for a, b in zip(ref[1:], got[1:]):
         assert np.array_equal(a, b)
 
 
@@ -157,19 +163,56 @@ def test_model_updated_orders_the_render_streams_after_the_callers_stream():
         assert np.array_equal(res["color"].cpu().numpy(), got[i]), i
 
 
-@pytest.mark.parametrize("kw", [dict(blend_cus=224), dict(blend_cus=192, bin_cus="rest", fuse_cus="rest", blend_streams=1),
-                                dict(blend_cus=224, fuse_cus="blend", blend_streams=3), dict(layout="two_stage"),
-                                dict(layout="two_stage", bin_streams=2)])
-def test_cu_partitioned_streams_equal_serial(kw):
-    """CU-masked streams (gs2m_stream_create / gs2m_raster_set_blend_stream): the compositing launches run on streams
-    restricted to a subset of the CUs, ordered against the binning chain by events inside the library -- same images, same
-    volume as the serial single-stream order."""
+def test_serial_mode_with_two_pairs_per_launch_equals_view_by_view():
+    """inflight = 1 + pairs_per_launch = 2 (what tools/profile_round.sh profiles: the timed launch shapes, serial on one
+    stream): same images and volume as one pair per launch."""
     ref = _run(1)
-    got = _run(3, fuse_batch=2, **kw)
+    got = _run_grouped(1, 6, 6)
     for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
         assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
     for a, b in zip(ref[1:], got[1:]):
         assert np.array_equal(a, b)
+
+
+def test_release_fences_the_slots_next_render_behind_the_consumers_reads():
+    """`release(slot)`: reads of a slot's images enqueued on the caller's stream are ordered before the slot's
+    re-render `inflight` submits later, without a host synchronisation -- a slow consumer kernel chain on a side stream still
+    sees the image of ITS view."""
+    import torch
+    from gs2mesh_amd.pipeline import RenderFusePipeline
+    from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+    cfg = synthetic.CONFIGS["C1"]
+    dev = torch.device("cuda:0")
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
+    gd["raw"] = True
+    W, H = cfg.width, cfg.height
+    poses = synthetic.ring_poses(6, cfg.ring_radius, 0, 6)
+    cams = []
+    for p in poses:
+        l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
+        cams.append([camera_from(l), camera_from(r)])
+    pipe = RenderFusePipeline(gd, W, H, inflight=2, device=0)
+    pipe.prepare(cams[0])
+    consumer = torch.cuda.Stream(device=dev)
+    big = torch.zeros((64, 1024, 1024), device=dev)
+    copies = []
+    for i in range(6):
+        slot = pipe.submit(cams[i])
+        with torch.cuda.stream(consumer):
+            pipe.wait_rendered(slot, stream_only=True)      # no host sync: the consumer stream waits for the render
+            for _ in range(4):
+                big.add_(1.0)                               # a slow consumer in front of the read
+            copies.append(pipe.color[slot].clone())
+            pipe.release(slot)
+    pipe.finish()
+    consumer.synchronize()
+    fresh = Rasterizer(0)
+    fresh.set_option(1, 1)
+    fresh.set_option(5, 2)
+    for i in range(6):
+        res = fresh.render_views(gd, cams[i])
+        assert np.array_equal(res["color"].cpu().numpy(), copies[i].cpu().numpy()), i
 
 
 def test_fuseless_render_does_not_touch_a_pending_views_image():

@@ -367,21 +367,6 @@ def test_list_sizes_at_the_boundaries_of_the_sort_paths(backend, n, ties):
     assert_image_close(img, ref_img)
 
 
-@pytest.mark.parametrize("env", [{"GS2M_SORT_KEYS_PER_THREAD": "16", "GS2M_SORT_SMALL_WPB": "1"},
-                                 {"GS2M_SORT_SMALL_WPB": "2", "GS2M_SORT_WAVE_BUCKET": "0"}])
-def test_sort_geometry_knobs_do_not_change_results(env):
-    """The A/B knobs of the per-tile sort (16 keys per thread in the size-class kernels, 1 / 2 lists per workgroup in the
-    small-list kernel, bitonic network only) are read once per process: the sort tests again in a subprocess (emulator)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_raster_parity.py"), "-x", "-q", "-m", "not gpu",
-                        "-k", "mid_size_lists or dense_lists or lists_grow"], capture_output=True, text=True, timeout=1800,
-                       env=dict(os.environ, **env), cwd=root)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("rows,cull,packed,n_views", [(1, 0, False, 4), (2, 1, False, 4), (2, 1, True, 4), (2, 1, False, 5), (2, 1, False, 6),
                                                       (2, 1, False, 8)])
 def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, rows, cull, packed, n_views):
@@ -686,46 +671,38 @@ def test_hip_path_against_reference_golden(backend):
     assert_image_close(be.host(img), z["out_color"])
 
 
-@pytest.mark.parametrize("env", [{"GS2M_NWG_TARGET": "2", "GS2M_MAX_WG_THREADS": "128"},
-                                 {"GS2M_NWG_TARGET": "3", "GS2M_MAX_WG_THREADS": "1024"},
-                                 {"GS2M_NWG_TARGET": "64", "GS2M_MAX_WG_THREADS": "64"},
-                                 {"GS2M_BLEND_MODE": "1"}])
-def test_workgroup_geometry_knobs_do_not_change_results(env):
-    """k_count_tiles / k_scatter with few large workgroup chunks (several loop iterations per workgroup, partial last
-    iteration) and with small workgroups: same records, instance lists and image as the reference golden.  The knobs are
-    read once per process, hence the subprocess (emulator build of the kernel sources).  GS2M_BLEND_MODE=1: the
-    compositing loop without lane masks in scalar registers (execution-mask form, raster_blend.h MODE 1)."""
+@pytest.mark.parametrize("opts", [{_lib.OPT_BIN_WORKGROUPS: 2, _lib.OPT_BIN_WG_THREADS: 128},
+                                  {_lib.OPT_BIN_WORKGROUPS: 3, _lib.OPT_BIN_WG_THREADS: 1024},
+                                  {_lib.OPT_BIN_WORKGROUPS: 64, _lib.OPT_BIN_WG_THREADS: 64},
+                                  {_lib.OPT_BLEND_MODE: 1}])
+def test_tuning_options_do_not_change_results(backend, opts):
+    """The tuning options of gs2m_raster_set_option: k_count_tiles / k_scatter with few large workgroup chunks (several loop
+    iterations per workgroup, partial last iteration) and with small workgroups; GS2M_OPT_BLEND_MODE 1 = the compositing loop
+    without lane masks in scalar registers (execution-mask form, raster_blend.h MODE 1).  Same records, instance lists and
+    image as the reference golden."""
     import os
-    import subprocess
-    import sys
-    import textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import os, sys, numpy as np
-        sys.path.insert(0, os.path.join(%r, "tests")); sys.path.insert(0, %r)
-        from backends import make
-        from gs2mesh_amd.rasterizer import Rasterizer
-        be = make("emu")
-        z = np.load(os.path.join(%r, "tests", "golden", "ref_forward.npz"))
-        W, H, P = int(z["W"]), int(z["H"]), z["xyz"].shape[0]
-        for cull in (0, 1):
-            r = Rasterizer(0, lib=be.lib)
-            r.set_option(1, cull)
-            img, radii = r.forward(z["xyz"], z["opacity"], z["viewmatrix"], z["projmatrix"], z["campos"], z["bg"], W, H,
-                                   float(z["tanfovx"]), float(z["tanfovy"]), shs=z["shs"], scales=z["scales"],
-                                   rotations=z["rotations"])
-            assert np.array_equal(radii, z["out_radii"])
-            d = np.abs(np.asarray(img) - z["out_color"])
-            assert (d > 1e-5).mean() <= 1e-4 and d.max() <= 6e-3
-            if cull == 0:
-                n = int(z["out_num_rendered"])
-                assert r.last_num_rendered == n
-                pl, ranges = r.download_binning(0, n, ((W + 15) // 16) * ((H + 15) // 16))
-                assert np.array_equal(pl, z["out_point_list"]) and np.array_equal(ranges, z["out_ranges"])
-        print("KNOBS_OK")
-    """ % (root, root, root))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
-    assert r.returncode == 0 and "KNOBS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    be = backend
+    d = be.dev
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_forward.npz"))
+    W, H = int(z["W"]), int(z["H"])
+    for cull in (0, 1):
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        img, radii = r.forward(d(z["xyz"]), d(z["opacity"]), d(z["viewmatrix"]), d(z["projmatrix"]), d(z["campos"]), d(z["bg"]),
+                               W, H, float(z["tanfovx"]), float(z["tanfovy"]), shs=d(z["shs"]), scales=d(z["scales"]),
+                               rotations=d(z["rotations"]))
+        assert np.array_equal(be.host(radii), z["out_radii"])
+        dd = np.abs(be.host(img) - z["out_color"])
+        assert (dd > 1e-5).mean() <= 1e-4 and dd.max() <= 6e-3
+        if cull == 0:
+            n = int(z["out_num_rendered"])
+            assert r.last_num_rendered == n
+            pl, ranges = r.download_binning(0, n, ((W + 15) // 16) * ((H + 15) // 16))
+            assert np.array_equal(pl, z["out_point_list"]) and np.array_equal(ranges, z["out_ranges"])
+    with pytest.raises(RuntimeError):
+        Rasterizer(0, lib=be.lib).set_option(_lib.OPT_BIN_WG_THREADS, 100)     # not a multiple of 64
 
 
 @pytest.mark.parametrize("cull", [0, 1])

@@ -175,6 +175,37 @@ def test_pack_unpack_round_trip_and_merge(backend):
     np.testing.assert_allclose(tm[order], tf, atol=1e-6)
 
 
+def test_packed_exchange_form_flags_values_that_do_not_fit_its_fields(backend):
+    """XFORM_SUM_PACKED holds w in 10 bits and the colour sums in 18: state injected through unpack_sum with larger
+    weights (a C-API user, or a volume whose frame bound was lost) must not carry silently between the fields.
+    k_tsdf_pack<PACKED> raises status bit 8; `unpack*` without a `frames` bound disqualifies the volume from the packed
+    payload (frames_integrated > 1023); with the bound it stays eligible."""
+    from gs2mesh_amd import _lib
+    be = backend
+    vol = ScalableTSDFVolume(2.0 / 96, 0.1, max_blocks=64, lib=be.lib)
+    keys = np.array([[0, 0, 0], [1, 0, 0]], np.int32)
+    buf = np.zeros((2, 5, 4096), np.float32)
+    buf[:, 1] = 5.0          # weights
+    buf[:, 0] = 2.5          # wsum
+    buf[:, 2:] = 600.0       # colour sums
+    vol.unpack_sum(be.dev(keys), be.dev(buf), frames=5)
+    assert vol.frames_integrated == 5
+    fb, ib = be.dev(np.zeros((2, 1, 4096), np.float32)), be.dev(np.zeros((2, 4096), np.int64))
+    vol.pack(be.dev(keys), _lib.XFORM_SUM_PACKED, fb, ib)
+    assert vol.status(raise_on_overflow=False)[2] == 0
+    p = be.host(ib)
+    assert np.all((p & 0x3ff) == 5) and np.all(((p >> 10) & 0x3ffff) == 600) and np.all((p >> 46) == 600)
+    buf[1, 1, 7] = 1500.0    # one voxel beyond the 10-bit weight field
+    vol.unpack_sum(be.dev(keys), be.dev(buf))            # no bound given
+    assert vol.frames_integrated > _lib.XFORM_PACKED_MAX_FRAMES
+    vol.pack(be.dev(keys), _lib.XFORM_SUM_PACKED, fb, ib)
+    assert vol.status(raise_on_overflow=False)[2] & 8
+    with pytest.raises(RuntimeError, match="packed exchange form"):
+        vol.status()
+    vol.reset()
+    assert vol.frames_integrated == 0 and vol.status()[2] == 0
+
+
 @pytest.mark.parametrize("color,use_mask", [(True, False), (True, True), (False, False)])
 def test_batch_integrate_is_bit_identical_to_frame_by_frame(backend, color, use_mask):
     """gs2m_tsdf_integrate_batch (voxel-stationary: all frames of the batch in one sweep over the touched blocks) vs the

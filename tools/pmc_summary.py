@@ -67,6 +67,21 @@ for k, cs in sorted(summary.items()):
                               branch_insts_per_launch=int(cs["SQ_INSTS_BRANCH"]) if "SQ_INSTS_BRANCH" in cs else None,
                               lds_bank_conflict_cycles=int(cs["SQ_LDS_BANK_CONFLICT"]) if "SQ_LDS_BANK_CONFLICT" in cs else None,
                               cull=bench.get("config", {}).get("exact_tile_cull", 1), source=f"profiles/{tag}_pmc_{cfg}.json")
+# the TSDF launches of the profiled command cover a whole sweep: record its frames so that bench.py can quote per-frame bytes
+sb = os.path.join(src, "stats_bench.json")
+try:
+    sweep = int(json.load(open(sb)).get("config", {}).get("tsdf_fuse_batch", 1))
+except Exception:
+    sweep = 1
+try:
+    ppl = int(json.load(open(sb)).get("config", {}).get("pairs_per_launch", 1))
+except Exception:
+    ppl = 1
+for st, t in traffic.items():
+    if st in ("tsdf_touch", "tsdf_integrate"):
+        t["frames_per_launch"] = sweep       # a launch = one sweep (profile_round.sh: warm-up = steps, so every sweep has this size)
+    else:
+        t["pairs_per_launch"] = ppl          # a raster launch covers this many stereo pairs (GS2M_OPT_PAIR_BATCH)
 tp = os.path.join(dst, "pmc_traffic.json")
 allt = json.load(open(tp)) if os.path.exists(tp) else {}
 allt[cfg] = traffic

@@ -16,7 +16,9 @@ if [ "$CFG" = "C2" ]; then
 else
   timeout 600 python $R/bench.py --config $CFG --steps 12 --warmup 3 --no-c3 --cpu-seconds 4 > $OUT/bench.json 2> $OUT/bench.err
 fi
-ARGS="--config $CFG --no-cpu-baseline --no-parity --no-c3 --inflight 1 --steps 12 --warmup 3 --min-repeats 2 --min-seconds 0.05"
+# serial on one stream (--inflight 1) with the DEFAULT launch shapes (2 stereo pairs per launch); warm-up = steps so that every
+# TSDF sweep of the run covers the same 12 frames (per-launch averages are then per 12-frame sweep)
+ARGS="--config $CFG --no-cpu-baseline --no-parity --no-c3 --no-steady-state --inflight 1 --steps 12 --warmup 12 --min-repeats 2 --min-seconds 0.05"
 # kernel stats of the serial order (--inflight 1: kernels in isolation = what bench.py's `stages` time with hipEvents)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/stats_bench.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
