@@ -48,7 +48,6 @@ struct gs2m_raster {
     std::vector<EvPair> ev_live;        // recorded, not yet read
     std::vector<hipEvent_t> ev_free;    // recycled events
     CamUniform* d_cams = nullptr;  // [GS2M_MAX_PASS_VIEWS]
-    unsigned* d_done = nullptr;    // [GS2M_MAX_PASS_VIEWS] tickets of k_hist_colscan's workgroups (zero between passes)
     GeomRec* d_recs = nullptr;
     size_t recs_cap = 0;  // records
     unsigned long long* d_tilemask = nullptr;
@@ -115,8 +114,6 @@ extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
     gs2m_raster* r = new gs2m_raster();
     r->device = device;
     if (hipMalloc((void**)&r->d_cams, sizeof(CamUniform) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
-        hipMalloc((void**)&r->d_done, sizeof(unsigned) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
-        hipMemset(r->d_done, 0, sizeof(unsigned) * GS2M_MAX_PASS_VIEWS) != hipSuccess ||
         hipMalloc((void**)&r->d_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
         hipHostMalloc((void**)&r->h_status, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess ||
         hipMemset(r->d_status, 0, sizeof(ViewStatus) * (GS2M_MAX_STATUS + 1)) != hipSuccess) {
@@ -132,7 +129,6 @@ extern "C" int gs2m_raster_create(gs2m_raster** out, int device) {
 extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     if (!r) return 0;
     (void)hipFree(r->d_cams);
-    (void)hipFree(r->d_done);
     (void)hipFree(r->d_recs);
     (void)hipFree(r->d_tilemask);
     (void)hipFree(r->d_shpack);
@@ -351,13 +347,15 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     }
     if (dbg_check(r, st, "count_tiles")) return 1;
     {
-        // column scan + (its last workgroup per view) the tile scan: one launch (round 3: two, GS2M_STAGE_TILESCAN is not
-        // launched any more and reports 0)
         StageTimer tm(r, st, GS2M_STAGE_COLSCAN);
-        gs2m_launch_hist_colscan(st, nvt, r->d_hist, n_wg, tiles, r->d_tile_count, r->d_done, r->d_tile_start, gx,
-                                 r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
+        gs2m_launch_hist_colscan(st, nvt, r->d_hist, n_wg, tiles, r->d_tile_count);
     }
-    if (dbg_check(r, st, "hist_colscan + tile_scan")) return 1;
+    if (dbg_check(r, st, "hist_colscan")) return 1;
+    {
+        StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
+        gs2m_launch_tile_scan(st, nvt, r->d_tile_count, r->d_tile_start, tiles, gx, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
+    }
+    if (dbg_check(r, st, "tile_scan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
         if (gs2m_launch_scatter(nv, pairs, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,

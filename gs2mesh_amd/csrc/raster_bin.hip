@@ -2,12 +2,12 @@
 #include "raster_sort.h"
 #include "raster_internal.h"
 
-void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count, unsigned* done,
-                              unsigned* tile_start, int gx, ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {
-    // column scan of the per-workgroup histogram rows; the last workgroup of a view to finish runs the view's tile scan
-    // (tile offsets, status words, size-class work lists of the sort, compositing schedule) in the same launch
-    GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(64 * GS2M_COLSCAN_SEGS), 0, st, hist, n_wg, tiles, tile_count, done,
-                tile_start, gx, status, sticky, cap, sort_lists);
+void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count) {
+    GS2M_LAUNCH(k_hist_colscan, dim3((tiles + 63) / 64, nv), dim3(64 * GS2M_COLSCAN_SEGS), 0, st, hist, n_wg, tiles, tile_count);
+}
+void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles, int gx,
+                           ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists) {
+    GS2M_LAUNCH(k_tile_scan, dim3(nv), dim3(1024), 0, st, tile_count, tile_start, tiles, gx, status, sticky, cap, sort_lists);
 }
 size_t gs2m_sort_lists_words(int nv, int tiles) { return (size_t)nv * (GS2M_SORT_CLASSES * (tiles + 1) + tiles); }  // class lists + schedule
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,

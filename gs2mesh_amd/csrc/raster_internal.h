@@ -29,8 +29,9 @@ void gs2m_launch_pack_camera(hipStream_t st, CamUniform* cams, int slot, const f
                              const float* projmatrix, const float* campos, const float* bg, float tanfovx,
                              float tanfovy, int W, int H, int th);
 
-void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count, unsigned* done,
-                              unsigned* tile_start, int gx, ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists);
+void gs2m_launch_hist_colscan(hipStream_t st, int nv, unsigned* hist, int n_wg, int tiles, unsigned* tile_count);
+void gs2m_launch_tile_scan(hipStream_t st, int nv, const unsigned* tile_count, unsigned* tile_start, int tiles, int gx,
+                           ViewStatus* status, ViewStatus* sticky, unsigned cap, unsigned* sort_lists);
 size_t gs2m_sort_lists_words(int nv, int tiles);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint);

@@ -19,12 +19,17 @@
 // (L2-resident) and writes the running prefix.  16 segments: a thread's dependent chain is ~15 rows for the usual
 // ~256-row matrix (4 segments of 256-thread workgroups left the kernel latency-bound at 120 workgroups).
 #define GS2M_COLSCAN_SEGS 16
-// Exclusive scan of tile_count over tiles of view v by ONE 1024-thread workgroup (every thread of it calls this).
+// Exclusive scan of tile_count over tiles: one 1024-thread workgroup per view.
 // tile_start[v][0..tiles]; status[v] = {N, N > cap}; sticky = {max N, any N > cap} since the last status query.
-// Round 4: no launch of its own any more -- the LAST workgroup of k_hist_colscan to finish a view runs it (below).
-GS2M_DEVICE void tile_scan_view(const int v, const int n_views, const unsigned* tile_count, unsigned* __restrict__ tile_start,
-                                int tiles, int gx, ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap,
-                                unsigned* __restrict__ sort_lists) {
+// (Round 4 tried to run this in the LAST workgroup of k_hist_colscan to finish a view -- ticket counter + __threadfence -- to
+// save the launch: the agent-scope release every one of the ~470 column-scan workgroups then executes writes back its XCD's
+// whole L2 (the histogram rows the counting kernel just wrote are dirty there): k_hist_colscan 21 -> 129 us per launch, step
+// 0.304 -> 0.392 ms.  Reverted; profiles/r4_experiments.txt.)
+GS2M_KERNEL void __launch_bounds__(1024)
+k_tile_scan(const unsigned* __restrict__ tile_count, unsigned* __restrict__ tile_start, int tiles, int gx,
+            ViewStatus* __restrict__ status_all, ViewStatus* __restrict__ sticky, unsigned cap, unsigned* __restrict__ sort_lists) {
+    const int v = (int)blockIdx.x, n_views = (int)gridDim.x;
+    ViewStatus* status = status_all + v;
     __shared__ unsigned part[16];    // wave totals of the scan
     __shared__ unsigned n_class[GS2M_SORT_CLASSES];
     __shared__ unsigned w_pos[64];   // compositing schedule: 64 weight buckets of the list chunks
@@ -139,11 +144,8 @@ GS2M_DEVICE void tile_scan_view(const int v, const int n_views, const unsigned* 
 }
 
 GS2M_KERNEL void __launch_bounds__(64 * GS2M_COLSCAN_SEGS)
-k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count, unsigned* __restrict__ done,
-               unsigned* __restrict__ tile_start, int gx, ViewStatus* __restrict__ status, ViewStatus* __restrict__ sticky, unsigned cap,
-               unsigned* __restrict__ sort_lists) {
+k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __restrict__ tile_count) {
     __shared__ unsigned seg_sum[GS2M_COLSCAN_SEGS][64];
-    __shared__ unsigned s_last;
     const int lane = (int)(threadIdx.x & 63u), seg = (int)(threadIdx.x >> 6);
     const int t = (int)blockIdx.x * 64 + lane;
     const int v = (int)blockIdx.y;
@@ -191,17 +193,6 @@ k_hist_colscan(unsigned* __restrict__ hist, int n_wg, int tiles, unsigned* __res
         }
         if (seg == 0) tile_count[(size_t)v * tiles + t] = total;
     }
-    // The tile scan of a view needs every column total of it: the workgroup that finishes the view LAST runs it (release:
-    // the totals of this workgroup are visible device-wide before its ticket; acquire: the last one sees all of them).  One
-    // launch and one launch gap less on the critical chain of every pass (round 3: k_tile_scan 10.6 us + the gap).
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&done[v], 1u) == gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (s_last == 0u) return;
-    __threadfence();
-    if (threadIdx.x == 0) done[v] = 0u;   // ready for the next pass on this handle
-    tile_scan_view(v, (int)gridDim.y, tile_count, tile_start, tiles, gx, status + v, sticky, cap, sort_lists);
 }
 
 // ---- register-blocked bitonic sort -----------------------------------------------------------

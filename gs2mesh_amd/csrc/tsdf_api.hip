@@ -340,8 +340,8 @@ extern "C" int gs2m_tsdf_integrate_batch(gs2m_tsdf* t, int n_frames, const float
         gs2m_set_error("[ScalableTSDFVolume::Integrate] Unsupported image format.");
         return 1;
     }
-    if (n_frames > 0 && (width <= 0 || height <= 0 || !(fx != 0) || !(fy != 0) || !(depth_scale != 0))) {
-        gs2m_set_error("gs2m_tsdf_integrate_batch: bad intrinsics / size");
+    if (n_frames > 0 && (width <= 0 || height <= 0 || width > 65535 || height > 65535 || !(fx != 0) || !(fy != 0) || !(depth_scale != 0))) {
+        gs2m_set_error("gs2m_tsdf_integrate_batch: bad intrinsics / size (the sweep packs pixel coordinates in 16 bits: <= 65535)");
         return 1;
     }
     HIPCHK(hipSetDevice(t->device));

@@ -379,6 +379,12 @@ k_tsdf_integrate(TsdfVolume V, TsdfFrame f, const float* __restrict__ depth, con
 // by k_tsdf_clear_fmask afterwards (the four quarters of a block run on different workgroups).  C2: 39.2 -> 32.7 us per frame
 // in sweeps of 10, 36.9 -> 29.7 in sweeps of 24; forcing 6 / 7 waves per SIMD (80 / 72 VGPRs, spills) gains nothing (32.9 /
 // 35.7).  Same arithmetic per voxel: bit-identical.
+// Round 4, measured and not kept (profiles/r4_experiments.txt): the frames of a block probed four at a time by the four waves
+// of the workgroup ("frame lanes": LDS exchange + barrier per round, one voxel of state per thread) 30 -> 80 us per frame --
+// the dependent round trips only move from the frame loop to a loop over x-quarters; the colour gathered together with the
+// depth (one round trip per frame instead of two dependent ones, but for every probed voxel) 30.5 -> 35.2: the sweep is bound
+// by the number of gathers and its ~12 M vector instructions per frame, not by exposed latency; 6 waves per SIMD (80 VGPRs,
+// 5 spilled) 30.5 -> 30.5 on C2, 76.6 -> 72.1 on C4 (not worth a second kernel).
 GS2M_KERNEL void __launch_bounds__(256)
 k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) {
     __shared__ float s_p0[16], s_p1[16];
@@ -433,7 +439,8 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
         // order with the same arithmetic: bit-identical to the frame-by-frame path.
         struct Probe {
             int fi;
-            int pix[4], uu[4], vv[4];
+            int pix[4];
+            unsigned uv[4];        // u | v << 16 (image sizes <= 65535, checked by the host side)
             float zc[4], d[4];
         };
         auto probe = [&](const int fi, Probe& P) __attribute__((always_inline)) {
@@ -455,15 +462,15 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 P.pix[j] = -1;
-                P.uu[j] = P.vv[j] = 0;
+                P.uv[j] = 0u;
                 P.zc[j] = pc2;
                 if (!(pc2 <= 0)) {
                     const float u_f = pc0 * f.fx_f / pc2 + f.cx_f + 0.5f;
                     const float v_f = pc1 * f.fy_f / pc2 + f.cy_f + 0.5f;
                     if (u_f >= 0.0001f && u_f < f.safe_w && v_f >= 0.0001f && v_f < f.safe_h) {
-                        P.uu[j] = (int)u_f;
-                        P.vv[j] = (int)v_f;
-                        P.pix[j] = P.vv[j] * f.W + P.uu[j];
+                        const int uu = (int)u_f, vv = (int)v_f;
+                        P.uv[j] = (unsigned)uu | ((unsigned)vv << 16);
+                        P.pix[j] = vv * f.W + uu;
                     }
                 }
                 pc0 += f.Es02;
@@ -501,8 +508,8 @@ k_tsdf_integrate_batch(TsdfVolume V, const TsdfBatchFrame* __restrict__ frames) 
                 }
                 if (P.pix[j] >= 0 && dd > 0.0f) {
                     // Image::CreateDepthToCameraDistanceMultiplierFloatImage, evaluated on the fly and only here
-                    const float xx = (P.uu[j] - f.cx_f) * f.fx_inv_f;
-                    const float yy = (P.vv[j] - f.cy_f) * f.fy_inv_f;
+                    const float xx = ((int)(P.uv[j] & 0xffffu) - f.cx_f) * f.fx_inv_f;
+                    const float yy = ((int)(P.uv[j] >> 16) - f.cy_f) * f.fy_inv_f;
                     const float mult = sqrtf(xx * xx + yy * yy + 1.0f);
                     const float sdf = (dd - P.zc[j]) * mult;
                     if (sdf > -f.sdf_trunc_f) {

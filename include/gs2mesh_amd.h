@@ -87,7 +87,7 @@ enum {
 enum {
     GS2M_STAGE_PROJECT = 0, /* k_project       */
     GS2M_STAGE_COLSCAN = 1, /* k_hist_colscan  */
-    GS2M_STAGE_TILESCAN = 2,/* (round 4: fused into k_hist_colscan -- its last workgroup per view; always 0 launches) */
+    GS2M_STAGE_TILESCAN = 2,/* k_tile_scan     */
     GS2M_STAGE_SCATTER = 3, /* k_scatter       */
     GS2M_STAGE_SORT = 4,    /* k_sort_tiles    */
     GS2M_STAGE_BLEND = 5,   /* k_blend_*       */

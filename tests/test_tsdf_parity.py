@@ -206,13 +206,17 @@ def test_packed_exchange_form_flags_values_that_do_not_fit_its_fields(backend):
     assert vol.frames_integrated == 0 and vol.status()[2] == 0
 
 
-@pytest.mark.parametrize("color,use_mask", [(True, False), (True, True), (False, False)])
-def test_batch_integrate_is_bit_identical_to_frame_by_frame(backend, color, use_mask):
+@pytest.mark.parametrize("color,use_mask,n_frames,splits", [(True, False, 7, ((0, 4), (4, 7))), (True, True, 7, ((0, 4), (4, 7))),
+                                                            (False, False, 7, ((0, 4), (4, 7))), (True, True, 11, ((0, 11),)),
+                                                            (True, False, 11, ((0, 2), (2, 11)))])
+def test_batch_integrate_is_bit_identical_to_frame_by_frame(backend, color, use_mask, n_frames, splits):
     """gs2m_tsdf_integrate_batch (voxel-stationary: all frames of the batch in one sweep over the touched blocks) vs the
     per-frame path in the same frame order and vs the oracle: block sets, counts, tsdf and colour sums bit for bit, with
-    min-depth, depth scale / truncation and (optionally) per-frame masks; a second batch continues the same volume."""
+    min-depth, depth scale / truncation and (optionally) per-frame masks; a second batch continues the same volume.  Sweeps of
+    11 / 9 frames: blocks touched by more than four frames take several rounds of the frame-lane sweep (k_tsdf_sweep_fl: four
+    frames per round, ping-pong LDS buffers), a partial last round included."""
     be = backend
-    frs, K = frames(7, 160, 120, 170.0)
+    frs, K = frames(n_frames, 160, 120, 170.0)
     W, H, fx, fy, cx, cy = K
     voxel, trunc = 2.0 / 128, 0.08
     rng = np.random.default_rng(4)
@@ -228,7 +232,7 @@ def test_batch_integrate_is_bit_identical_to_frame_by_frame(backend, color, use_
         dd = np.where(dd < np.float32(2.9), 0, dd).astype(np.float32)
         ref.integrate(oracle.ScalableTSDFVolume.convert_depth(dd, 1.25, 3.4), c if color else None, W, H, fx, fy, cx, cy, E)
     bat = ScalableTSDFVolume(voxel, trunc, ct, max_blocks=2048, lib=be.lib)
-    for lo, hi in ((0, 4), (4, 7)):                 # two batches: the second one continues the running means
+    for lo, hi in splits:                           # the second batch continues the running means
         bat.integrate_batch([RGBDImage(be.dev(c), be.dev(d), **kw) for d, c, E in frs[lo:hi]], intr,
                             [E for _, _, E in frs[lo:hi]],
                             masks=[None if m is None else be.dev(m) for m in masks[lo:hi]] if use_mask else None,
