@@ -48,8 +48,8 @@ struct gs2m_raster {
     std::vector<EvPair> ev_live;        // recorded, not yet read
     std::vector<hipEvent_t> ev_free;    // recycled events
     CamUniform* d_cams = nullptr;  // [GS2M_MAX_PASS_VIEWS]
-    GeomRec* d_recs = nullptr;
-    size_t recs_cap = 0;  // records
+    float4* d_recs = nullptr;   // [3 * recs_cap] float4: the 32-B parts of recs_cap records, then their 16-B parts (GeomRecs)
+    size_t recs_cap = 0;  // float4s
     unsigned long long* d_tilemask = nullptr;
     float* d_shpack = nullptr;   // wave-transposed SH copy of the Gaussians last passed to gs2m_raster_pack_sh
     size_t shpack_cap = 0;
@@ -236,7 +236,7 @@ extern "C" int gs2m_raster_reserve(gs2m_raster* r, int P, int n_views, int W, in
     const int tiles = ((W + GS2M_TILE - 1) / GS2M_TILE) * ((H + GS2M_TILE - 1) / GS2M_TILE);
     int chunk, n_wg;
     geometry(r, P, &chunk, &n_wg);
-    if (ensure(&r->d_recs, &r->recs_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
+    if (ensure(&r->d_recs, &r->recs_cap, 3 * (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
     if (ensure(&r->d_tilemask, &r->mask_cap, (size_t)nv * (size_t)(P > 0 ? P : 1))) return 1;
     if (ensure(&r->d_hist, &r->hist_cap, (size_t)nv * n_wg * tiles)) return 1;
     size_t tc = r->tile_cap;
@@ -330,18 +330,20 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     }
     if (gs2m_raster_reserve(r, g.P, nvt, W, H, 0)) return 1;
     const unsigned cap = r->inst_cap;
+    // the records of the pass: [nvt * P] 32-B parts, then [nvt * P] 16-B parts
+    const GeomRecs recs{r->d_recs, r->d_recs + 2 * (size_t)nvt * (size_t)g.P};
     const int cull_arg_p = r->opt_exact_cull, cull_arg_s = r->opt_exact_cull;  // same option for counting and scatter
     // (round 3: projection and counting fused into one kernel -- the counting workgroups projecting their own Gaussians and
     // going on from registers -- measured 51 vs 28 + 28 us on C2 and 212 vs 135 + 80 us on C3: the counting step is bound by
     // its own LDS atomics and tile tests, not by re-reading the records; 128 VGPRs for 1024-thread workgroups.  Not kept.)
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
-        gs2m_launch_project(nv, pairs, st, g, r->d_cams, r->d_recs, out_radii, cull_arg_p, host_cams);
+        gs2m_launch_project(nv, pairs, st, g, r->d_cams, recs, out_radii, cull_arg_p, host_cams);
     }
     if (dbg_check(r, st, "project")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_COUNT);
-        if (gs2m_launch_count_tiles(nv, pairs, n_wg, wg_threads, lds_p, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
+        if (gs2m_launch_count_tiles(nv, pairs, n_wg, wg_threads, lds_p, st, recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
                                     cull_arg_p, g.ids != nullptr))
             return 1;
     }
@@ -358,7 +360,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     if (dbg_check(r, st, "tile_scan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
-        if (gs2m_launch_scatter(nv, pairs, n_wg, wg_threads, lds, st, r->d_recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
+        if (gs2m_launch_scatter(nv, pairs, n_wg, wg_threads, lds, st, recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
                                 r->d_tilemask, r->d_keys, cap, cull_arg_s, g.ids, g.ids != nullptr))
             return 1;
     }
@@ -383,7 +385,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     if (dbg_check(r, st, "sort_tiles")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
-        if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, r->d_recs, r->d_cams,
+        if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, recs, r->d_cams,
                               g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
                               r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_mode))
             return 1;
@@ -722,11 +724,25 @@ extern "C" int gs2m_raster_download_geometry(gs2m_raster* r, gs2m_stream stream,
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (P == 0) return 0;
     GeomRec* h = (GeomRec*)malloc(sizeof(GeomRec) * (size_t)P);
-    if (!h) {
+    float4* hab = (float4*)malloc(sizeof(float4) * 2 * (size_t)P);
+    float4* hc = (float4*)malloc(sizeof(float4) * (size_t)P);
+    if (!h || !hab || !hc) {
+        free(h);
+        free(hab);
+        free(hc);
         gs2m_set_error("out of host memory");
         return 1;
     }
-    hipError_t e = hipMemcpy(h, r->d_recs + (size_t)v * P, sizeof(GeomRec) * (size_t)P, hipMemcpyDeviceToHost);
+    // the two arrays of the last pass (GeomRecs: [last_nv * P] 32-B parts, then the 16-B parts) -> whole records
+    hipError_t e = hipMemcpy(hab, r->d_recs + 2 * (size_t)v * P, sizeof(float4) * 2 * (size_t)P, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(hc, r->d_recs + 2 * (size_t)r->last_nv * P + (size_t)v * P, sizeof(float4) * (size_t)P, hipMemcpyDeviceToHost);
+    for (int i = 0; e == hipSuccess && i < P; ++i) {
+        memcpy(&h[i], &hab[2 * (size_t)i], 32);
+        memcpy(reinterpret_cast<char*>(&h[i]) + 32, &hc[i], 16);
+    }
+    free(hab);
+    free(hc);
     if (e != hipSuccess) {
         free(h);
         gs2m_set_error("hipMemcpy: %s", hipGetErrorString(e));

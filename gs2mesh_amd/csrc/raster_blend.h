@@ -25,7 +25,7 @@ GS2M_DEVICE unsigned char quantize_u8(float c) {
 
 GS2M_KERNEL void __launch_bounds__(256)
 k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
-                const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
+                const GeomRecs recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
                 float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank) {
     __shared__ float4 s_a[256];  // mx, my, ca, cb
     __shared__ float4 s_b[256];  // cc, op, r, g
@@ -45,7 +45,7 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
     if (r0 > cap) r0 = cap;
     if (r1 > cap) r1 = cap;
     const unsigned long long* kv = keys + (size_t)v * cap;
-    const GeomRec* rv = recs + (size_t)v * P;
+    const GeomRecs rv = gs2m_recs_at(recs, (size_t)v * P);
     bool done = !inside;
     float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     int todo = (int)(r1 - r0);
@@ -55,10 +55,9 @@ k_blend_tile256(const unsigned long long* __restrict__ keys, const unsigned* __r
         if (base + (unsigned)tid < r1) {
             unsigned gid = (unsigned)(kv[base + tid] & 0xffffffffull);
             if (rank) gid = (unsigned)rank[gid];   // packed model: id in the key -> position of the record
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
-            s_a[tid] = r4[0];
-            s_b[tid] = r4[1];
-            s_c[tid] = r4[2].x;
+            s_a[tid] = rv.ab[2 * (size_t)gid];
+            s_b[tid] = rv.ab[2 * (size_t)gid + 1];
+            s_c[tid] = rv.c[gid].x;
         }
         __syncthreads();
         const int nb = todo < 256 ? todo : 256;
@@ -148,7 +147,7 @@ struct BlendInst {
 template <int WPB, int LROWS, int OCC, int MODE = 0>
 GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
-               const GeomRec* __restrict__ recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
+               const GeomRecs recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
                const unsigned* __restrict__ order) {
     // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
@@ -217,7 +216,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     r0 = (unsigned)gs2m_uniform((int)r0);
     r1 = (unsigned)gs2m_uniform((int)r1);
     const unsigned long long* kv = keys + (size_t)v * cap;
-    const GeomRec* rv = recs + (size_t)v * P;
+    const GeomRecs rv = gs2m_recs_at(recs, (size_t)v * P);
     const float LOG2E = 1.44269504088896340736f;
     const float QMIN = -7.99435343685885793770f;  // -log2(255): alpha >= 1/255 <=> q >= QMIN (decided in the log2 domain)
     // ---- prefetch pipeline: ids two batches ahead (one VGPR), records one batch ahead (DMA into LDS).  With a packed
@@ -236,10 +235,10 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             if (base + 64u + (unsigned)lane < r1) gid_next = (unsigned)rank[gid_next];
         }
         if (base + (unsigned)lane < r1) {
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid);
+            const float4* r4 = rv.ab + 2 * (size_t)gid;
             gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
             gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
-            gs2m_global_load_lds16(r4 + 2, &s_raw[wave][2][0]);
+            gs2m_global_load_lds16(rv.c + gid, &s_raw[wave][2][0]);
         }
     }
     while (base < r1) {
@@ -315,10 +314,10 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         const int nb = LROWS > 1 ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
         base += 64u;
         if (base + (unsigned)lane < r1) {  // records of the next batch -> LDS while this one is composited
-            const float4* r4 = reinterpret_cast<const float4*>(rv + gid_next);
+            const float4* r4 = rv.ab + 2 * (size_t)gid_next;
             gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
             gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
-            gs2m_global_load_lds16(r4 + 2, &s_raw[wave][2][0]);
+            gs2m_global_load_lds16(rv.c + gid_next, &s_raw[wave][2][0]);
         }
         if (rank) {
             // both loads are consumed after the next gs2m_wait_dma: the rank of the ids fetched a batch ago, and new ids

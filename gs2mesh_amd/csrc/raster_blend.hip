@@ -6,7 +6,7 @@
 //   variant 4: wave-per-tile kernel (k_blend_wave4e),
 //   0: the reference's structure (256-thread workgroup per tile, 1 pixel per lane; 16 x 16 lists only)
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
-                      const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P, unsigned cap,
+                      const unsigned* tile_start, GeomRecs recs, const CamUniform* cams, int P, unsigned cap,
                       float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order, int mode) {
     const dim3 block(256);
     if (variant == 4) {

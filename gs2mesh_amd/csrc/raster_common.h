@@ -32,16 +32,24 @@ struct CamUniform {
 #define GS2M_CAM_ROWS(cam) ((cam).th >> 4)
 #define GS2M_CAM_GYS(cam) (((cam).gy + ((cam).th >> 4) - 1) / ((cam).th >> 4))
 
-// Projected per-(view, Gaussian) record: 48 B, three 16-B vectors so that the blend stage
-// gathers one contiguous record per instance instead of three arrays
-// (reference: means2D 8 B + conic_opacity 16 B + rgb 12 B + depth 4 B in four arrays,
-// rasterizer_impl.h:30-45; rgb gathered from global per contributing pixel, forward.cu:355).
-struct alignas(16) GeomRec {
+// Projected per-(view, Gaussian) record: 48 B = three 16-B vectors
+//   {mx, my, ca, cb} {cc, op, r, g} | {b, depth, rect0, rect1}
+// (reference: means2D 8 B + conic_opacity 16 B + rgb 12 B + depth 4 B in four arrays, rasterizer_impl.h:30-45; rgb gathered
+// from global per contributing pixel, forward.cu:355).  Round 4: stored as TWO arrays -- the 32-B geometry / colour part `ab`
+// and the 16-B binning part `c` (depth + tile rect, + the blue channel to fill the vector) -- because the scatter kernel needs
+// the binning part only: out of the 48-B records its 16-B loads still pulled every line (C3: 245 MB fetched for 64 MB used,
+// PMC round 3).  The compositing stage gathers both parts of an instance (three 16-B DMA loads, as before).
+struct GeomRec {             // host-side / emulator view of one whole record (parity taps)
     float mx, my, ca, cb;    // mean2D, conic.x, conic.y
     float cc, op, r, g;      // conic.z, opacity, rgb.r, rgb.g
     float b, depth;          // rgb.b, view-space z
     unsigned rect0, rect1;   // tile rect: rect0 = x0 | y0<<16, rect1 = x1 | y1<<16 (x1==x0 => invisible)
 };
+struct GeomRecs {            // device view: both arrays hold [views * P] records, passed by value
+    float4* ab;              // [i][2]
+    float4* c;               // [i]
+};
+GS2M_DEVICE GeomRecs gs2m_recs_at(const GeomRecs& r, size_t first) { return GeomRecs{r.ab + 2 * first, r.c + first}; }
 
 // Inputs of the projection stage (device pointers).
 struct GaussIn {

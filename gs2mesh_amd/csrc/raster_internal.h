@@ -8,14 +8,14 @@
 size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads);
 // host_cams: null (the uniforms are already in `cams`, device memory) or the nv * pairs host-side uniforms of the pass (carried in
 // the launch packet; the kernel also stores them to `cams`)
-void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRec* recs, int* radii,
+void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRecs recs, int* radii,
                          int exact_cull, const CamUniform* host_cams);
-int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull, int interleave);
 int gs2m_count_threads(int chunk, int max_threads);
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads);
-int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
                         const int* ids, int interleave);
@@ -36,7 +36,7 @@ size_t gs2m_sort_lists_words(int nv, int tiles);
 void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, unsigned long long* tmp,
                             const unsigned* tile_start, int tiles, unsigned cap, const unsigned* sort_lists, const int* class_hint);
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
-                      const unsigned* tile_start, const GeomRec* recs, const CamUniform* cams, int P,
+                      const unsigned* tile_start, GeomRecs recs, const CamUniform* cams, int P,
                       unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order,
                       int mode);
 

@@ -133,7 +133,7 @@ GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
 // zeroed and ok = false when nothing of the Gaussian reaches view v) and op the activated opacity: the fused
 // projection + counting kernel continues from these registers.  s_sh = this wave's DMA landing zone, [12][64] float4 (DMA_SH only).
 template <int NV, bool DMA_SH, bool STREAM = true>
-GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs,
+GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict__ cams, const GeomRecs recs,
                                   int* __restrict__ radii, int exact_cull, int gi, bool valid, float4* s_sh, int lane_id,
                                   ProjView* pv, float& op, float& thr) {
     const int ncoef = (g.D + 1) * (g.D + 1);
@@ -235,7 +235,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
             if (exact_cull) thr = cull_threshold(op);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                GeomRec* rec = recs + (size_t)v * g.P + gi;
+                const size_t ri = (size_t)v * g.P + gi;
                 if (radii) radii[(size_t)v * g.P + (g.ids ? g.ids[gi] : gi)] = pv[v].radius;
                 if (!pv[v].ok) {
                     // invisible: only the vector holding the (empty) rect is written
@@ -244,7 +244,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                     w2.y = 0.0f;
                     w2.z = 0.0f;
                     w2.w = 0.0f;
-                    reinterpret_cast<float4*>(rec)[2] = w2;
+                    recs.c[ri] = w2;
                     continue;
                 }
                 float cr, cg, cb;
@@ -316,10 +316,9 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                 w2.y = pv[v].depth;
                 w2.z = __uint_as_float((unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16));
                 w2.w = __uint_as_float((unsigned)pv[v].x1 | ((unsigned)pv[v].y1 << 16));
-                float4* r4 = reinterpret_cast<float4*>(rec);
-                r4[0] = w0;
-                r4[1] = w1;
-                r4[2] = w2;
+                recs.ab[2 * ri] = w0;
+                recs.ab[2 * ri + 1] = w1;
+                recs.c[ri] = w2;
             }
         }
     }
@@ -340,7 +339,7 @@ struct CamUniformArg {
 // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.  The
 // colour pass then reads the 16 coefficients of one channel at a time back from LDS.
 template <int NV, bool DMA_SH, bool STREAM, bool HOSTCAMS>
-GS2M_DEVICE void project_kernel_body(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs,
+GS2M_DEVICE void project_kernel_body(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRecs recs,
                                      int* __restrict__ radii, int exact_cull, CamUniform* __restrict__ cams_out) {
     __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
     // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH: two stereo pairs per launch)
@@ -351,7 +350,7 @@ GS2M_DEVICE void project_kernel_body(const GaussIn& g, const CamUniform* __restr
         unsigned* dst = reinterpret_cast<unsigned*>(cams_out + NV * blockIdx.y);
         for (unsigned i = threadIdx.x; i < NV * sizeof(CamUniform) / 4u; i += GS2M_PROJECT_THREADS) dst[i] = src[i];
     }
-    recs += (size_t)NV * blockIdx.y * g.P;
+    recs = gs2m_recs_at(recs, (size_t)NV * blockIdx.y * g.P);
     if (radii) radii += (size_t)NV * blockIdx.y * g.P;
     const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
     const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
@@ -362,14 +361,14 @@ GS2M_DEVICE void project_kernel_body(const GaussIn& g, const CamUniform* __restr
 // uniforms in device memory (operator-level API: the caller's matrices are device tensors, k_pack_camera)
 template <int NV, bool DMA_SH, bool STREAM = true>
 GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // forcing 5 waves per SIMD on the round-2 kernel (96 VGPRs, spills): C2 30 -> 36 us, C3 149 -> 204
-k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRec* __restrict__ recs, int* __restrict__ radii,
+k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRecs recs, int* __restrict__ radii,
           int exact_cull) {
     project_kernel_body<NV, DMA_SH, STREAM, false>(g, cams, recs, radii, exact_cull, nullptr);
 }
 // uniforms in the kernel arguments (pipeline-level API, host-side cameras)
 template <int NV, bool DMA_SH, bool STREAM = true>
 GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
-k_project_hc(GaussIn g, CamUniformArg hc, CamUniform* __restrict__ cams_out, GeomRec* __restrict__ recs, int* __restrict__ radii,
+k_project_hc(GaussIn g, CamUniformArg hc, CamUniform* __restrict__ cams_out, GeomRecs recs, int* __restrict__ radii,
              int exact_cull) {
     project_kernel_body<NV, DMA_SH, STREAM, true>(g, &hc.c[0], recs, radii, exact_cull, cams_out);
 }
@@ -518,7 +517,7 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
 // writes the workgroup's histogram row.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(1024)
-k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
+k_count_tiles(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
               unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull, int interleave) {
     GS2M_DYN_LDS(unsigned, lds);
     const int tid = (int)threadIdx.x;
@@ -527,7 +526,7 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
     // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH): its own records, masks and histogram rows
     cams += NV * blockIdx.y;
-    recs += (size_t)NV * blockIdx.y * P;
+    recs = gs2m_recs_at(recs, (size_t)NV * blockIdx.y * P);
     tilemask += (size_t)NV * blockIdx.y * P;
     hist += (size_t)NV * blockIdx.y * n_wg * tiles;
     // workgroup-private tile histogram, two 16-bit counters per word (a workgroup owns `chunk` <= 65535
@@ -550,10 +549,10 @@ k_count_tiles(const GeomRec* __restrict__ recs, int P, const CamUniform* __restr
         for (int v = 0; v < NV; ++v) {
             nw0[v] = nw1[v] = nw2[v] = float4{0.0f, 0.0f, 0.0f, 0.0f};
             if (f0 >= 0 && f0 + lane < e0) {
-                const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + f0 + lane);
-                nw2[v] = r4[2];
-                nw0[v] = r4[0];
-                nw1[v] = r4[1];
+                const size_t ri = (size_t)v * P + f0 + lane;
+                nw2[v] = recs.c[ri];
+                nw0[v] = recs.ab[2 * ri];
+                nw1[v] = recs.ab[2 * ri + 1];
             }
         }
     };
@@ -616,7 +615,7 @@ struct ScatterStage {
 // replay the tile mask written there, larger ones repeat the same per-tile test.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(1024)
-k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
+k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
           const unsigned* __restrict__ hist, const unsigned* __restrict__ tile_start,
           const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
           int exact_cull, const int* __restrict__ ids, int interleave) {
@@ -627,7 +626,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
     // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH)
     cams += NV * blockIdx.y;
-    recs += (size_t)NV * blockIdx.y * P;
+    recs = gs2m_recs_at(recs, (size_t)NV * blockIdx.y * P);
     tilemask += (size_t)NV * blockIdx.y * P;
     hist += (size_t)NV * blockIdx.y * n_wg * tiles;
     tile_start += (size_t)NV * blockIdx.y * (tiles + 1);
@@ -659,7 +658,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
             n_msk = 0ull;
             if (f0 >= 0 && f0 + lane < e0) {
                 if (ids) n_kid = (unsigned)ids[f0 + lane];
-                n_w2 = reinterpret_cast<const float4*>(recs + (size_t)v * P + f0 + lane)[2];
+                n_w2 = recs.c[(size_t)v * P + f0 + lane];   // the 16-B binning part only: contiguous, fully used lines
                 n_msk = tilemask[(size_t)v * P + f0 + lane];   // only meaningful (and only used) for rects of <= 64 tiles
             }
         };
@@ -744,7 +743,7 @@ k_scatter(const GeomRec* __restrict__ recs, int P, const CamUniform* __restrict_
                 const unsigned long long key = ((unsigned long long)gs2m_shfl(dbits, o) << 32) | gs2m_shfl(kid, o);
                 float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
                 if (exact_cull) {
-                    const float4* r4 = reinterpret_cast<const float4*>(recs + (size_t)v * P + gs2m_shfl(gi, o));
+                    const float4* r4 = recs.ab + 2 * ((size_t)v * P + gs2m_shfl(gi, o));
                     const float4 w0 = r4[0];
                     const float4 w1 = r4[1];
                     mx = w0.x;

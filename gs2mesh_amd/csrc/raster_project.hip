@@ -16,7 +16,7 @@ size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads) {
     return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_SCATTER_STAGE_BYTES_PER_WAVE;
 }
 
-void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRec* recs, int* radii,
+void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRecs recs, int* radii,
                          int exact_cull, const CamUniform* host_cams) {
     const unsigned nx = (unsigned)((g.P + 255) / 256);
     if (nx == 0) return;
@@ -48,7 +48,7 @@ void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, Ca
     else GS2M_LAUNCH((k_project<1, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
 }
 
-int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull, int interleave) {
     if (lds_bytes > 64 * 1024) {
@@ -70,7 +70,7 @@ int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds
     return 0;
 }
 
-int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, const GeomRec* recs, int P,
+int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
                         const int* ids, int interleave) {
