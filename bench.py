@@ -152,8 +152,11 @@ def main():
                          "world size 1: times the local part of the exchange (key union, pack, RCCL self-copy, unpack) on one GPU")
     ap.add_argument("--tile-rows", type=int, default=int(os.environ.get("GS2M_BENCH_TILE_ROWS", "2")), choices=[1, 2],
                     help="binning tile = 16 x (16*rows) pixels (GS2M_OPT_TILE_ROWS); 1 = the reference's tiles")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "6")),
-                    help="stereo pairs in flight on separate HIP streams (1 = everything serial on one stream)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("GS2M_BENCH_INFLIGHT", "2")),
+                    help="launch chains in flight on separate HIP streams (1 = everything serial on one stream).  Round 4: 2 (x 2 "
+                         "stereo pairs per launch = 4 pairs in flight) -- with two pairs per launch more slots only add contention and "
+                         "pipeline fill / drain: C2 20-step job 0.292 (2 slots) / 0.307 (3) / 0.309 (4) / 0.301 (5) / 0.307 (6) ms per "
+                         "step, profiles/r4_pipeline_sweeps.txt")
     ap.add_argument("--fuse-batch", type=int, default=int(os.environ.get("GS2M_BENCH_FUSE_BATCH", "0")),
                     help="views integrated per voxel-stationary TSDF batch sweep (1 = view by view; same volume either way); "
                          "0 (default) = the K views of a job in equal sweeps of at most 32 views")
