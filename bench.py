@@ -163,7 +163,7 @@ def main():
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
-    ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "2")), choices=[1, 2],
+    ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "2")), choices=[1, 2, 4],
                     help="2 (default) = two consecutive stereo pairs share every launch of the binning chain and the compositing "
                          "(GS2M_OPT_PAIR_BATCH; same images and volume; C2 0.315 -> 0.305 ms per step); 1 = one pair per launch")
     ap.add_argument("--min-repeats", type=int, default=5)
@@ -248,7 +248,7 @@ def main():
         if args.fuse_batch < 2 or K < 2:
             args.pairs_per_launch = 1
         else:
-            args.fuse_batch += args.fuse_batch % 2
+            args.fuse_batch += (-args.fuse_batch) % args.pairs_per_launch
     cfg = synthetic.CONFIGS[args.config]
     Wd, Ht = cfg.width, cfg.height
     cx, cy = Wd / 2.0, Ht / 2.0

@@ -176,7 +176,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             }
             r->opt_tile_rows = value;
             return 0;
-        case GS2M_OPT_PAIR_BATCH: r->opt_pair_batch = value != 0; return 0;
+        case GS2M_OPT_PAIR_BATCH:
+            if (value < 0 || value > GS2M_MAX_PAIRS) {
+                gs2m_set_error("GS2M_OPT_PAIR_BATCH must be 0 .. %d (stereo pairs per launch)", GS2M_MAX_PAIRS);
+                return 1;
+            }
+            r->opt_pair_batch = value;
+            return 0;
         case GS2M_OPT_DEBUG_SYNC: r->opt_debug = value != 0; return 0;
         case GS2M_OPT_STAGE_TIMING: r->opt_timing = value != 0; return 0;
         case GS2M_OPT_BIN_WORKGROUPS:
@@ -302,7 +308,7 @@ struct StageTimer {  // RAII: a rocTX range (GS2M_ROCTX=1) and, when timing is o
 // One fused pass over `pairs` groups of nv (<= GS2M_MAX_VIEWS) views whose CamUniforms are already in r->d_cams (host_cams ==
 // null) or travel with the projection launch (host_cams = the nv * pairs host-side uniforms).
 // A group is what one projection / counting / scatter workgroup handles (a stereo pair: parameters and Sigma once for both
-// eyes); with pairs = 2 (GS2M_OPT_PAIR_BATCH) two groups share every launch (blockIdx.y), each with half the workgroups.
+// eyes); with pairs > 1 (GS2M_OPT_PAIR_BATCH) that many groups share every launch (blockIdx.y), each with 1 / pairs of the workgroups.
 static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W, int H, float* out_color,
                      unsigned char* out_rgb8, int* out_radii, int status_slot, hipStream_t st, const CamUniform* host_cams) {
     const int nvt = nv * pairs;   // views of the pass: the scans, the per-tile sort and the compositing take them all (grid.y)
@@ -559,8 +565,13 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     while (per > 1 && gs2m_scatter_lds_bytes(per, tiles, 64) > 160 * 1024) per--;
     for (int v0 = 0; v0 < n_views;) {
         const int nv = n_views - v0 < per ? n_views - v0 : per;
-        // GS2M_OPT_PAIR_BATCH: two full groups (stereo pairs) per pass when the call has them
-        const int pairs = (r->opt_pair_batch && per == GS2M_MAX_VIEWS && n_views - v0 >= GS2M_MAX_PAIRS * per) ? GS2M_MAX_PAIRS : 1;
+        // GS2M_OPT_PAIR_BATCH: up to that many full groups (stereo pairs) per pass, as far as the call has them
+        int pairs = 1;
+        if (r->opt_pair_batch > 1 && per == GS2M_MAX_VIEWS) {
+            pairs = (n_views - v0) / per;
+            if (pairs > r->opt_pair_batch) pairs = r->opt_pair_batch;
+            if (pairs < 1) pairs = 1;
+        }
         const int nvt = nv * pairs;
         CamUniform cu[GS2M_MAX_PASS_VIEWS];
         for (int k = 0; k < nvt; ++k) {

@@ -4,7 +4,7 @@
 
 #define GS2M_TILE 16        // DGR/cuda_rasterizer/config.h:16-17 (BLOCK_X = BLOCK_Y = 16)
 #define GS2M_MAX_VIEWS 2    // views fused per workgroup (a stereo pair: the Gaussian's parameters and Sigma are read once for both)
-#define GS2M_MAX_PAIRS 2    // such groups per launch (GS2M_OPT_PAIR_BATCH): blockIdx.y of the projection / counting / scatter kernels
+#define GS2M_MAX_PAIRS 4    // such groups per launch (GS2M_OPT_PAIR_BATCH): blockIdx.y of the projection / counting / scatter kernels
 #define GS2M_MAX_PASS_VIEWS (GS2M_MAX_VIEWS * GS2M_MAX_PAIRS)
 #define GS2M_SORT_LDS 4096  // keys sorted per workgroup in LDS (32 KiB)
 // chunk of the compositing schedule (k_tile_scan -> blend): GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring lists

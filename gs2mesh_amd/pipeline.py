@@ -51,8 +51,8 @@ class RenderFusePipeline:
         # pairs_per_launch = 2 (GS2M_OPT_PAIR_BATCH): two consecutive stereo pairs go through ONE chain of launches (`submit`
         # buffers the first, the second triggers the launch; `drain` flushes an odd one).  Batched fusion only.
         self.ppl = int(pairs_per_launch)
-        if self.ppl not in (1, 2):
-            raise ValueError("pairs_per_launch must be 1 or 2")
+        if self.ppl not in (1, 2, 3, 4):
+            raise ValueError("pairs_per_launch must be 1 .. 4")
         self._group = []
         self.device = int(device)
         self.bg = bg
@@ -69,7 +69,7 @@ class RenderFusePipeline:
                 if value is not None:
                     r.set_option(self.RASTER_OPTION_IDS[name], int(value))
             if self.ppl > 1:
-                r.set_option(_lib.OPT_PAIR_BATCH, 1)
+                r.set_option(_lib.OPT_PAIR_BATCH, self.ppl)
             self.rasterizers.append(r)
             self.color.append(torch.empty((2 * self.ppl, 3, self.H, self.W), dtype=torch.float32, device=dev))
             # rgb8[j] = where slot j's latest u8 pair lives (the slot's own buffer, or the pending view's batch buffer)
@@ -103,7 +103,7 @@ class RenderFusePipeline:
         self._bflat = [torch.empty((2 * nb, self.H, self.W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
         self._bpair = [[self._bflat[b][2 * k:2 * k + 2] for k in range(nb)] for b in range(2)]
         if self.ppl > 1 and (self.fuse_batch < 2 or any(b % self.ppl for b in self._plan)):
-            raise ValueError("pairs_per_launch = 2 needs batched fusion with even sweep sizes (fuse_batch)")
+            raise ValueError("pairs_per_launch > 1 needs batched fusion with sweep sizes (fuse_batch) that are multiples of it")
         self._bcopied = [[torch.cuda.Event() for _ in range(nb)] for _ in range(2)]
         self._batch_done = [None, None]
         self._bset = 0
@@ -156,7 +156,7 @@ class RenderFusePipeline:
         ``color[slot]`` / ``rgb8[slot]`` will hold the pair (valid after `wait_rendered(slot)` / `finish`)."""
         if self.ppl > 1:
             if depth is None:
-                raise ValueError("pairs_per_launch = 2: every view is fused (depth required)")
+                raise ValueError("pairs_per_launch > 1: every view is fused (depth required)")
             self._group.append((cams, depth, extrinsic, mask, depth_scale, depth_trunc, min_depth))
             j = self._n % self.inflight
             if len(self._group) == self.ppl:

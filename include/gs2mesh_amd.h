@@ -65,10 +65,11 @@ enum {
                                      reference's `debug`: auxiliary.h:166-173)            */
     GS2M_OPT_STAGE_TIMING = 4,    /* 1 = bracket every stage launch with hipEvents on the
                                      work stream (read with gs2m_raster_stage_times)      */
-    GS2M_OPT_PAIR_BATCH = 8,      /* gs2m_render_views with >= 4 views: 1 = two stereo pairs share every launch (the projection /
-                                     counting / scatter workgroups of a pair are half as many, blockIdx.y picks the pair; scans,
-                                     per-tile sort and compositing take the four views in one grid): the per-launch and
-                                     per-workgroup fixed costs are paid once for two pairs.  Same results.  Default 0. */
+    GS2M_OPT_PAIR_BATCH = 8,      /* gs2m_render_views: up to `value` (2 .. 4; 0 / 1 = off, the default) stereo pairs share every launch
+                                     of a pass, as far as the call has them (the projection / counting / scatter workgroups of a pair are
+                                     1 / pairs as many, blockIdx.y picks the pair; scans, per-tile sort and compositing take all the views
+                                     in one grid): the per-launch and per-workgroup fixed costs are paid once, and the compositing grid
+                                     is long against its tail.  Same results. */
     /* Tuning options (results never change; defaults are the measured optima, profiles/r3_experiments.txt): */
     GS2M_OPT_BIN_WORKGROUPS = 9,  /* workgroups of the counting / scatter kernels per stereo pair (default 0 = 256, one per CU: the
                                      per-workgroup histogram rows / cursors scale with their number) */

@@ -66,8 +66,8 @@ def test_batched_fusion_equals_view_by_view(inflight, fuse_batch):
         assert np.array_equal(a, b)
 
 
-def _run_grouped(inflight, n_views, fuse_batch):
-    """pairs_per_launch = 2: the same job as `_run`, two consecutive stereo pairs per chain of launches."""
+def _run_grouped(inflight, n_views, fuse_batch, ppl=2):
+    """pairs_per_launch = ppl: the same job as `_run`, `ppl` consecutive stereo pairs per chain of launches."""
     import torch
     from gs2mesh_amd.integration import PinholeCameraIntrinsic, ScalableTSDFVolume
     from gs2mesh_amd.pipeline import RenderFusePipeline
@@ -81,7 +81,7 @@ def _run_grouped(inflight, n_views, fuse_batch):
     poses = synthetic.ring_poses(n_views, cfg.ring_radius, 0, n_views)
     intr = PinholeCameraIntrinsic(W, H, cfg.focal, cfg.focal, W / 2, H / 2)
     vol = ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, max_blocks=4096, device=0)
-    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0, fuse_batch=fuse_batch, pairs_per_launch=2)
+    pipe = RenderFusePipeline(gd, W, H, vol, intr, inflight=inflight, device=0, fuse_batch=fuse_batch, pairs_per_launch=ppl)
     cams, depths, Es = [], [], []
     for p in poses:
         l, r = synthetic.stereo_cameras(p, W, H, cfg.focal, cfg.focal, cfg.baseline)
@@ -94,14 +94,14 @@ def _run_grouped(inflight, n_views, fuse_batch):
     images = []
     for i in range(n_views):
         slot = pipe.submit(cams[i], depths[i], Es[i], depth_trunc=cfg.baseline * 20, min_depth=cfg.baseline * 4)
-        if i % 2 == 1:                                     # the group of views i - 1, i has been launched on `slot`
+        if i % ppl == ppl - 1:                             # the group of views i - ppl + 1 .. i has been launched on `slot`
             pipe.wait_rendered(slot)
             c, u = pipe.color[slot].cpu().numpy(), pipe.rgb8[slot].cpu().numpy()
-            images += [(c[0:2].copy(), u[0:2].copy()), (c[2:4].copy(), u[2:4].copy())]
-    pipe.finish()                                          # flushes an odd last view
-    if n_views % 2:
+            images += [(c[2 * k:2 * k + 2].copy(), u[2 * k:2 * k + 2].copy()) for k in range(ppl)]
+    pipe.finish()                                          # flushes an incomplete last group
+    if n_views % ppl:
         c, u = pipe.color[slot].cpu().numpy(), pipe.rgb8[slot].cpu().numpy()
-        images.append((c[0:2].copy(), u[0:2].copy()))
+        images += [(c[2 * k:2 * k + 2].copy(), u[2 * k:2 * k + 2].copy()) for k in range(n_views % ppl)]
     keys, tsdf, weight, rgb = vol.download()
     pipe.close()
     order = np.lexsort(keys.T[::-1])
@@ -109,13 +109,13 @@ def _run_grouped(inflight, n_views, fuse_batch):
     return images, keys[order], tsdf[order], weight[order], rgb[order]
 
 
-@pytest.mark.parametrize("n_views,fuse_batch", [(6, 6), (7, 4), (6, [4, 2])])
-def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch):
+@pytest.mark.parametrize("n_views,fuse_batch,ppl", [(6, 6, 2), (7, 4, 2), (6, [4, 2], 2), (8, 8, 4), (10, 8, 4), (9, 6, 3)])
+def test_two_pairs_per_launch_pipeline_equals_serial(n_views, fuse_batch, ppl):
     """RenderFusePipeline(pairs_per_launch=2): two consecutive stereo pairs per chain of launches (GS2M_OPT_PAIR_BATCH),
     their u8 pairs rendered into consecutive buffers of the pending TSDF batch; an odd last view is flushed by `finish`.
     Images and volume are bit-identical to the serial order."""
     ref = _run(1, n_views=n_views)
-    got = _run_grouped(3, n_views, fuse_batch)
+    got = _run_grouped(3 if ppl == 2 else 2, n_views, fuse_batch, ppl)
     for (c0, u0), (c1, u1) in zip(ref[0], got[0]):
         assert np.array_equal(c0, c1) and np.array_equal(u0, u1)
     for a, b in zip(ref[1:], got[1:]):

@@ -367,14 +367,16 @@ def test_list_sizes_at_the_boundaries_of_the_sort_paths(backend, n, ties):
     assert_image_close(img, ref_img)
 
 
-@pytest.mark.parametrize("rows,cull,packed,n_views", [(1, 0, False, 4), (2, 1, False, 4), (2, 1, True, 4), (2, 1, False, 5), (2, 1, False, 6),
-                                                      (2, 1, False, 8)])
-def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, rows, cull, packed, n_views):
-    """GS2M_OPT_PAIR_BATCH: the projection / counting / scatter kernels take two stereo pairs per launch (blockIdx.y picks
-    the pair, half the workgroups per pair), scans / per-tile sort / compositing the four views in one grid.  Everything a
-    call returns or leaves behind is identical to one pair per launch: images, u8 images, radii, instance counts, and --
-    per view -- the projected records and the instance lists.  5 views: one batched pass + one single view; 6: a batched
-    pass + a plain pair; 8: two batched passes."""
+@pytest.mark.parametrize("rows,cull,packed,n_views,ppl", [(1, 0, False, 4, 2), (2, 1, False, 4, 2), (2, 1, True, 4, 2), (2, 1, False, 5, 2),
+                                                          (2, 1, False, 6, 2), (2, 1, False, 8, 2), (2, 1, False, 8, 4), (2, 1, True, 8, 4),
+                                                          (2, 1, False, 7, 4), (1, 0, False, 8, 3)])
+def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, rows, cull, packed, n_views, ppl):
+    """GS2M_OPT_PAIR_BATCH: the projection / counting / scatter kernels take up to `ppl` (2 .. 4) stereo pairs per launch
+    (blockIdx.y picks the pair, 1 / pairs of the workgroups per pair), scans / per-tile sort / compositing all the views in one
+    grid.  Everything a call returns or leaves behind is identical to one pair per launch: images, u8 images, radii, instance
+    counts, and -- per view -- the projected records and the instance lists.  ppl 2: 5 views = one batched pass + one single
+    view; 6: a batched pass + a plain pair; 8: two batched passes.  ppl 4: 8 views = one pass of four pairs; 7 = a pass of three
+    pairs + a single view.  ppl 3, 8 views: a pass of three pairs + a plain pair."""
     W, H, f = 176, 112, 150.0
     g, s, q, o, shs, left, right = scene(2600, 33, W, H, f, log_s=math.log(0.05))
     *_rest, left2, right2 = scene(10, 34, W, H, f, az=0.9)       # a second pair of cameras
@@ -386,7 +388,7 @@ def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, r
               raw=True, sh_degree=3)
     tiles = ((W + 15) // 16) * (((H + 15) // 16 + rows - 1) // rows)
     outs = []
-    for batch in (0, 1):
+    for batch in (0, ppl):
         r = Rasterizer(0, lib=be.lib)
         r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
         r.set_option(_lib.OPT_TILE_ROWS, rows)
@@ -402,7 +404,7 @@ def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, r
     np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
-    if n_views == 4:
+    if n_views == 4 and ppl == 2:
         # one pair per launch leaves views 2, 3 in the arenas (as views 0, 1 of its last pass); two pairs per launch all four
         ra, rb = a[4], b[4]
         for v in range(2):
