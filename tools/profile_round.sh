@@ -26,5 +26,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_SQ -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_SQ.err
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_SQ2 -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_SQ2.err
+if [ "$CFG" = "C2" ]; then
+  # kernel trace of the PIPELINED default (what runs when): tools/trace_summary.py -> trace_summary.txt + a condensed trace
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline --no-parity --no-c3 --no-steady-state --min-repeats 3 --min-seconds 0.02 > /dev/null 2> $OUT/trace.err
+  T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
+  [ -n "$T" ] && python $R/tools/trace_summary.py $T 20 > $OUT/trace_summary.txt 2>&1
+  find $OUT/trace -name "*kernel_trace.csv" -delete    # the raw trace is large; the condensed window stays
+fi
 find $OUT -name "*.csv" | wc -l
 tail -c 300 $OUT/bench.json
