@@ -66,7 +66,8 @@ def committed_traffic(cfg_name):
 
 
 def raster_only(args, cfg_name, dev, local_rank, pairs=12):
-    """Render-only sub-measurement (no TSDF, serial on one stream, hipEvents per launch): used for the C3 sub-line."""
+    """Render-only sub-measurement (no TSDF, serial on one stream, hipEvents per launch, the default launch shape:
+    `--pairs-per-launch` stereo pairs per chain of launches): used for the C3 sub-line."""
     import torch
     from gs2mesh_amd import _lib, synthetic
     from gs2mesh_amd.rasterizer import Rasterizer, camera_from
@@ -84,14 +85,20 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     R.set_option(_lib.OPT_EXACT_TILE_CULL, int(args.cull))
     R.set_option(_lib.OPT_TILE_ROWS, int(args.tile_rows))
     R.set_option(_lib.OPT_BLEND_VARIANT, int(args.blend))
+    ppl = max(1, int(args.pairs_per_launch))
+    if ppl > 1:
+        R.set_option(_lib.OPT_PAIR_BATCH, ppl)
     if args.spatial_order > 0 or (args.spatial_order < 0 and cfg.P >= 1_000_000):
         R.pack_model(gd)
     else:
         R.pack_sh(gd)
-    color = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
-    rgb8 = torch.empty((2, cfg.height, cfg.width, 3), dtype=torch.uint8, device=dev)
-    res = R.render_views(gd, cams[0], out_color=color, out_rgb8=rgb8, want_radii=True)
-    R.reserve(cfg.P, 2, cfg.width, cfg.height, int(max(res["num_rendered"]) * 1.5))
+    color = torch.empty((2 * ppl, 3, cfg.height, cfg.width), dtype=torch.float32, device=dev)
+    rgb8 = torch.empty((2 * ppl, cfg.height, cfg.width, 3), dtype=torch.uint8, device=dev)
+    res = R.render_views(gd, cams[0], out_color=color[:2], out_rgb8=rgb8[:2], want_radii=True)
+    R.reserve(cfg.P, 2 * ppl, cfg.width, cfg.height, int(max(res["num_rendered"]) * 1.5))
+    # groups of ppl consecutive pairs = one chain of launches each
+    cams = [[c for pair in cams[i:i + ppl] for c in pair] for i in range(0, len(cams) - len(cams) % ppl, ppl)]
+    n_pairs = len(cams) * ppl
     radii0 = res["radii"]
     p_vis = [(radii0[v] > 0).sum().item() for v in range(2)]
     p_vis_union = ((radii0[0] > 0) | (radii0[1] > 0)).sum().item()
@@ -103,7 +110,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     for c in cams:
         R.render_views(gd, c, out_color=color, out_rgb8=rgb8, sync=False)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / len(cams)
+    dt = (time.perf_counter() - t0) / n_pairs
     R.set_option(_lib.OPT_STAGE_TIMING, 1)
     for c in cams:
         R.render_views(gd, c, out_color=color, out_rgb8=rgb8, sync=False)
@@ -112,14 +119,15 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     _, ov, _ = R.status(2)
     alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye)
     tr = committed_traffic(cfg_name)
+    st = {k: (ms / ppl, c) for k, (ms, c) in st.items()}     # per stereo pair (a launch covers ppl pairs)
     stages = {k: dict(avg_us=round(1e3 * ms / max(c, 1), 2), frac_hbm=round(alg[k] / max(1e-9, 1e-3 * ms / max(c, 1)) / HBM_PEAK, 4),
                       alg_bytes=int(alg[k]),
                       traffic=(int(tr[k]["hbm_bytes_per_launch"] / max(1, int(tr[k].get("pairs_per_launch", 1))))   # per stereo pair
                                if tr.get(k, {}).get("cull") == args.cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
               for k, (ms, c) in st.items()}
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
-    return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {len(cams)} pairs, "
-                         f"serial on one stream",
+    return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {n_pairs} pairs, "
+                         f"serial on one stream, {ppl} stereo pair(s) per launch (stage times per pair)", pairs_per_launch=ppl,
                 num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis, overflow=bool(ov),
                 ms_per_pair_wall=round(1e3 * dt, 4), stages=stages,
                 traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 * FETCH + WRITE) KiB per launch)",
@@ -564,10 +572,11 @@ def main():
             return oracle.ScalableTSDFVolume.convert_depth(d, 1.0, depth_trunc)
 
         # upstream runs `#pragma omp parallel for` over the 16 x-slices of one block with all host threads;
-        # on a many-core host that oversubscribes, so probe {16, all cores} on one frame and keep the faster
+        # on a many-core host that oversubscribes (C4 frames took minutes with 256 threads), so probe {16, min(64, cores)} on
+        # one frame and keep the faster
         best_threads, best_t = None, None
         d0 = prep(Wm)
-        for nt in sorted({min(16, cores), cores}):
+        for nt in sorted({min(16, cores), min(64, cores)}):
             probe = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
             probe.set_threads(nt)
             tc = time.perf_counter()
@@ -589,7 +598,7 @@ def main():
         cpu = dict(value=round(blocks_cpu * 4096 / t_cpu / 1e6, 2), unit="Mvoxel-updates/s", cores=best_threads,
                    host_cores=cores, kind="port",
                    label="restated Open3D 0.17 ScalableTSDFVolume::Integrate (oracle/tsdf_oracle.cpp, OpenMP over the "
-                         "16 x-slices of a block like upstream; thread count = faster of {16, all host cores})",
+                         "16 x-slices of a block like upstream; thread count = faster of {16, min(64, host cores)})",
                    sample=f"{n_cpu} of the {K} timed {args.config} frames ({Wd}x{Ht}), integrate() only, {t_cpu:.1f} s")
         # render half: the REFERENCE'S OWN rasteriser kernels compiled for the CPU (oracle/_ref, built in the dev
         # container from /root/reference; the prebuilt library travels to the GPU box), one eye of the first timed pair

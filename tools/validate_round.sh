@@ -9,5 +9,5 @@ CFGS=${@:-C2 C3}
 for c in $CFGS; do bash tools/profile_round.sh $TAG $c 2>&1 | tail -1 | cut -c1-200; done
 for c in C4 C5; do
   O=gpurun_out/${TAG}_$c; mkdir -p $O
-  timeout 600 python bench.py --config $c --steps 12 --warmup 4 --no-c3 --cpu-seconds 4 > $O/bench.json 2> $O/bench.err; tail -c 200 $O/bench.json
+  timeout 600 python bench.py --config $c --steps 12 --warmup 4 --no-c3 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -c 200 $O/bench.json
 done
