@@ -9,7 +9,7 @@ from gs2mesh_amd.rasterizer import Rasterizer, camera_from
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="C2,C3")
-ap.add_argument("--modes", default="0,1,2,3,4,6,7")
+ap.add_argument("--modes", default="0,1,0,1,0,1")
 ap.add_argument("--groups", type=int, default=6)
 a = ap.parse_args()
 for cname in a.configs.split(","):
@@ -25,6 +25,7 @@ for cname in a.configs.split(","):
     groups = [cams[i] + cams[i + 1] for i in range(0, len(cams), 2)]
     out = torch.empty((4, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
     ref = None
+    torch.cuda.synchronize()
     for mode in [int(m) for m in a.modes.split(",")]:
         R = Rasterizer(0)
         R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
