@@ -27,6 +27,13 @@ GS2M_DEVICE unsigned hist_get(const unsigned* hh, int hw, int t) {
     return (hh[hi ? t - hw : t] >> (hi ? 16 : 0)) & 0xffffu;
 }
 
+// A rect of the binning grid that is one tile wide or one tile high and has at most GS2M_THIN_MAX tiles: handled by its own lane
+// in k_count_tiles and k_scatter (both must classify alike).
+#define GS2M_THIN_MAX 4u
+GS2M_DEVICE bool gs2m_thin_rect(unsigned w, unsigned h, unsigned area) {
+    return area != 0u && area <= GS2M_THIN_MAX && (w == 1u || h == 1u);
+}
+
 struct ProjView {
     float mx, my, ca, cb, cc, depth, cova, covc;
     int x0, y0, x1, y1, radius;
@@ -423,8 +430,18 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
         if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
         unsigned* hh = lhist + v * hw;
         const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
+        // ---- thin rects (one tile wide or one tile high, <= GS2M_THIN_MAX tiles; round 4): no corner to cut -- the exact test only
+        // runs for rects of >= 2 x 2 tiles -- so every tile is kept: the lane bumps its own tiles, no staging, no item space, no
+        // tile mask (k_scatter classifies the rect the same way and does not read one).  A 2 M-Gaussian scene of small splats is
+        // ~80 % thin rects (C3: count 68 -> see profiles/r4_experiments.txt); C2's splats span >= 2 x 2 tiles and take the
+        // balanced walk below as before.
+        const bool thin = gs2m_thin_rect(w, h, area);
+        if (thin) {
+            const int t0 = pv[v].y0 * gx + pv[v].x0, dt = w == 1u ? gx : 1;
+            for (unsigned t = 0; t < area; ++t) hist_bump(hh, hw, t0 + (int)t * dt);
+        }
         // ---- small rects: flattened item space ----
-        const bool small = area != 0u && area <= 64u;
+        const bool small = area != 0u && area <= 64u && !thin;
         const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
         if (smalls != 0ull) {
             const int k = gs2m_popc64(smalls & lanes_lt(lane));
@@ -688,7 +705,17 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
             if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
             unsigned* cur = cursor + v * tiles;
             unsigned long long* kv = keys + (size_t)v * cap;
-            const bool small = area != 0u && area <= 64u;
+            // thin rects (see k_count_tiles): every tile is kept, the lane emits its own keys
+            const bool thin = gs2m_thin_rect(w, h, area);
+            if (thin) {
+                const unsigned long long key = ((unsigned long long)dbits << 32) | kid;
+                const int t0 = y0 * gx + x0, dt = w == 1u ? gx : 1;
+                for (unsigned t = 0; t < area; ++t) {
+                    const unsigned pos = atomicAdd(&cur[t0 + (int)t * dt], 1u);
+                    if (pos < cap) kv[pos] = key;
+                }
+            }
+            const bool small = area != 0u && area <= 64u && !thin;
             const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
             if (smalls != 0ull) {
                 const unsigned long long msk = small ? msk_pre : 0ull;
