@@ -84,8 +84,9 @@ struct gs2m_raster {
     unsigned inst_cap = 0;      // per-view capacity requested
     // [1 + GS2M_MAX_STATUS]: slot 0 is STICKY ({max instances any call needed, any call overflowed} since the last
     // gs2m_raster_status), slots 1.. are the views of the last call
-    ViewStatus* d_status = nullptr;
-    ViewStatus* h_status = nullptr;  // pinned mirror
+    ViewStatus* d_status = nullptr;  // slot 0: the sticky word (device atomics)
+    ViewStatus* h_status = nullptr;  // pinned, device-mapped: slots 1.. are WRITTEN BY k_tile_scan itself (round 4: no status copy
+                                     // launch behind every pass); slot 0 mirrors the sticky word at gs2m_raster_status
     // last call
     int last_P = 0, last_nv = 0, last_tiles = 0, last_views_total = 0;
     unsigned last_cap = 0;
@@ -361,7 +362,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     if (dbg_check(r, st, "hist_colscan")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_TILESCAN);
-        gs2m_launch_tile_scan(st, nvt, r->d_tile_count, r->d_tile_start, tiles, gx, r->d_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
+        gs2m_launch_tile_scan(st, nvt, r->d_tile_count, r->d_tile_start, tiles, gx, r->h_status + 1 + status_slot, r->d_status, cap, r->d_sort_lists);
     }
     if (dbg_check(r, st, "tile_scan")) return 1;
     {
@@ -432,8 +433,7 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     if (P == 0) {
         // rasterize_points.cu:68,81: the zero-filled image is returned untouched
         HIPCHK(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * (size_t)width * height, st));
-        HIPCHK(hipMemsetAsync(r->d_status + 1, 0, sizeof(ViewStatus), st));
-        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * 2, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemsetAsync(r->h_status + 1, 0, sizeof(ViewStatus), st));   // stream-ordered like a pass's own status write
         r->last_P = 0;
         r->last_nv = 1;
         return 0;
@@ -478,7 +478,6 @@ extern "C" int gs2m_rasterize_forward(gs2m_raster* r, int P, int D, int M, const
     int rc = run_views(r, g, 1, 1, width, height, out_color, nullptr, radii, 0, st, nullptr);
     r->opt_debug = saved_debug;
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * 2, hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -522,8 +521,7 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
     if (gs->P == 0) {
         if (out_color) HIPCHK(hipMemsetAsync(out_color, 0, sizeof(float) * 3 * img * n_views, st));
         if (out_rgb8) HIPCHK(hipMemsetAsync(out_rgb8, 0, 3 * img * n_views, st));
-        HIPCHK(hipMemsetAsync(r->d_status + 1, 0, sizeof(ViewStatus) * n_views, st));
-        HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * (n_views + 1), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemsetAsync(r->h_status + 1, 0, sizeof(ViewStatus) * n_views, st));
         return 0;
     }
     if (!gs->xyz || !gs->scales || !gs->rotations || !gs->opacities || !gs->shs) {
@@ -599,7 +597,6 @@ extern "C" int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* gs, const
             return 1;
         v0 += nvt;
     }
-    HIPCHK(hipMemcpyAsync(r->h_status, r->d_status, sizeof(ViewStatus) * (n_views + 1), hipMemcpyDeviceToHost, st));
     return 0;
 }
 
@@ -686,6 +683,7 @@ extern "C" int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_view
     }
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(r->h_status, r->d_status, sizeof(ViewStatus), hipMemcpyDeviceToHost));   // the sticky word (the stream is idle)
     // slot 0 is sticky: an overflow in ANY call since the last query is reported (a later call on the same handle that
     // fits does not erase it), with the largest instance count any of those calls needed
     int ov = r->h_status[0].overflow != 0;
