@@ -378,11 +378,15 @@ def main():
     dt = statistics.median(dts)
     t_red = statistics.median(reds) if reds else None
     halo_blocks = None
-    if red is not None:
-        # owner-side finalisation step that follows a reduce-scatter (outside the timed job: mesh extraction is not part of
-        # the metric); at world size 1 this is its empty path
+    if red is not None and world == 1:
+        # owner-side finalisation step that follows a reduce-scatter (outside the timed job: mesh extraction is not part of the
+        # metric): at world size 1 (--always-collective) this is its empty path.  Not run at N > 1: the scaling run is the one
+        # chance to time the reduction on 8 GPUs and must not depend on a step the metric does not contain.
         from gs2mesh_amd.parallel import exchange_halo
-        halo_blocks = int(exchange_halo(vol, red))
+        try:
+            halo_blocks = int(exchange_halo(vol, red))
+        except Exception as e:      # never lose the line to a step that is not part of the metric
+            halo_blocks = f"error: {str(e)[:200]}"
 
     # ---- steady state vs fill / drain: the same job with 2K steps, timed the same way; slope between the two job lengths
     steady = None
