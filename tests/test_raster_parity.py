@@ -523,6 +523,53 @@ def test_blend_variants_match_the_oracle(backend, variant):
     assert_image_close(be.host(img), ref_img)
 
 
+@pytest.mark.parametrize("rows", [1, 2])
+def test_thin_rects_take_the_per_lane_path(backend, rows):
+    """Rects that are one binning tile wide or one high and at most 4 tiles (k_count_tiles / k_scatter: counted and scattered by
+    their own lane, no staging, no tile mask -- round 4) next to 2 x 2 and larger ones in the same waves: needles along x and along
+    y (1 x n, n x 1 tiles), dots (1 x 1), and isotropic blobs.  Reference instance lists exactly (16 x 16 tiles, no cull); with
+    16 x 32 tiles and the exact cull on: the same image and the oracle's culled instance count."""
+    W, H, f = 256, 192, 200.0
+    rng = np.random.default_rng(404)
+    P = 1500
+    xyz = rng.uniform(-1.2, 1.2, (P, 3)).astype(np.float32)
+    xyz[:, 2] = rng.uniform(-0.3, 0.3, P)
+    s = np.full((P, 3), 0.004, np.float32)                       # dots: ~1 px sigma -> mostly 1 x 1 rects
+    kind = rng.integers(0, 4, P)
+    s[kind == 1, 0] = rng.uniform(0.03, 0.08, (kind == 1).sum())  # needles along x (the exact cull makes their rects 1 tile high)
+    s[kind == 2, 1] = rng.uniform(0.03, 0.08, (kind == 2).sum())  # needles along y
+    s[kind == 3] = rng.uniform(0.05, 0.15, ((kind == 3).sum(), 1)).astype(np.float32)   # blobs: 3 x 3 tiles and more
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    o = rng.uniform(0.05, 0.9, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    be = backend
+    d = be.dev
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                                 cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    tt = geom_ref["tiles_touched"]
+    assert (tt == 1).sum() > 100 and (tt == 2).sum() > 100 and (tt > 4).sum() > 100, np.bincount(np.minimum(tt, 9))
+    for cull in (0, 1):
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+        r.set_option(_lib.OPT_TILE_ROWS, rows)
+        img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                               d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols), scales=d(s),
+                               rotations=d(q))
+        ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q,
+                                                   exact_cull=bool(cull))
+        np.testing.assert_array_equal(be.host(radii), ref_radii)
+        assert_image_close(be.host(img), ref_img)
+        if rows == 1 and cull == 0:
+            assert r.last_num_rendered == ref_n
+            ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+            pl, ranges = r.download_binning(0, ref_n, ((W + 15) // 16) * ((H + 15) // 16))
+            np.testing.assert_array_equal(ranges, ref_ranges)
+            np.testing.assert_array_equal(pl, ref_pl)
+        elif rows == 1:
+            assert abs(r.last_num_rendered - ref_n) <= max(2, 2e-3 * ref_n)
+
+
 @pytest.mark.parametrize("cull", [0, 1])
 def test_huge_and_tiny_gaussians_mixed(backend, cull):
     """Rect areas from 1 tile to the whole 13 x 9 tile grid in one wave: exercises the balanced tile
