@@ -32,6 +32,19 @@ def assert_image_close(got, ref, frac_tol=1e-4, small=1e-5, big=6e-3):
     assert d.max() <= big, f"max abs diff {d.max():.3e}"
 
 
+def assert_image_attributed(img, geom, W, H, bg=(0.0, 0.0, 0.0), rgb=None):
+    """The CHECKED form of the image bar (oracle/parity.py, as in the full-size tests): max |delta| <= 2e-4 on every pixel where
+    no decision of renderCUDA sits within 1e-5 of its threshold in the oracle's own replay of the reference record `geom`, and every
+    other pixel within the bound of the contributions that can flip -- zero unexplained pixels.  `rgb`: the colours where they
+    were passed precomputed (the oracle's projection then leaves its own rgb empty)."""
+    from oracle import parity
+    fa = parity.compositing_attribution(dict(means2D=geom["means2D"], depths=geom["depths"], conic_opacity=geom["conic_opacity"],
+                                             rgb=geom["rgb"] if rgb is None else rgb), geom["radii"], W, H,
+                                        np.asarray(img, np.float32), bg)
+    assert fa["ok"] and fa["unexplained_pixels"] == 0 and fa["max_abs_clean"] <= 2e-4, {k: fa[k] for k in (
+        "flip_pixels", "max_abs_clean", "max_abs_flip", "unexplained_pixels", "worst_unexplained")}
+
+
 def scene(P, seed, W, H, f, log_s=math.log(0.03), ring=3.5, az=0.3):
     g = synthetic.synth_v1(P, seed, log_s)
     s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
@@ -81,8 +94,9 @@ def test_projection_binning_image_parity(backend):
     ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
     np.testing.assert_array_equal(ranges, ref_ranges)
     np.testing.assert_array_equal(pl, ref_pl)
-    # -- image
+    # -- image: the global bar, and the checked flip statement on the (bit-exact) record
     assert_image_close(img, ref_img)
+    assert_image_attributed(img, geom_ref, W, H, bg)
 
 
 @pytest.mark.parametrize("deg,M", [(0, 1), (1, 4), (2, 9), (3, 16), (1, 16)])
@@ -560,6 +574,7 @@ def test_thin_rects_take_the_per_lane_path(backend, rows):
                                                    exact_cull=bool(cull))
         np.testing.assert_array_equal(be.host(radii), ref_radii)
         assert_image_close(be.host(img), ref_img)
+        assert_image_attributed(be.host(img), geom_ref, W, H, rgb=cols)
         if rows == 1 and cull == 0:
             assert r.last_num_rendered == ref_n
             ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
@@ -606,6 +621,9 @@ def test_huge_and_tiny_gaussians_mixed(backend, cull):
         assert r.last_num_rendered == ref_n
     assert ref_n > 2000
     assert_image_close(be.host(img), ref_img)
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                                 cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    assert_image_attributed(be.host(img), geom_ref, W, H, bg=(0.2, 0.1, 0.0), rgb=cols)
 
 
 def test_packed_sh_layout_gives_identical_results(backend):
