@@ -133,10 +133,29 @@ GS2M_DEVICE void tsdf_touch_body(const TsdfVolume& V, const TsdfFrame& f, const 
     int wlo[3], whi[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        stg->lo[r][lane] = lo[r];
-        stg->hi[r][lane] = hi[r];
         wlo[r] = wave_min_i(lo[r]);
         whi[r] = wave_max_i(hi[r]);
+    }
+    // Neighbouring pixels mostly have the SAME block box (a +-trunc cube is ~1.3 blocks wide, 64 strided pixels span ~5): only the
+    // boxes that differ from the previous lane's are staged (round 4: typically 5-15 of 64), so the containment loop below runs
+    // over the distinct boxes instead of all 64 lanes.  The union of the kept boxes is the union of all boxes: same block set.
+    bool same = lane > 0 && valid;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int plo = gs2m_shfl_up(lo[r], 1), phi = gs2m_shfl_up(hi[r], 1);
+        same = same && plo == lo[r] && phi == hi[r];
+    }
+    const bool pvalid = gs2m_shfl_up(valid ? 1 : 0, 1) != 0;
+    const bool keep = valid && !(same && pvalid);
+    const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
+    const int n_keep = gs2m_popc64(kept);
+    if (keep) {
+        const int slot = gs2m_popc64(kept & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            stg->lo[r][slot] = lo[r];
+            stg->hi[r][slot] = hi[r];
+        }
     }
     gs2m_wave_sync();
     const long long total_ll = ((long long)whi[0] - wlo[0] + 1) * ((long long)whi[1] - wlo[1] + 1) *
@@ -154,10 +173,10 @@ GS2M_DEVICE void tsdf_touch_body(const TsdfVolume& V, const TsdfFrame& f, const 
         const int cx = c / nyz, rem = c - cx * nyz;
         const int cy = rem / nz;
         const int bx = wlo[0] + cx, by = wlo[1] + cy, bz = wlo[2] + (rem - cy * nz);
-        // containment in ANY lane's box: branch-free so the 384 broadcast LDS reads pipeline
+        // containment in ANY staged box: branch-free so the broadcast LDS reads pipeline
         int in_any = 0;
-#pragma unroll 8
-        for (int k = 0; k < 64; ++k)
+#pragma unroll 4
+        for (int k = 0; k < n_keep; ++k)
             in_any |= (int)(bx >= stg->lo[0][k]) & (int)(bx <= stg->hi[0][k]) & (int)(by >= stg->lo[1][k]) &
                       (int)(by <= stg->hi[1][k]) & (int)(bz >= stg->lo[2][k]) & (int)(bz <= stg->hi[2][k]);
         const bool inside = in_any != 0;
