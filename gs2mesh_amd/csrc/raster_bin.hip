@@ -18,13 +18,11 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
     // possibly stale): the class kernels walk their lists grid-stride, so any grid >= 1 is correct -- the hint only keeps a
     // class that is (almost) empty from launching hundreds of workgroups of 40-80 KiB LDS that wait for CU space just to
     // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
-    GS2M_LAUNCH(k_sort_tiles_small<4>, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, tiles, cap);
-    if (class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0) {
-        // every size class was empty last time: ONE LDS-free launch that still sorts whatever it finds, exactly and in bounded
-        // time even when the hint is stale (k_sort_tiles_rank: rank-sorted runs of 256 + rank merges)
-        GS2M_LAUNCH(k_sort_tiles_rank, dim3(32, nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
-        return;
-    }
+    // every size class was empty last time: no class kernels; the first workgroups of the small-list kernel still sort whatever
+    // larger lists they find, exactly and in bounded time even when the hint is stale (sort_class_lists_rank)
+    const int fold = class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0;
+    GS2M_LAUNCH(k_sort_tiles_small<4>, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, tiles, cap, tmp, sort_lists, fold);
+    if (fold) return;
     const int full[3] = {tiles < 1024 ? tiles : 1024, tiles < 512 ? tiles : 512, tiles < 512 ? tiles : 512};
     int g[3];
     for (int c = 0; c < 3; ++c) {

@@ -438,34 +438,123 @@ GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int
     return true;
 }
 
+// LDS-free stand-in for the three size-class kernels, launched INSTEAD of them when the previous call on the handle found
+// every class empty (the usual case at 16 x 32 tiles of a 300 k-Gaussian model: no list above 512 instances).  The class
+// kernels carry 40-80 KiB of static LDS per workgroup; under the pipelined load (a compositing grid of another stream holds
+// 157 of the 160 KiB of every CU) even their EMPTY launches waited 30-40 us each for a CU with room -- three times per view
+// on the critical chain of its slot (kernel trace, round 3).  This kernel needs no LDS, so its 256-thread workgroups are
+// placed at once.  It is not a hint-dependent shortcut: the hint may be stale (scene or camera change, status copy not yet
+// landed), so if the view DOES have larger lists it sorts them, exactly and in bounded time -- runs of 256 keys by rank
+// (keys are unique: rank = number of smaller keys of the run = position in the run), then rank-merge passes between `keys`
+// and `tmp` as in k_sort_tiles: O(256 n + n log^2 n) instead of the O(n^2) of a rank sort over the whole list (a stale hint
+// on a C3-like view used to cost milliseconds).  The lists are L1 / L2 resident and a workgroup only re-reads what its own
+// threads wrote, visible after the workgroup barrier.
+// Round 4: no launch of its own any more -- the first GS2M_SORT_RANK_BLOCKS workgroups of k_sort_tiles_small run it after their
+// own lists (one launch less on the chain of every pass).
+#define GS2M_SORT_RANK_BLOCKS 32
+GS2M_DEVICE void sort_class_lists_rank(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
+                                       const unsigned* __restrict__ tile_start, int tiles, unsigned cap,
+                                       const unsigned* __restrict__ sort_lists, const int v, const unsigned first, const unsigned stride,
+                                       const int tid) {
+    for (int cls = 0; cls < GS2M_SORT_CLASSES; ++cls) {
+        const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + cls) * (tiles + 1);
+        const unsigned count = list[0];
+        for (unsigned li = first; li < count; li += stride) {
+            const int t = (int)list[1 + li];
+            unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
+            unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
+            if (b > cap) b = cap;
+            if (e > cap) e = cap;
+            const int n = (int)(e - b);
+            unsigned long long* kv = keys + (size_t)v * cap + b;
+            unsigned long long* tv = tmp + (size_t)v * cap + b;
+            // runs of 256 keys, each sorted by rank into tmp
+            for (int r0 = 0; r0 < n; r0 += 256) {
+                const int rn = n - r0 < 256 ? n - r0 : 256;
+                if (tid < rn) {
+                    const unsigned long long key = kv[r0 + tid];
+                    int rank = 0;
+                    for (int j = 0; j < rn; ++j) rank += kv[r0 + j] < key ? 1 : 0;
+                    tv[r0 + rank] = key;
+                }
+            }
+            __syncthreads();
+            unsigned long long* src = tv;
+            unsigned long long* dst = kv;
+            for (int w = 256; w < n; w <<= 1) {
+                for (int i = tid; i < n; i += 256) {
+                    const int blk = i / (2 * w);
+                    const int a0 = blk * 2 * w;
+                    const int a1 = a0 + w < n ? a0 + w : n;            // A = [a0,a1)
+                    const int b1 = a0 + 2 * w < n ? a0 + 2 * w : n;    // B = [a1,b1)
+                    const unsigned long long key = src[i];
+                    int lo, hi, base;
+                    if (i < a1) {  // element of A: count of B elements smaller than key
+                        lo = a1;
+                        hi = b1;
+                        base = i - a0;
+                    } else {
+                        lo = a0;
+                        hi = a1;
+                        base = i - a1;
+                    }
+                    const int lo0 = lo;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (src[mid] < key) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    dst[a0 + base + (lo - lo0)] = key;
+                }
+                __syncthreads();
+                unsigned long long* x = src;
+                src = dst;
+                dst = x;
+            }
+            if (src != kv) {
+                for (int i = tid; i < n; i += 256) kv[i] = src[i];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // WPB waves per workgroup, one list per wave (no workgroup barrier: a wave leaves as soon as its list is done).  C2 launches
 // 7600 lists per pair: as single-wave workgroups their dispatch alone took a third of the kernel.
 template <int WPB>
 GS2M_KERNEL void __launch_bounds__(64 * WPB)
 k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start, int tiles,
-                   unsigned cap) {
+                   unsigned cap, unsigned long long* __restrict__ tmp, const unsigned* __restrict__ sort_lists, int fold_rank) {
     __shared__ unsigned long long s_key_all[WPB][GS2M_SORT_WAVE];
     __shared__ unsigned s_cnt_all[WPB][GS2M_SORT_WAVE / 2 + 2];
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     unsigned long long* s_key = s_key_all[wave];
     unsigned* s_cnt = s_cnt_all[wave];
     const int t = gs2m_uniform((int)blockIdx.x * WPB + wave), v = (int)blockIdx.y;
-    if (t >= tiles) return;
-    unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
-    unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
-    if (b > cap) b = cap;
-    if (e > cap) e = cap;
-    const int n = (int)(e - b);
-    if (n <= 1 || n > GS2M_SORT_WAVE) return;  // larger tiles: k_sort_tiles
-    unsigned long long* kv = keys + (size_t)v * cap + b;
-    if (n <= 64) sort_wave_regs<1>(kv, n, lane);
-    else if (n <= 128) {
-        if (!(sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<2>(kv, n, lane);
-    } else if (n <= 256) {
-        if (!(sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<4>(kv, n, lane);
-    } else {
-        if (!(sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt))) sort_wave_regs<8>(kv, n, lane);
+    if (t < tiles) {
+        unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
+        unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
+        if (b > cap) b = cap;
+        if (e > cap) e = cap;
+        const int n = (int)(e - b);
+        unsigned long long* kv = keys + (size_t)v * cap + b;
+        if (n <= 1 || n > GS2M_SORT_WAVE) {
+            // nothing to do / a larger list: the size-class kernels, or the folded stand-in below
+        } else if (n <= 64) {
+            sort_wave_regs<1>(kv, n, lane);
+        } else if (n <= 128) {
+            if (!sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt)) sort_wave_regs<2>(kv, n, lane);
+        } else if (n <= 256) {
+            if (!sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt)) sort_wave_regs<4>(kv, n, lane);
+        } else {
+            if (!sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt)) sort_wave_regs<8>(kv, n, lane);
+        }
     }
+    // fold_rank: the previous call on the handle found every size class empty, so the class kernels are not launched; the first
+    // workgroups sort whatever larger lists there are after all (sort_class_lists_rank: exact, bounded; needs 256 threads)
+    if (WPB == 4 && fold_rank && blockIdx.x < GS2M_SORT_RANK_BLOCKS)
+        sort_class_lists_rank(keys, tmp, tile_start, tiles, cap, sort_lists, v, blockIdx.x,
+                              gridDim.x < GS2M_SORT_RANK_BLOCKS ? gridDim.x : GS2M_SORT_RANK_BLOCKS, (int)threadIdx.x);
 }
 
 template <int E>
@@ -769,85 +858,6 @@ k_sort_tiles(unsigned long long* __restrict__ keys, unsigned long long* __restri
             for (int i = tid; i < n; i += 256) kv[i] = src[i];
         }
         __syncthreads();
-    }
-}
-
-// LDS-free stand-in for the three size-class kernels, launched INSTEAD of them when the previous call on the handle found
-// every class empty (the usual case at 16 x 32 tiles of a 300 k-Gaussian model: no list above 512 instances).  The class
-// kernels carry 40-80 KiB of static LDS per workgroup; under the pipelined load (a compositing grid of another stream holds
-// 157 of the 160 KiB of every CU) even their EMPTY launches waited 30-40 us each for a CU with room -- three times per view
-// on the critical chain of its slot (kernel trace, round 3).  This kernel needs no LDS, so its 256-thread workgroups are
-// placed at once.  It is not a hint-dependent shortcut: the hint may be stale (scene or camera change, status copy not yet
-// landed), so if the view DOES have larger lists it sorts them, exactly and in bounded time -- runs of 256 keys by rank
-// (keys are unique: rank = number of smaller keys of the run = position in the run), then rank-merge passes between `keys`
-// and `tmp` as in k_sort_tiles: O(256 n + n log^2 n) instead of the O(n^2) of a rank sort over the whole list (a stale hint
-// on a C3-like view used to cost milliseconds).  The lists are L1 / L2 resident and a workgroup only re-reads what its own
-// threads wrote, visible after the workgroup barrier.
-GS2M_KERNEL void __launch_bounds__(256)
-k_sort_tiles_rank(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
-                  const unsigned* __restrict__ tile_start, int tiles, unsigned cap, const unsigned* __restrict__ sort_lists) {
-    const int tid = (int)threadIdx.x;
-    const int v = (int)blockIdx.y;
-    for (int cls = 0; cls < GS2M_SORT_CLASSES; ++cls) {
-        const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + cls) * (tiles + 1);
-        const unsigned count = list[0];
-        for (unsigned li = blockIdx.x; li < count; li += gridDim.x) {
-            const int t = (int)list[1 + li];
-            unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
-            unsigned e = tile_start[(size_t)v * (tiles + 1) + t + 1];
-            if (b > cap) b = cap;
-            if (e > cap) e = cap;
-            const int n = (int)(e - b);
-            unsigned long long* kv = keys + (size_t)v * cap + b;
-            unsigned long long* tv = tmp + (size_t)v * cap + b;
-            // runs of 256 keys, each sorted by rank into tmp
-            for (int r0 = 0; r0 < n; r0 += 256) {
-                const int rn = n - r0 < 256 ? n - r0 : 256;
-                if (tid < rn) {
-                    const unsigned long long key = kv[r0 + tid];
-                    int rank = 0;
-                    for (int j = 0; j < rn; ++j) rank += kv[r0 + j] < key ? 1 : 0;
-                    tv[r0 + rank] = key;
-                }
-            }
-            __syncthreads();
-            unsigned long long* src = tv;
-            unsigned long long* dst = kv;
-            for (int w = 256; w < n; w <<= 1) {
-                for (int i = tid; i < n; i += 256) {
-                    const int blk = i / (2 * w);
-                    const int a0 = blk * 2 * w;
-                    const int a1 = a0 + w < n ? a0 + w : n;            // A = [a0,a1)
-                    const int b1 = a0 + 2 * w < n ? a0 + 2 * w : n;    // B = [a1,b1)
-                    const unsigned long long key = src[i];
-                    int lo, hi, base;
-                    if (i < a1) {  // element of A: count of B elements smaller than key
-                        lo = a1;
-                        hi = b1;
-                        base = i - a0;
-                    } else {
-                        lo = a0;
-                        hi = a1;
-                        base = i - a1;
-                    }
-                    const int lo0 = lo;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (src[mid] < key) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    dst[a0 + base + (lo - lo0)] = key;
-                }
-                __syncthreads();
-                unsigned long long* x = src;
-                src = dst;
-                dst = x;
-            }
-            if (src != kv) {
-                for (int i = tid; i < n; i += 256) kv[i] = src[i];
-            }
-            __syncthreads();
-        }
     }
 }
 

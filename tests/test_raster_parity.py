@@ -233,7 +233,7 @@ def test_crowded_tile_uses_the_merge_path_and_saturates(backend, P):
 
 
 def test_lists_grow_after_a_view_without_large_lists(backend):
-    """The size-class kernels of the per-tile sort are replaced by ONE LDS-free launch (k_sort_tiles_rank) when the previous
+    """The size-class kernels of the per-tile sort are replaced by an LDS-free stand-in (sort_class_lists_rank, run by the first workgroups of k_sort_tiles_small) when the previous
     call on the handle found every class empty.  That launch is not a hint-dependent shortcut: a view that suddenly HAS lists
     of 600 ... 9000 instances (all three classes) after a sparse one is still sorted exactly."""
     W, H, f = 48, 32, 60.0
