@@ -59,3 +59,37 @@ def test_the_image_border_does_not_erode():
     # closing: dilation [0, 17] (clipped), erosion: windows reaching outside the image only test their in-image part:
     # x in [0, 13]; second erosion: x in [0, 13 - 4] = [0, 9]; all rows survive
     assert np.array_equal(out, rect(H, W, 0, 29, 0, 9))
+
+
+def _brute(m, k, erode):
+    """the documented definition, pixel by pixel: min / max over src(y + dy, x + dx), dy, dx in [-k // 2, k - 1 - k // 2],
+    positions outside the image skipped (= the +inf / -inf default border)"""
+    H, W = m.shape
+    a = k // 2
+    out = np.zeros_like(m)
+    for y in range(H):
+        for x in range(W):
+            vals = [m[y + dy, x + dx] for dy in range(-a, k - a) for dx in range(-a, k - a)
+                    if 0 <= y + dy < H and 0 <= x + dx < W]
+            out[y, x] = all(vals) if erode else any(vals)
+    return out
+
+
+def test_random_masks_against_the_definition_and_against_scipy_filters():
+    """Two independent restatements on random masks, even and odd kernels, kernels larger than the image: the brute-force
+    definition above, and scipy.ndimage's minimum / maximum filters (origin 0: for a size-k window scipy takes
+    [i - k // 2, i + k - 1 - k // 2], the same extent as OpenCV's default anchor; cval = the value that never wins)."""
+    from scipy import ndimage
+    rng = np.random.default_rng(7)
+    for H, W, k, p in [(23, 31, 10, 0.5), (17, 9, 3, 0.7), (12, 40, 10, 0.93), (30, 30, 7, 0.1), (8, 8, 10, 0.8), (25, 25, 2, 0.5)]:
+        m = rng.random((H, W)) < p
+        for erode in (False, True):
+            got = _morph(m, k, erode)
+            assert got.shape == m.shape and got.dtype == bool
+            assert np.array_equal(got, _brute(m, k, erode)), (H, W, k, erode)
+            f = ndimage.minimum_filter if erode else ndimage.maximum_filter
+            ref = f(m.astype(np.uint8), size=k, mode="constant", cval=1 if erode else 0).astype(bool)
+            assert np.array_equal(got, ref), (H, W, k, erode)
+        # the composed preprocessing = the composition of the restated steps
+        want = _brute(_brute(_brute(m, k, False), k, True), k, True)
+        assert np.array_equal(preprocess_object_mask(m, closing_kernel_size=k, erosion_kernel_size=k), want)
