@@ -219,6 +219,14 @@ def main():
     world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    line_out = sys.stdout
+    if world > 1 or args.always_collective:
+        # RCCL 2.26 prints a version banner through C stdio on STDOUT (seen on the GPU box: five lines, flushed at exit, i.e.
+        # AFTER the JSON line, from every rank).  The contract is ONE line on stdout: keep a private handle on the real stdout
+        # for that line and point descriptor 1 at stderr for everything a library may print.
+        sys.stdout.flush()
+        line_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -658,7 +666,8 @@ def main():
                         "around every launch, `pairs_per_launch` stereo pairs per chain of launches = the launch shapes of the "
                         "timed pass (kernels in isolation; raster `avg_us` = launch_us / pairs_per_launch, TSDF `avg_us` per frame); "
                         "`value`: timed pass with `pairs_in_flight` slots overlapped on separate streams")
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out)
+        line_out.flush()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

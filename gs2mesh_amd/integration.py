@@ -97,6 +97,7 @@ class ScalableTSDFVolume:
         self.frames_base = 0
         self.frames_local = 0
         self.replicated = False      # the state is the all-reduced volume (every rank holds it: summing it again would count it R times)
+        self.has_halo = False        # holds neighbour-only copies of other ranks' blocks (exchange_halo): their keys read as the sentinel
         self._xbuf = {}              # persistent, grow-only exchange buffers (gs2mesh_amd.parallel)
 
     def close(self):
@@ -114,6 +115,7 @@ class ScalableTSDFVolume:
         _lib.check(self._lib.gs2m_tsdf_reset(self._h, stream or C.c_void_p(0)), self._lib)
         self.frames_base = self.frames_local = 0
         self.replicated = False
+        self.has_halo = False
 
     @property
     def frames_integrated(self):
@@ -290,7 +292,18 @@ class ScalableTSDFVolume:
         return TriangleMesh.from_triangle_soup(verts, cols if has_color else None, edge_index=eidx)
 
     # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
-    def block_keys(self, like=None, stream=None, raise_on_overflow=True):
+    def exchange_device(self):
+        """where the exchange buffers of this volume live: the GPU, or the host for the emulator build (CPU tests)"""
+        if _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available()):
+            return torch.device("cpu")
+        return torch.device(f"cuda:{self.device}")
+
+    def block_keys(self, like=None, stream=None, raise_on_overflow=True, out=None, n=None):
+        """Keys of the allocated blocks, slot order (halo copies: sentinel key).  ``out`` / ``n``: write the first n rows of a
+        caller buffer (n from a status() the caller already paid for: no synchronisation here)."""
+        if out is not None:
+            _lib.check(self._lib.gs2m_tsdf_block_keys(self._h, int(n), _ptr(out), _stream_of(out, stream)), self._lib)
+            return out[: int(n)]
         n = min(self.status(stream, raise_on_overflow)[0], self.max_blocks)
         if _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available()):
             keys = np.zeros((n, 3), np.int32)
@@ -313,7 +326,9 @@ class ScalableTSDFVolume:
         n = int(keys.shape[0])
         _lib.check(self._lib.gs2m_tsdf_unpack(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
                                               int(bool(halo)), _stream_of(keys, stream)), self._lib)
-        if not halo:
+        if halo:
+            self.has_halo = self.has_halo or n > 0
+        else:
             self._inherit(frames)
 
     def _inherit(self, frames):
@@ -331,5 +346,7 @@ class ScalableTSDFVolume:
         n = int(keys.shape[0])
         _lib.check(self._lib.gs2m_tsdf_unpack_sum(self._h, _ptr(keys), n, _ptr(buf), int(bool(halo)),
                                                   _stream_of(keys, stream)), self._lib)
-        if not halo:
+        if halo:
+            self.has_halo = self.has_halo or n > 0
+        else:
             self._inherit(frames)

@@ -5,8 +5,9 @@ the CPU tests).  Stereo views are independent units, so rank r renders and integ
 chunk of the views into its own block-sparse volume with NO data-path collective; the only exchange
 is one sum-reduction of the TSDF accumulators at the end (``reduce_volume``):
 
-  1. ONE fixed-size ``all_gather`` of the block keys (``max_blocks`` rows per rank, sentinel-padded, plus one
-     row carrying the rank's block count and overflow flags -- no size handshake, no per-rank ``.item()``);
+  1. ONE fixed-size ``all_gather`` of the block keys (``max_blocks`` rows per rank, the first n of them valid, plus two
+     header rows carrying the rank's block count, overflow flags and frame counts -- no size handshake, no per-rank
+     ``.item()``; the lists are cut out of the gathered buffer by the header's counts);
      every rank builds the same canonical (sorted, unique) union; an overflow on ANY rank raises on EVERY
      rank after the collective (nobody is left waiting in one);
   2. ``gs2m_tsdf_pack`` writes the local accumulators of the union blocks in SUM form into persistent, grow-only
@@ -42,6 +43,14 @@ _OVERFLOW_TEXT = ((1, "block pool exhausted (raise max_blocks)"), (2, "hash tabl
                   (8, "a voxel did not fit the packed exchange form (weight > 1023 or colour sum >= 2^18)"))
 
 
+def _mark(marks, name):
+    """profiling aid (tools/reduce_breakdown.py): phase boundary, device drained; nothing happens without a list"""
+    if marks is not None:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        marks.append((name, time.perf_counter()))
+
+
 def shard_range(n_items: int, rank: int, world: int):
     """Contiguous, balanced (+-1) chunk [lo, hi) of n_items for `rank` (contiguous so that
     stereo_warm chains stay intact inside a chunk)."""
@@ -51,14 +60,26 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, hi
 
 
+_CONST = {}      # (name, device) -> small constant tensors of the key arithmetic (created once: no host -> device copy per call)
+
+
+def _const(name, values, device):
+    t = _CONST.get((name, str(device)))
+    if t is None:
+        t = _CONST[(name, str(device))] = torch.tensor(values, dtype=torch.int64, device=device)
+    return t
+
+
 def _pack_keys(keys: torch.Tensor) -> torch.Tensor:
-    k = keys.to(torch.int64) + (1 << 20)
-    return (k[:, 0] << 42) | (k[:, 1] << 21) | k[:, 2]
+    """[n,3] int32 block indices -> one int64 per block (x | y | z biased to 21 bits each: ascending packed value =
+    lexicographic order).  Four launches (bias, widen, scale, row sum)."""
+    mult = _const("mult", [1 << 42, 1 << 21, 1], keys.device)
+    return ((keys + (1 << 20)).to(torch.int64) * mult).sum(dim=1)
 
 
 def _unpack_keys(u: torch.Tensor) -> torch.Tensor:
-    out = torch.stack([(u >> 42) & 0x1FFFFF, (u >> 21) & 0x1FFFFF, u & 0x1FFFFF], dim=1) - (1 << 20)
-    return out.to(torch.int32).contiguous()
+    shifts = _const("shifts", [42, 21, 0], u.device)
+    return (((u[:, None] >> shifts) & 0x1FFFFF) - (1 << 20)).to(torch.int32)
 
 
 def _lex_unique(keys: torch.Tensor) -> torch.Tensor:
@@ -72,49 +93,57 @@ def _as_tensor(keys):
     return keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys))
 
 
-def canonical_keys(volume, group=None, always_collective: bool = False):
+def canonical_keys(volume, group=None, always_collective: bool = False, marks=None):
     """Union of the block keys of all ranks in canonical order, on the local device, + the OR of the ranks'
     overflow flags + an upper bound of every voxel weight of the SUM over the ranks + whether any rank holds an already
     all-reduced (replicated) state.  One fixed-size all_gather (persistent buffers); one host read (of the gathered header
     rows).  Halo copies held by a volume are not its blocks (sentinel keys).
     Weight bound: a rank's state = a part it inherited (`frames_base`: a reduce-scatter leaves the ranks with DISJOINT parts
     of one reduced volume, so across ranks the inherited bounds do not add up -- their maximum holds) + the frames it
-    integrated since (`frames_local`: these do add up)."""
-    keys = _as_tensor(volume.block_keys(raise_on_overflow=False))
-    _, _, ov = volume.status(raise_on_overflow=False)
+    integrated since (`frames_local`: these do add up).
+    The exchange is latency, not bytes (C2: 3960 keys): the local list is written straight into the send buffer, the header
+    travels as ONE small copy, the ranks' lists are cut out of the gathered buffer by the counts of the header (a mask would
+    cost a device -> host round trip), sentinel rows are only filtered when some rank says it holds halo copies."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     collective = world > 1 or (always_collective and dist.is_initialized())
     if not collective:
+        keys = _as_tensor(volume.block_keys(raise_on_overflow=False))
+        _, _, ov = volume.status(raise_on_overflow=False)
         return _lex_unique(keys[keys[:, 0] != _SENTINEL]), int(ov), 0, int(volume.frames_integrated), False
     K = int(volume.max_blocks)
-    n_local = int(keys.shape[0])
-    buf = volume.exchange_buffer("keys_send", (K + 2, 3), torch.int32, keys.device)
-    buf.fill_(_SENTINEL)
-    buf[:n_local] = keys
-    buf[K, 0] = n_local
-    buf[K, 1] = int(ov)
-    buf[K, 2] = K
-    buf[K + 1, 0] = int(volume.frames_local)
-    buf[K + 1, 1] = int(volume.frames_base)
-    buf[K + 1, 2] = int(bool(volume.replicated))
-    gathered = volume.exchange_buffer("keys_recv", (world * (K + 2), 3), torch.int32, keys.device)
+    n_local, _, ov = volume.status(raise_on_overflow=False)
+    n_local = min(int(n_local), K)
+    buf = volume.exchange_buffer("keys_send", (K + 2, 3), torch.int32, volume.exchange_device())
+    volume.block_keys(out=buf, n=n_local)
+    flags = int(bool(volume.replicated)) | (2 if volume.has_halo else 0)
+    head_local = torch.tensor([[n_local, int(ov), K], [int(volume.frames_local), int(volume.frames_base), flags]], dtype=torch.int32)
+    buf[K:].copy_(head_local)
+    gathered = volume.exchange_buffer("keys_recv", (world * (K + 2), 3), torch.int32, buf.device)
+    _mark(marks, "keys: local list + header")
     dist.all_gather_into_tensor(gathered, buf, group=group)
+    _mark(marks, "keys: all_gather")
     g = gathered.view(world, K + 2, 3)
-    head = g[:, K:, :].cpu()                                  # the one host read of the exchange
+    head = g[:, K:, :].cpu().numpy().astype(np.int64)         # the one host read of the exchange; [world, 2, 3]
+    _mark(marks, "keys: header read")
     if int(head[:, 0, 2].min()) != K or int(head[:, 0, 2].max()) != K:
         raise RuntimeError("reduce_volume: every rank must create its volume with the same max_blocks")
-    ov_any = 0
-    for f in head[:, 0, 1].tolist():
-        ov_any |= int(f)
+    ov_any = int(np.bitwise_or.reduce(head[:, 0, 1]))
     frames_total = int(head[:, 1, 0].sum()) + int(head[:, 1, 1].max())
-    replicated = bool(int(head[:, 1, 2].max())) and world > 1
-    body = g[:, :K, :].reshape(-1, 3)
-    valid = body[:, 0] != _SENTINEL
-    return _lex_unique(body[valid]), ov_any, 1, frames_total, replicated
+    flags_any = int(np.bitwise_or.reduce(head[:, 1, 2]))
+    replicated = bool(flags_any & 1) and world > 1
+    counts = [min(max(int(c), 0), K) for c in head[:, 0, 0]]
+    parts = [g[r, :c] for r, c in enumerate(counts) if c]
+    if not parts:
+        return g[0, :0], ov_any, 1, frames_total, replicated
+    body = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+    if flags_any & 2:
+        body = body[body[:, 0] != _SENTINEL]
+    _mark(marks, "keys: host checks + slices")
+    return _lex_unique(body), ov_any, 1, frames_total, replicated
 
 
 def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_collective: bool = False,
-                  payload: str = "auto", algo: str = "rccl"):
+                  payload: str = "auto", algo: str = "rccl", marks=None):
     """Sum-reduce the TSDF accumulators of all ranks into `volume`.
 
     mode "reduce_scatter": rank r ends with blocks [lo_r, hi_r) of the canonical list only (use `exchange_halo`
@@ -131,7 +160,9 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if mode not in ("reduce_scatter", "allreduce") or payload not in ("auto", "packed", "f32") or algo not in ("rccl", "direct"):
         raise ValueError((mode, payload, algo))
-    keys, ov_any, n_coll, frames_total, replicated = canonical_keys(volume, group, always_collective)
+    _mark(marks, "start")
+    keys, ov_any, n_coll, frames_total, replicated = canonical_keys(volume, group, always_collective, marks)
+    _mark(marks, "keys: union (pack, unique, unpack)")
     if replicated:
         # identical on every rank (it travelled in the gathered header): all of them raise
         raise RuntimeError("reduce_volume: a rank holds an all-reduced (replicated) volume -- summing it again would count its "
@@ -161,6 +192,7 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
     ibuf = volume.exchange_buffer("send_i64", (n_pad, 4096), torch.int64, dev) if packed else None
     if n_pad:
         volume.pack(kpad, form, fbuf, ibuf)
+    _mark(marks, "pack")
     nbytes = n_pad * 4096 * (12 if packed else 20)
     lo, hi = 0, n
     if collective and n_pad:
@@ -194,6 +226,7 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
             if packed:
                 dist.all_reduce(ibuf, op=dist.ReduceOp.SUM, group=group)
                 n_coll += 1
+    _mark(marks, "collectives")
     if packed:
         # device-side check of the packed form (k_tsdf_pack): a local weight / colour sum that did not fit its field means the
         # frame bound was wrong (state injected through the C API).  Checked AFTER the collectives, so that a rank that
@@ -207,6 +240,7 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
     if cnt:
         volume.unpack(kpad[:cnt].contiguous(), form, fbuf[:cnt], ibuf[:cnt] if packed else None, frames=frames_total)
     volume.status()
+    _mark(marks, "reset + unpack + status")
     volume.frames_base, volume.frames_local = frames_total, 0     # every weight of the reduced state is bounded by the total
     volume.replicated = collective and not scatter and world > 1
     return dict(n_blocks_union=n, bytes_per_rank=nbytes, keys=keys, owned=(lo, hi), collectives=n_coll, mode=mode,

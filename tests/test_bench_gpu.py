@@ -23,7 +23,11 @@ def test_c4_strong_scaling_job_with_the_exchange_at_world_one():
     r = _bench(["--config", "C4", "--steps", "16", "--warmup", "2", "--scaling", "strong", "--always-collective", "--no-c3",
                 "--no-cpu-baseline", "--no-parity", "--no-steady-state", "--min-repeats", "2", "--min-seconds", "0"])
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    # ONE line on stdout, whatever the collective library prints (RCCL's version banner goes to C stdout: bench.py moves
+    # descriptor 1 to stderr before the process group is created)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:8]
+    line = lines[0]
     out = json.loads(line)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_C4_strong_world1.json"), "w") as fh:

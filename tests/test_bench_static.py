@@ -59,3 +59,13 @@ def test_gpus_flag_and_launcher_world_must_agree():
     assert r.returncode != 0 and "must agree" in r.stderr, r.stderr[-500:]
     r = _run_bench(["--gpus", "4"])
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr, r.stderr[-500:]
+
+
+def test_the_json_line_is_the_only_thing_on_stdout_when_a_collective_library_is_loaded():
+    """RCCL prints a version banner on C stdout (flushed at exit, after the line): bench.py keeps a private handle on the real
+    stdout for its ONE line and points descriptor 1 at stderr before any process group exists."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count("print(") == 1 and "print(json.dumps(out), file=line_out)" in src
+    i_dup, i_init = src.index("os.dup2(2, 1)"), src.index("dist.init_process_group(")
+    assert i_dup < i_init
+    assert "line_out = os.fdopen(os.dup(1), \"w\")" in src and "line_out.flush()" in src
