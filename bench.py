@@ -496,7 +496,8 @@ def main():
                         valu["frac_of_issue_bound"] = round(valu["issue_bound_us_at_2p4GHz"] / (t_launch * 1e6), 3)
         except Exception:
             traffic = None
-    roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
+    # `bound` names what limits the kernel; achieved / peak / frac stay the HBM figures the contract asks for
+    roofline = dict(kernel=dom, bound=("valu" if dom == "blend" else "hbm"), frac_basis="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
                     frac=round(achieved / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_source,
                     traffic_over_algorithmic=(round(traffic / (alg[dom] * upl), 3) if traffic else None),
                     algorithmic_bytes_per_launch=int(alg[dom] * upl), avg_launch_us=round(t_launch * 1e6, 2),
@@ -588,14 +589,28 @@ def main():
         # one frame and keep the faster
         best_threads, best_t = None, None
         d0 = prep(Wm)
-        for nt in sorted({min(16, cores), min(64, cores)}):
+        probes = {}
+
+        def probe_one(nt):
             probe = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
             probe.set_threads(nt)
             tc = time.perf_counter()
-            probe.integrate(d0, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[Wm])
+            nb = probe.integrate(d0, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[Wm])
             tp = time.perf_counter() - tc
+            probes[nt] = dict(threads=nt, value=round(nb * 4096 / tp / 1e6, 2), unit="Mvoxel-updates/s", sample=f"1 frame, {tp:.2f} s")
+            return tp
+
+        for nt in sorted({min(16, cores), min(64, cores)}):
+            tp = probe_one(nt)
             if best_t is None or tp < best_t:
                 best_threads, best_t = nt, tp
+        # "threads = all host cores" -- reported next to the faster setting (one frame; skipped when the
+        # 16-thread frame already takes seconds: 256 threads on 16 x-slices only oversubscribe)
+        if cores not in probes:
+            if best_t < 2.0:
+                probe_one(cores)
+            else:
+                probes[cores] = dict(threads=cores, skipped=f"one frame takes {best_t:.1f} s at {best_threads} threads")
         ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
         ref.set_threads(best_threads)
         t_cpu, n_cpu, blocks_cpu = 0.0, 0, 0
@@ -608,7 +623,7 @@ def main():
             if t_cpu > args.cpu_seconds:
                 break
         cpu = dict(value=round(blocks_cpu * 4096 / t_cpu / 1e6, 2), unit="Mvoxel-updates/s", cores=best_threads,
-                   host_cores=cores, kind="port",
+                   host_cores=cores, kind="port", all_cores=probes.get(cores), by_threads=[probes[k] for k in sorted(probes)],
                    label="restated Open3D 0.17 ScalableTSDFVolume::Integrate (oracle/tsdf_oracle.cpp, OpenMP over the "
                          "16 x-slices of a block like upstream; thread count = faster of {16, min(64, host cores)})",
                    sample=f"{n_cpu} of the {K} timed {args.config} frames ({Wd}x{Ht}), integrate() only, {t_cpu:.1f} s")

@@ -7,6 +7,8 @@ test-suite also uses it on the CPU emulator build of the same kernel sources (te
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -103,8 +105,56 @@ def bind(lib: C.CDLL, require_all: bool = True) -> C.CDLL:
 
 
 _LIB = None
-# tests that run the emulator build flip this (tests/emu_lib.py); the product never does
-ALLOW_HOST_POINTERS = False
+
+
+class DeviceMemory:
+    """Where the wrappers' buffers live and how a buffer becomes a pointer for the C ABI: HIP device memory, nothing
+    else (there is no CPU path).  The wrappers go through the module-level ``MEMORY`` object; the emulator test
+    harness substitutes its own subclass from the test tree (tests/backends.py) -- no switch for it exists here."""
+
+    def ptr(self, x, dtype=None, name="tensor"):
+        """Device pointer of a contiguous torch tensor.  None / empty -> NULL."""
+        import torch
+        if x is None:
+            return None
+        if not isinstance(x, torch.Tensor):
+            raise RuntimeError(f"{name}: the C ABI takes HIP device memory (a torch tensor on a GPU), got {type(x).__name__}")
+        if x.numel() == 0:
+            return None
+        if not x.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+        if dtype is not None and x.dtype != dtype:
+            raise TypeError(f"{name} must be {dtype}, got {x.dtype}")
+        if not x.is_cuda:
+            raise RuntimeError(f"{name} must live on a HIP device (there is no CPU path)")
+        return C.c_void_p(x.data_ptr())
+
+    def buffer_device(self, device):
+        import torch
+        return torch.device(f"cuda:{int(device)}")
+
+    def zeros(self, shape, np_dtype, device):
+        """zero-filled scratch / result buffer on ``device`` (numpy dtype names the element type)"""
+        import torch
+        tdt = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32, "uint32": torch.int32,
+               "int64": torch.int64, "uint8": torch.uint8}[np.dtype(np_dtype).name]
+        return torch.zeros(tuple(shape), dtype=tdt, device=self.buffer_device(device))
+
+    def upload(self, a, torch_dtype, device):
+        """host array or tensor -> contiguous device tensor of ``torch_dtype``"""
+        import torch
+        if isinstance(a, torch.Tensor):
+            if a.dtype != torch_dtype:
+                a = a.to(torch_dtype)
+            return a.contiguous() if a.is_cuda else a.contiguous().to(self.buffer_device(device))
+        return torch.from_numpy(np.ascontiguousarray(a)).to(torch_dtype).to(self.buffer_device(device))
+
+    def download(self, t):
+        """device buffer -> numpy"""
+        return t.detach().cpu().numpy()
+
+
+MEMORY = DeviceMemory()
 
 
 def get() -> C.CDLL:

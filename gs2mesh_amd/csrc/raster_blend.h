@@ -245,11 +245,12 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         unsigned lq = 0u;  // quadrants that still have unfinished pixels
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            lq |= ((MODE == 1 ? gs2m_ballot_b(thr[k] < 0.0f) != 0ull : dn[k] != ~0ull) ? 1u : 0u) << k;
+            lq |= ((MODE != 0 ? gs2m_ballot_b(thr[k] < 0.0f) != 0ull : dn[k] != ~0ull) ? 1u : 0u) << k;
         if (lq == 0u) break;
         gs2m_wait_dma();       // this batch's records have landed in s_raw
         gs2m_wave_sync();      // ... and the previous batch's staged instances have been read by every lane
         int nb_staged = 0;
+        unsigned long long gslots = 0ull;   // MODE 2: staged slots that take the general path
         bool batch_general = false;   // any staged instance of this batch needs the reference's power > 0 test / alpha cap
         {
             const float4 ra = s_raw[wave][0][lane], rb = s_raw[wave][1][lane], rc = s_raw[wave][2][lane];
@@ -281,7 +282,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             // close to singular that rounding could make the quadratic form negative
             // MODE 1 applies the alpha cap to every instance (one v_min) and flags only the conics that need the power > 0 test
             const bool singular = !(ra.z > 0.0f && rb.x > 0.0f && det >= 1.0e-3f * ra.z * rb.x);
-            const bool general = MODE == 1 ? singular : (!(op <= 0.98f) || singular);
+            const bool general = MODE == 1 ? singular : (!(op <= 0.98f) || singular);   // MODE 2: like MODE 0, resolved per RUN of the batch
             BlendInst bi;
             bi.a = ra;
             bi.b = rb;
@@ -292,10 +293,11 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             bi.c.x = rc.x;
             bi.c.y = __uint_as_float(m | (general ? 0x100u : 0u));
             batch_general = gs2m_ballot_b(general && have && m != 0u) != 0ull;
-            if (LROWS > 1) {
+            if (LROWS > 1 || MODE == 2) {
                 // the list also serves the other half of the 16 x 32 tile: stage only the instances that reach this
                 // half (ballot compaction), so the compositing loop never iterates over the others
-                const bool mine = m != 0u && have;
+                // MODE 2 has no per-instance mask test in the loop: instances that only reach finished quadrants go here too
+                const bool mine = (MODE == 2 ? (m & lq) != 0u : m != 0u) && have;
                 const unsigned long long keep = gs2m_ballot_b(mine);
                 const int slot = gs2m_popc64(keep & ((1ull << lane) - 1ull));
                 if (mine) {
@@ -304,6 +306,17 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                     s_c[wave][slot] = bi.c;
                 }
                 nb_staged = gs2m_popc64(keep);
+                if (MODE == 2) {
+                    // slots (positions after compaction) of the instances that need the general path: scalar bit loop
+                    // over the (few) flagged lanes -- slot = number of kept lanes below
+                    unsigned long long gl = gs2m_ballot_b(general && mine);
+                    gslots = 0ull;
+                    while (gl != 0ull) {
+                        const int g = __ffsll((long long)gl) - 1;
+                        gl &= gl - 1ull;
+                        gslots |= 1ull << gs2m_popc64(keep & ((1ull << g) - 1ull));
+                    }
+                }
             } else {
                 s_a[wave][lane] = bi.a;
                 s_b[wave][lane] = bi.b;
@@ -311,7 +324,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             }
         }
         gs2m_wave_sync();   // s_raw has been consumed, the staged batch is complete
-        const int nb = LROWS > 1 ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
+        const int nb = (LROWS > 1 || MODE == 2) ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
         base += 64u;
         if (base + (unsigned)lane < r1) {  // records of the next batch -> LDS while this one is composited
             const float4* r4 = rv.ab + 2 * (size_t)gid_next;
@@ -424,6 +437,102 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 if (qm0 & (int)lq) step_body(gen_tag, qm0, K0, A0, B0);
             }
         };
+        if (MODE == 2) {
+            // ---- MODE 2 (round 5): "evaluate all four quadrants".  The loop of MODE 0 spends more scalar than vector issue
+            // (per instance-wave on C2: 134 vector cycles per SIMD, but 28 scalar-ALU instructions at ~4.2 SIMD-cycles each
+            // when the CU's one scalar unit is the bottleneck + 12 branches; tools/ubench/salu_rates.hip, r5_rates.hip):
+            // quadrant-mask bit tests, lane-mask bookkeeping, the per-quadrant flag test.  Here an instance that reaches
+            // the loop gets all four quadrants evaluated (2 FMAs + 1 compare each; the 8-px column / row terms are shared),
+            // the candidate test is ONE v_cmp against the lane's own threshold (a finished pixel carries THR_DONE) followed by
+            // a branch on VCC, the accumulate path runs under the execution mask, and the instances that need the
+            // reference's power > 0 test / alpha cap (forward.cu:336-343) are split out per RUN: the staged batch is a
+            // sequence of flag-free runs (software-pipelined fast copy, no cap: op <= 0.98) separated by single flagged
+            // instances (general copy), found with scalar bit scans of `gslots` -- no flag test per instance or quadrant.
+            struct Pre2 {
+                float e0, e1, n0, n1, dy0, dy1;
+            };
+            // column / row terms of one instance (the first use of its broadcast registers: the LDS wait sits here, BEFORE
+            // the next instance's reads are issued, so it never covers a read that was just issued)
+            auto pre2 = [&](const float4 A, const float4 B) __attribute__((always_inline)) {
+                const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
+                Pre2 p;
+                p.dy0 = A.y - pyf0;
+                p.dy1 = A.y - pyf1;
+                p.e0 = fmaf(A.z * dx0, dx0, B.y);
+                p.e1 = fmaf(A.z * dx1, dx1, B.y);
+                p.n0 = -(A.w * dx0);
+                p.n1 = -(A.w * dx1);
+                return p;
+            };
+            auto quads2 = [&](auto gen_tag, const Pre2 p, const float4 B, const float CLx) __attribute__((always_inline)) {
+                constexpr int GTAG = (int)decltype(gen_tag)::value;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dy = (k >> 1) ? p.dy1 : p.dy0;
+                    const float qv = fmaf(fmaf(B.x, dy, (k & 1) ? p.n1 : p.n0), dy, (k & 1) ? p.e1 : p.e0);   // same products and sums as MODE 0
+                    const bool cand = qv >= thr[k];
+                    if (gs2m_any_active_lane(cand)) {     // v_cmp + s_cbranch_vccz
+                        GS2M_NO_IF_CONVERT();
+                        if (cand) {
+                            float alpha = gs2m_fast_exp2(qv);
+                            if (GTAG == 1) {
+                                alpha = fminf(0.99f, alpha);              // alpha cap (forward.cu:343)
+                                alpha = qv > B.y ? 0.0f : alpha;          // power > 0: skipped (forward.cu:336-337)
+                            }
+                            const float test_T = fmaf(-T[k], alpha, T[k]);
+                            float Tn = test_T;
+                            if (gs2m_any_active_lane(test_T < 0.0001f)) {   // a pixel saturates once: behind a wave-uniform branch
+                                GS2M_NO_IF_CONVERT();
+                                const bool sat = test_T < 0.0001f;
+                                thr[k] = sat ? THR_DONE : thr[k];
+                                Tn = sat ? T[k] : test_T;
+                            }
+                            const float wT = T[k] - Tn;
+                            C0[k] = fmaf(B.z, wT, C0[k]);
+                            C1[k] = fmaf(B.w, wT, C1[k]);
+                            C2[k] = fmaf(CLx, wT, C2[k]);
+                            T[k] = Tn;
+                        }
+                    }
+                }
+            };
+            const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
+            const float2* spc = &s_c[wave][0];
+            int j0 = 0;
+            while (j0 < nb) {
+                // next flagged slot at or after j0 (nb if none)
+                const unsigned long long gq = gslots >> j0;
+                const int j1 = gq != 0ull ? j0 + (__ffsll((long long)gq) - 1) : nb;
+                if (j0 < j1) {
+                    float4 A0 = spa[j0], B0 = spb[j0], A1, B1;
+                    float K0 = spc[j0].x, K1;
+                    int j = j0;
+                    for (; j + 1 < j1; j += 2) {
+                        const Pre2 p0 = pre2(A0, B0);
+                        GS2M_SCHED_BARRIER();
+                        A1 = spa[j + 1];
+                        B1 = spb[j + 1];
+                        K1 = spc[j + 1].x;
+                        GS2M_SCHED_BARRIER();
+                        quads2(std::integral_constant<int, 0>{}, p0, B0, K0);
+                        const Pre2 p1 = pre2(A1, B1);
+                        GS2M_SCHED_BARRIER();
+                        A0 = spa[j + 2];
+                        B0 = spb[j + 2];
+                        K0 = spc[j + 2].x;
+                        GS2M_SCHED_BARRIER();
+                        quads2(std::integral_constant<int, 0>{}, p1, B1, K1);
+                    }
+                    if (j < j1) quads2(std::integral_constant<int, 0>{}, pre2(A0, B0), B0, K0);
+                }
+                if (j1 < nb) {
+                    const float4 Ag = spa[j1], Bg = spb[j1];
+                    quads2(std::integral_constant<int, 1>{}, pre2(Ag, Bg), Bg, spc[j1].x);
+                }
+                j0 = j1 + 1;
+            }
+            continue;
+        }
         // one copy of the loop: the instance's flag (bit 8 of the mask word) selects the general path inside the body
         // (a second copy of the loop for flagged batches costs ~12 registers: spills at 7 waves per SIMD)
         (void)batch_general;

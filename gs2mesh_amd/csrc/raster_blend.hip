@@ -14,6 +14,11 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
         // schedule: ceil(chunks / 8) chunks per XCD, GS2M_SCHED_CHUNK lists per chunk, tile_rows waves per list, 4 waves per workgroup
         const int nch = ((gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW) * ((ltiles / gx + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
         const dim3 g2(8u * ((unsigned)(((nch + 7) / 8) * GS2M_SCHED_CHUNK * tile_rows + 3) / 4u), nv);
+        if (mode == 2) {   // GS2M_OPT_BLEND_MODE 2: all four quadrants per instance, flag-free runs (round 5)
+            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 2>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
+            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 2>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
+            return 0;
+        }
         if (mode == 1) {   // GS2M_OPT_BLEND_MODE 1: execution-mask form of the loop
             if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 1>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);
             else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 1>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order);

@@ -134,19 +134,10 @@ class ScalableTSDFVolume:
 
     # ---------------------------------------------------------------------------------------
     def _to_dev(self, a, dtype):
-        """numpy -> device tensor (or pass-through for emulator tests / device tensors)."""
+        """host array / tensor -> contiguous device tensor of ``dtype`` (``_lib.MEMORY.upload``)."""
         if a is None:
             return None
-        if _is_torch(a):
-            if a.dtype != dtype:
-                a = a.to(dtype)
-            return a.contiguous()
-        a = np.ascontiguousarray(a)
-        if _lib.ALLOW_HOST_POINTERS:
-            np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8}[dtype] if torch is not None else None
-            return a.astype(np_dtype, copy=False) if np_dtype is not None else a
-        t = torch.from_numpy(a).to(dtype)
-        return t.to(f"cuda:{self.device}", non_blocking=False)
+        return _lib.MEMORY.upload(a, dtype, self.device)
 
     def integrate(self, image: RGBDImage, intrinsic: PinholeCameraIntrinsic, extrinsic, mask=None, min_depth=0.0,
                   stream=None):
@@ -272,21 +263,14 @@ class ScalableTSDFVolume:
         nt = int(n.value)
         if nt == 0:
             return TriangleMesh()
-        host = _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available())
-        if host:
-            verts = np.zeros((nt, 3, 3), np.float64)
-            cols = np.zeros((nt, 3, 3), np.float64)
-            eidx = np.zeros((nt, 3, 4), np.int32)
-        else:
-            verts = torch.zeros((nt, 3, 3), dtype=torch.float64, device=f"cuda:{self.device}")
-            cols = torch.zeros((nt, 3, 3), dtype=torch.float64, device=f"cuda:{self.device}")
-            eidx = torch.zeros((nt, 3, 4), dtype=torch.int32, device=f"cuda:{self.device}")
+        verts = _lib.MEMORY.zeros((nt, 3, 3), np.float64, self.device)
+        cols = _lib.MEMORY.zeros((nt, 3, 3), np.float64, self.device)
+        eidx = _lib.MEMORY.zeros((nt, 3, 4), np.int32, self.device)
         got = C.c_int64(0)
         _lib.check(self._lib.gs2m_tsdf_extract_indexed(self._h, _stream_of(verts, stream), nt, _ptr(verts), _ptr(cols),
                                                        _ptr(eidx), C.byref(got)), self._lib)
         self.status(stream)
-        if not host:
-            verts, cols, eidx = verts.cpu().numpy(), cols.cpu().numpy(), eidx.cpu().numpy()
+        verts, cols, eidx = _lib.MEMORY.download(verts), _lib.MEMORY.download(cols), _lib.MEMORY.download(eidx)
         has_color = self.color_type == TSDFVolumeColorType.RGB8
         # welded by Open3D's vertex identity (the cut edge), not by position
         return TriangleMesh.from_triangle_soup(verts, cols if has_color else None, edge_index=eidx)
@@ -294,9 +278,7 @@ class ScalableTSDFVolume:
     # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
     def exchange_device(self):
         """where the exchange buffers of this volume live: the GPU, or the host for the emulator build (CPU tests)"""
-        if _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available()):
-            return torch.device("cpu")
-        return torch.device(f"cuda:{self.device}")
+        return _lib.MEMORY.buffer_device(self.device)
 
     def block_keys(self, like=None, stream=None, raise_on_overflow=True, out=None, n=None):
         """Keys of the allocated blocks, slot order (halo copies: sentinel key).  ``out`` / ``n``: write the first n rows of a
@@ -305,10 +287,7 @@ class ScalableTSDFVolume:
             _lib.check(self._lib.gs2m_tsdf_block_keys(self._h, int(n), _ptr(out), _stream_of(out, stream)), self._lib)
             return out[: int(n)]
         n = min(self.status(stream, raise_on_overflow)[0], self.max_blocks)
-        if _lib.ALLOW_HOST_POINTERS and not (torch is not None and torch.cuda.is_available()):
-            keys = np.zeros((n, 3), np.int32)
-        else:
-            keys = torch.zeros((n, 3), dtype=torch.int32, device=f"cuda:{self.device}")
+        keys = _lib.MEMORY.zeros((n, 3), np.int32, self.device)
         _lib.check(self._lib.gs2m_tsdf_block_keys(self._h, n, _ptr(keys), _stream_of(keys, stream)), self._lib)
         return keys
 

@@ -24,29 +24,8 @@ def _is_torch(x):
 
 
 def _ptr(x, dtype=None, name="tensor"):
-    """Device pointer of a contiguous torch tensor (or, for the emulator tests only, the host
-    pointer of a numpy array).  None -> NULL."""
-    if x is None:
-        return None
-    if _is_torch(x):
-        if x.numel() == 0:
-            return None
-        if not x.is_contiguous():
-            raise ValueError(f"{name} must be contiguous")
-        if dtype is not None and x.dtype != dtype:
-            raise TypeError(f"{name} must be {dtype}, got {x.dtype}")
-        if not x.is_cuda and not _lib.ALLOW_HOST_POINTERS:
-            raise RuntimeError(f"{name} must live on a HIP device (there is no CPU path)")
-        return C.c_void_p(x.data_ptr())
-    if isinstance(x, np.ndarray):
-        if not _lib.ALLOW_HOST_POINTERS:
-            raise RuntimeError("numpy arrays are only accepted by the emulator test harness")
-        if x.size == 0:
-            return None
-        if not x.flags["C_CONTIGUOUS"]:
-            raise ValueError(f"{name} must be contiguous")
-        return C.c_void_p(x.ctypes.data)
-    raise TypeError(f"{name}: unsupported type {type(x)}")
+    """Pointer for the C ABI: the device pointer of a contiguous torch tensor on a GPU (``_lib.MEMORY``).  None -> NULL."""
+    return _lib.MEMORY.ptr(x, dtype, name)
 
 
 _NP2T = {}

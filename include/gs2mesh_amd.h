@@ -182,6 +182,22 @@ typedef struct gs2m_gaussians {
  *   out_radii  [n_views,P] i32 device, or NULL
  * All views must share width/height.  Asynchronous; same arena/overflow contract as
  * gs2m_rasterize_forward.
+ *
+ * STATED TOLERANCE against the reference rasteriser (DGR/cuda_rasterizer/forward.cu:261-374) on identical inputs; the same
+ * statement holds for gs2m_rasterize_forward.  Projection, instance lists and sort order are exact (record, point_list,
+ * ranges, radii, num_rendered bit-identical at the defaults).  The compositing stage evaluates alpha in the log2 domain
+ * (v_exp_f32, 1 ulp) and accumulates rgb * (T - T'), so:
+ *   - on every pixel where NO decision of renderCUDA (power > 0, alpha < 1/255, T' < 1e-4) is taken within a relative
+ *     band of 1e-5 of its threshold, |out_color - reference| <= 2e-4 per value ("clean bar");
+ *     measured <= 5.5e-7 on C2 .. C5 (profiles/r4_parity_*.json);
+ *   - elsewhere a decision may flip; the difference is then bounded by 2e-4 + the contribution of the flipped
+ *     instances (oracle/parity.py:flip_attribution computes that bound per pixel; the tests assert zero unexplained
+ *     pixels).  Measured global maxima: 2.0e-3 on C2 (25 k of 3.84 M pixels carry a candidate flip), 3.8e-4 on C3,
+ *     3.8e-3 on C4, 6.2e-4 on C5; the tests bound them by <= 2x measured (tests/test_fullsize_gpu.py:BENCH_PARITY_BOUNDS);
+ *   - out_rgb8 differs from the quantised reference by at most 1 LSB, on <= 70 pixels of a C2 eye;
+ *   - with g->raw != 0 (activations fused into the projection: exp / sigmoid / normalize in device arithmetic, 1 ulp from
+ *     numpy's) about 1 radius in 3e5 Gaussians moves by one pixel and one (Gaussian, tile) instance with it; the
+ *     bench line and the tests report the count (`radii_mismatches`), the image bound above already includes it.
  */
 int gs2m_render_views(gs2m_raster* r, const gs2m_gaussians* g, const gs2m_camera* cams,
                       int n_views, const float* bg /* host[3] */, float scale_modifier,

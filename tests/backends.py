@@ -18,6 +18,53 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 from gs2mesh_amd import _lib  # noqa: E402
 
 
+class HostMemory(_lib.DeviceMemory):
+    """Memory policy of the EMULATOR harness: the emulator build of the kernels runs on the CPU, so its "device"
+    pointers are host pointers (numpy arrays, CPU torch tensors).  Lives in the test tree; the product's policy
+    (``_lib.DeviceMemory``) refuses both."""
+
+    def ptr(self, x, dtype=None, name="tensor"):
+        import torch
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            if x.numel() == 0:
+                return None
+            if not x.is_contiguous():
+                raise ValueError(f"{name} must be contiguous")
+            if dtype is not None and x.dtype != dtype:
+                raise TypeError(f"{name} must be {dtype}, got {x.dtype}")
+            return C.c_void_p(x.data_ptr())
+        if isinstance(x, np.ndarray):
+            if x.size == 0:
+                return None
+            if not x.flags["C_CONTIGUOUS"]:
+                raise ValueError(f"{name} must be contiguous")
+            return C.c_void_p(x.ctypes.data)
+        raise TypeError(f"{name}: unsupported type {type(x)}")
+
+    def buffer_device(self, device):
+        import torch
+        return torch.device("cpu")
+
+    def zeros(self, shape, np_dtype, device):
+        return np.zeros(tuple(shape), np_dtype)
+
+    def upload(self, a, torch_dtype, device):
+        import torch
+        if isinstance(a, torch.Tensor):
+            return (a if a.dtype == torch_dtype else a.to(torch_dtype)).contiguous()
+        np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8}[torch_dtype]
+        return np.ascontiguousarray(a).astype(np_dtype, copy=False)
+
+    def download(self, t):
+        return np.asarray(t)
+
+
+def use_host_memory(on: bool):
+    _lib.MEMORY = HostMemory() if on else _lib.DeviceMemory()
+
+
 class EmuBackend:
     name = "emu"
     _cached = None
@@ -27,7 +74,7 @@ class EmuBackend:
             import build_emu
             EmuBackend._cached = _lib.bind(C.CDLL(build_emu.build()), require_all=False)
         self.lib = EmuBackend._cached
-        _lib.ALLOW_HOST_POINTERS = True
+        use_host_memory(True)
 
     def dev(self, a):
         return None if a is None else np.ascontiguousarray(a)
@@ -48,7 +95,7 @@ class GpuBackend:
             pytest.skip("no GPU visible")
         self.torch = torch
         self.lib = _lib.get()
-        _lib.ALLOW_HOST_POINTERS = False
+        use_host_memory(False)
 
     def dev(self, a):
         if a is None:

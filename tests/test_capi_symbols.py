@@ -63,13 +63,20 @@ def test_host_pointers_are_rejected_by_the_product_wrappers():
     import numpy as np
     import torch
     from gs2mesh_amd import _lib, rasterizer
-    old = _lib.ALLOW_HOST_POINTERS
-    _lib.ALLOW_HOST_POINTERS = False
+    old = _lib.MEMORY
+    _lib.MEMORY = _lib.DeviceMemory()
     try:
         with pytest.raises(RuntimeError):
             rasterizer._ptr(np.zeros(4, np.float32))
         with pytest.raises(RuntimeError, match="HIP device"):
             rasterizer._ptr(torch.zeros(4))
     finally:
-        _lib.ALLOW_HOST_POINTERS = old
+        _lib.MEMORY = old
 
+
+def test_product_tree_has_no_host_pointer_switch():
+    """the emulator harness injects its memory policy from the test tree (tests/backends.HostMemory)"""
+    import pathlib
+    root = pathlib.Path(__file__).resolve().parents[1] / "gs2mesh_amd"
+    for f in root.rglob("*.py"):
+        assert "ALLOW_HOST_POINTERS" not in f.read_text(), f

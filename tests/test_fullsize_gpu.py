@@ -59,7 +59,15 @@ def test_c2_stereo_pair_vs_oracle_and_invariants():
     assert (radii != ref_radii).mean() < 2e-3
     assert abs(n_ref_mode[0] - ref_n) < 2e-3 * ref_n
     diff = np.abs(img[0] - ref)
-    assert (diff > 2e-5).mean() < 2e-3 and diff.max() < 2e-2
+    # measured on MI355X: max 2.0e-3 on this eye (profiles/r4_parity_C2_blend4.json: 2.6e-3 worst over the bench's pair);
+    # bound = 2x measured, and the outliers are held to the CHECKED flip statement below, not to the global bound alone
+    assert (diff > 2e-5).mean() < 2e-3 and diff.max() < 5e-3, float(diff.max())
+    from oracle import parity
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, 0)
+    rr = R.render_views(gd, pair, want_radii=True)
+    assert np.array_equal(rr["color"].cpu().numpy(), img)
+    fa = parity.compositing_attribution(R.download_geometry(0, cfg.P), rr["radii"].cpu().numpy()[0], cfg.width, cfg.height, img[0])
+    assert fa["ok"] and fa["max_abs_clean"] <= 2e-4 and fa["unexplained_pixels"] == 0, {k: fa[k] for k in ("max_abs_clean", "unexplained_pixels", "worst_unexplained")}
     mse = float((diff.astype(np.float64) ** 2).mean())
     psnr = 20 * np.log10(1.0 / np.sqrt(mse)) if mse > 0 else np.inf      # GS/utils/image_utils.py:17-19
     assert psnr > 80.0, psnr

@@ -741,7 +741,7 @@ def test_hip_path_against_reference_golden(backend):
 @pytest.mark.parametrize("opts", [{_lib.OPT_BIN_WORKGROUPS: 2, _lib.OPT_BIN_WG_THREADS: 128},
                                   {_lib.OPT_BIN_WORKGROUPS: 3, _lib.OPT_BIN_WG_THREADS: 1024},
                                   {_lib.OPT_BIN_WORKGROUPS: 64, _lib.OPT_BIN_WG_THREADS: 64},
-                                  {_lib.OPT_BLEND_MODE: 1}])
+                                  {_lib.OPT_BLEND_MODE: 1}, {_lib.OPT_BLEND_MODE: 2}])
 def test_tuning_options_do_not_change_results(backend, opts):
     """The tuning options of gs2m_raster_set_option: k_count_tiles / k_scatter with few large workgroup chunks (several loop
     iterations per workgroup, partial last iteration) and with small workgroups; GS2M_OPT_BLEND_MODE 1 = the compositing loop
@@ -927,6 +927,37 @@ def test_trained_like_splats_with_flip_attribution(backend, rows, cull):
     assert fa["ok"], fa
     assert fa["max_abs_clean"] <= 2e-4, fa
     assert_image_close(img, ref_img, frac_tol=3e-4)
+
+
+
+@pytest.mark.parametrize("rows,cull", [(1, 0), (2, 1)])
+def test_blend_loop_forms_are_bit_identical(backend, rows, cull):
+    """GS2M_OPT_BLEND_MODE 0 / 1 / 2 are three loop forms of the same arithmetic (raster_blend.h): lane masks in scalar
+    registers, execution masks, and "all four quadrants + flag-free runs" (round 5).  On `synthetic.trained_like` -- 30 % of
+    the opacities at the alpha cap (the general path of every mode), saturating pixels, near-singular conics, lists longer
+    than one staging batch -- the three images must be equal bit for bit, at both binning tile sizes."""
+    W, H, f = 200, 136, 180.0
+    g = synthetic.trained_like(5000, 23, math.log(0.03), focal=f)
+    s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
+    shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+    pose = synthetic.ring_pose(0.3, 3.5)
+    pose = np.concatenate([pose[0], pose[1][:, None]], axis=1)
+    cam, _ = synthetic.stereo_cameras(pose, W, H, f, f, 0.245)
+    bg = np.asarray([0.2, 0.1, 0.3], np.float32)
+    be = backend
+    d = be.dev
+    imgs = []
+    for mode in (0, 1, 2):
+        r = Rasterizer(0, lib=be.lib)
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+        r.set_option(_lib.OPT_TILE_ROWS, rows)
+        r.set_option(_lib.OPT_BLEND_MODE, mode)
+        img, _ = r.forward(d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                           d(bg), W, H, cam.tanfovx, cam.tanfovy, shs=d(shs), scales=d(s), rotations=d(q))
+        imgs.append(np.array(be.host(img)))
+    assert np.array_equal(imgs[0], imgs[1])
+    assert np.array_equal(imgs[0], imgs[2])
+    assert (imgs[0] != bg[:, None, None]).any()
 
 
 def test_flip_bounds_count_the_decisions_at_their_thresholds():
