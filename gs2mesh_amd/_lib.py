@@ -41,6 +41,9 @@ OPT_PAIR_BATCH = 8
 OPT_BIN_WORKGROUPS = 9      # tuning options: results never change
 OPT_BIN_WG_THREADS = 10
 OPT_BLEND_MODE = 11
+OPT_BLEND_PROFILE = 12
+BLEND_PROF_COUNTERS = ("waves", "wave_cycles", "dma_wait", "staging", "prefetch_issue", "loop", "epilogue", "batches",
+                       "staged_instances", "listed_instances")
 XFORM_SUM_F32, XFORM_RAW_F32, XFORM_SUM_PACKED = 0, 1, 2
 XFORM_PACKED_MAX_FRAMES = 1023
 OPT_DEBUG_SYNC = 3
@@ -65,6 +68,7 @@ _PROTOS = {
     "gs2m_raster_pack_invalidate": (i32, [vp]),
     "gs2m_raster_status": (i32, [vp, vp, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64)]),
     "gs2m_raster_stage_times": (i32, [vp, vp, C.POINTER(f64), C.POINTER(i64)]),
+    "gs2m_raster_blend_cycles": (i32, [vp, vp, C.POINTER(C.c_uint64)]),
     "gs2m_raster_download_geometry": (i32, [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "gs2m_raster_download_binning": (i32, [vp, vp, i32, i64, vp, C.c_int32, vp]),
     "gs2m_tsdf_extract_count": (i32, [vp, vp, C.POINTER(i64)]),

@@ -83,4 +83,13 @@ GS2M_DEVICE float gs2m_fast_log2(float x) { return __log2f(x); }
 GS2M_DEVICE void gs2m_global_load_lds16(const void* g, void* lds_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
+// shader clock (s_memtime): phase stamps of the profile builds
+// One asm statement: the value is complete when the statement ends (the scalar-memory return is asynchronous -- a
+// destination the compiler believes free would be overwritten later), and it waits for the scalar / LDS counter only, never
+// for vector memory (the builtin made the compiler drain the record DMA at every stamp: 7.5x slower kernel).
+GS2M_DEVICE unsigned long long gs2m_clock() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    return t;
+}
 GS2M_DEVICE void gs2m_wait_dma() { __builtin_amdgcn_s_waitcnt(0x0f70); }  // s_waitcnt vmcnt(0)

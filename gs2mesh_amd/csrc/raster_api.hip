@@ -40,7 +40,9 @@ extern "C" int gs2m_version(void) { return GS2M_VERSION; }
 struct gs2m_raster {
     int device = 0;
     int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_pair_batch = 0;
-    int opt_bin_workgroups = 256, opt_bin_wg_threads = 1024, opt_blend_mode = 0;   // tuning options (gs2m_raster_set_option)
+    int opt_bin_workgroups = 256, opt_bin_wg_threads = 1024, opt_blend_mode = 2;   // tuning options (gs2m_raster_set_option)
+    int opt_blend_profile = 0;
+    unsigned long long* d_blend_prof = nullptr;   // [GS2M_BLEND_PROF_COUNTERS] phase-cycle sums of the profile build (GS2M_OPT_BLEND_PROFILE)
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -146,6 +148,7 @@ extern "C" int gs2m_raster_destroy(gs2m_raster* r) {
     (void)hipFree(r->d_keys);
     (void)hipFree(r->d_tmp);
     (void)hipFree(r->d_status);
+    (void)hipFree(r->d_blend_prof);
     (void)hipHostFree(r->h_status);
     for (auto& p : r->ev_live) {
         (void)hipEventDestroy(p.a);
@@ -206,6 +209,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
                 return 1;
             }
             r->opt_blend_mode = value;
+            return 0;
+        case GS2M_OPT_BLEND_PROFILE:
+            r->opt_blend_profile = value != 0;
+            if (value && !r->d_blend_prof) {
+                HIPCHK(hipMalloc((void**)&r->d_blend_prof, 64 * 16 * sizeof(unsigned long long)));   // 64 copies, one per 128 B
+                HIPCHK(hipMemset(r->d_blend_prof, 0, 64 * 16 * sizeof(unsigned long long)));
+            }
             return 0;
         default: gs2m_set_error("unknown option %d", option); return 1;
     }
@@ -394,7 +404,8 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
         if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, recs, r->d_cams,
                               g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
-                              r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_mode))
+                              r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_mode,
+                              r->opt_blend_profile ? r->d_blend_prof : nullptr))
             return 1;
     }
     if (dbg_check(r, st, "blend")) return 1;
@@ -720,6 +731,22 @@ extern "C" int gs2m_raster_stage_times(gs2m_raster* r, gs2m_stream stream, doubl
         r->ev_free.push_back(p.b);
     }
     r->ev_live.clear();
+    return 0;
+}
+
+extern "C" int gs2m_raster_blend_cycles(gs2m_raster* r, gs2m_stream stream, uint64_t* counters) {
+    if (!r || !counters) {
+        gs2m_set_error("gs2m_raster_blend_cycles: NULL argument");
+        return 1;
+    }
+    for (int i = 0; i < GS2M_BLEND_PROF_COUNTERS; ++i) counters[i] = 0;
+    if (!r->d_blend_prof) return 0;
+    unsigned long long h[64 * 16];
+    HIPCHK(hipMemcpyAsync(h, r->d_blend_prof, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(r->d_blend_prof, 0, sizeof(h), (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    for (int c = 0; c < 64; ++c)
+        for (int i = 0; i < GS2M_BLEND_PROF_COUNTERS; ++i) counters[i] += h[c * 16 + i];
     return 0;
 }
 

@@ -144,12 +144,27 @@ struct BlendInst {
     float2 c;
 };
 
-template <int WPB, int LROWS, int OCC, int MODE = 0>
+// PROF = 1 (GS2M_OPT_BLEND_PROFILE): the same kernel with s_memtime stamps at the phase boundaries of every wave, summed
+// into prof[GS2M_BLEND_PROF_N] with one atomic per counter per wave (the stamps cost ~10 % themselves: shares, not times).
+#define GS2M_BLEND_PROF_N 10
+template <int WPB, int LROWS, int OCC, int MODE = 0, int PROF = 0>
 GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRecs recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
-               const unsigned* __restrict__ order) {
+               const unsigned* __restrict__ order, unsigned long long* __restrict__ prof = nullptr) {
+    unsigned long long pt_wait = 0, pt_stage = 0, pt_issue = 0, pt_loop = 0, pn_batches = 0, pn_staged = 0;
+    // Phase stamps of the profile build: the interval since the previous stamp is added to the phase that ENDS here.
+    unsigned long long pt_pro = 0, pt_epi = 0;
+    const unsigned long long pt_begin = PROF ? gs2m_clock() : 0ull;
+    unsigned long long pt_mark = pt_begin;
+    auto stamp = [&](unsigned long long& acc) __attribute__((always_inline)) {
+        if (PROF) {
+            const unsigned long long now = gs2m_clock();
+            acc += now - pt_mark;
+            pt_mark = now;
+        }
+    };
     // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
     // log2 o, r, g}, c = {b, quadrant mask | general << 8 (bits)}; 2 pad slots: the software-pipelined reads run 2
     // instances ahead.  5.6 KiB of LDS per wave with the DMA landing zone: 7 waves per SIMD fit the 160 KiB.
@@ -241,13 +256,16 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             gs2m_global_load_lds16(rv.c + gid, &s_raw[wave][2][0]);
         }
     }
+    stamp(pt_pro);   // prologue: schedule lookup, first ids / ranks / record DMA
     while (base < r1) {
         unsigned lq = 0u;  // quadrants that still have unfinished pixels
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             lq |= ((MODE != 0 ? gs2m_ballot_b(thr[k] < 0.0f) != 0ull : dn[k] != ~0ull) ? 1u : 0u) << k;
         if (lq == 0u) break;
+        stamp(pt_loop);        // (tail of the previous batch's loop + the all-finished test)
         gs2m_wait_dma();       // this batch's records have landed in s_raw
+        stamp(pt_wait);
         gs2m_wave_sync();      // ... and the previous batch's staged instances have been read by every lane
         int nb_staged = 0;
         unsigned long long gslots = 0ull;   // MODE 2: staged slots that take the general path
@@ -324,6 +342,7 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             }
         }
         gs2m_wave_sync();   // s_raw has been consumed, the staged batch is complete
+        stamp(pt_stage);
         const int nb = (LROWS > 1 || MODE == 2) ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
         base += 64u;
         if (base + (unsigned)lane < r1) {  // records of the next batch -> LDS while this one is composited
@@ -338,6 +357,11 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             if (base + 128u + (unsigned)lane < r1) kid_next2 = (unsigned)(kv[base + 128u + lane] & 0xffffffffull);
         } else if (base + 64u + (unsigned)lane < r1) {
             gid_next = (unsigned)(kv[base + 64u + lane] & 0xffffffffull);
+        }
+        stamp(pt_issue);
+        if (PROF) {
+            pn_batches += 1;
+            pn_staged += (unsigned long long)nb;
         }
         // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
         // constants are in flight while instance j is composited (no LDS wait on the critical path).
@@ -538,7 +562,9 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         (void)batch_general;
         run_loop(std::integral_constant<int, 2>{});
     }
+    stamp(pt_loop);
     gs2m_wait_dma();   // never leave with a DMA write to this workgroup's LDS in flight
+    stamp(pt_wait);
     const size_t plane = (size_t)H * W;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -558,6 +584,23 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 o8[1] = quantize_u8(o1);
                 o8[2] = quantize_u8(o2);
             }
+        }
+    }
+    if (PROF && prof) {
+        stamp(pt_epi);
+        if (lane == 0) {
+            // 64 copies of the counter block, one per 128 B: a launch ends ~30 k waves, all on the same 10 words otherwise
+            unsigned long long* pc = prof + (size_t)(blockIdx.x & 63u) * 16;
+            atomicAdd(&pc[0], 1ull);
+            atomicAdd(&pc[1], pt_mark - pt_begin);
+            atomicAdd(&pc[2], pt_wait);
+            atomicAdd(&pc[3], pt_stage);
+            atomicAdd(&pc[4], pt_issue + pt_pro);
+            atomicAdd(&pc[5], pt_loop);
+            atomicAdd(&pc[6], pt_epi);      // background blend + image stores
+            atomicAdd(&pc[7], pn_batches);
+            atomicAdd(&pc[8], pn_staged);
+            atomicAdd(&pc[9], (unsigned long long)(r1 - r0));
         }
     }
 }

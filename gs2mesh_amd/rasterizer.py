@@ -141,6 +141,13 @@ class Rasterizer:
         _lib.check(self._lib.gs2m_raster_stage_times(self._h, stream or C.c_void_p(0), ms, cnt), self._lib)
         return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.RASTER_STAGES)}
 
+    def blend_cycles(self, stream=None):
+        """With OPT_BLEND_PROFILE on: {counter: value} of the compositing kernel's phase stamps since the last query."""
+        n = len(_lib.BLEND_PROF_COUNTERS)
+        c = (C.c_uint64 * n)()
+        _lib.check(self._lib.gs2m_raster_blend_cycles(self._h, stream or C.c_void_p(0), c), self._lib)
+        return {name: int(c[i]) for i, name in enumerate(_lib.BLEND_PROF_COUNTERS)}
+
     # -- operator level -------------------------------------------------------------------------
     def forward(self, means3D, opacities, viewmatrix, projmatrix, campos, bg, W, H, tanfovx, tanfovy, shs=None,
                 colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, sh_degree=3,

@@ -74,8 +74,14 @@ enum {
     GS2M_OPT_BIN_WORKGROUPS = 9,  /* workgroups of the counting / scatter kernels per stereo pair (default 0 = 256, one per CU: the
                                      per-workgroup histogram rows / cursors scale with their number) */
     GS2M_OPT_BIN_WG_THREADS = 10, /* upper bound of their threads per workgroup, a multiple of 64 (default 0 = 1024) */
-    GS2M_OPT_BLEND_MODE = 11,     /* compositing loop of variant 4: 0 (default) = per-pixel decisions as lane masks in scalar
-                                     registers; 1 = execution-mask form (fewer scalar instructions, same time: DESIGN.md 3) */
+    GS2M_OPT_BLEND_MODE = 11,     /* compositing loop of variant 4 (three forms of the same arithmetic, bit-identical images):
+                                     2 (default, round 5) = every staged instance evaluates all four 8x8 quadrants, candidate
+                                     test = one v_cmp against the lane's own threshold, accumulate under the execution mask,
+                                     the alpha-cap / power > 0 instances split out per run of the staged batch;
+                                     0 = per-pixel decisions as lane masks in scalar registers + per-instance quadrant mask;
+                                     1 = execution-mask form of 0 */
+    GS2M_OPT_BLEND_PROFILE = 12,  /* 1 = launch the s_memtime-instrumented build of the compositing kernel (mode 2 only) and sum
+                                     its per-wave phase cycles in the handle; read with gs2m_raster_blend_cycles */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and
@@ -246,6 +252,15 @@ int gs2m_raster_status(gs2m_raster* r, gs2m_stream stream, int n_views,
  * and the number of launches to launches[GS2M_N_STAGES] (host arrays, caller-zeroed). */
 int gs2m_raster_stage_times(gs2m_raster* r, gs2m_stream stream, double* total_ms,
                             int64_t* launches);
+
+/* Phase profile of the compositing kernel (GS2M_OPT_BLEND_PROFILE 1): synchronises `stream`, copies the counters summed
+ * over every wave launched since the last query to counters[GS2M_BLEND_PROF_COUNTERS] (host) and clears them:
+ *   [0] waves  [1] wave lifetime  [2] waiting for the record DMA  [3] staging a batch (transform, cull, compaction)
+ *   [4] issuing the next batch's loads  [5] compositing loop  [6] epilogue (background, image stores)   -- shader cycles
+ *   [7] staged batches  [8] staged instances (after the per-half / finished-quadrant cull)  [9] listed instances
+ * The stamps themselves cost ~10 % of the wave's cycles: read the counters as shares. */
+#define GS2M_BLEND_PROF_COUNTERS 10
+int gs2m_raster_blend_cycles(gs2m_raster* r, gs2m_stream stream, uint64_t* counters);
 
 /* Debug/parity taps: copy the projected per-Gaussian record of view `v` of the last call to
  * HOST buffers (any may be NULL): means2D[P,2], depths[P], conic_opacity[P,4], rgb[P,3],

@@ -124,6 +124,7 @@ static inline int __ffsll(unsigned long long m) { return __builtin_ffsll((long l
 
 static inline void gs2m_global_load_lds16(const void* g, void* lds_base) { memcpy((char*)lds_base + 16 * ::emu::lane(), g, 16); }
 static inline void gs2m_wait_dma() {}
+static inline unsigned long long gs2m_clock() { return 0ull; }
 
 // ---- bit casts / math ----------------------------------------------------------------------
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }

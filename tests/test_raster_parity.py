@@ -930,14 +930,14 @@ def test_trained_like_splats_with_flip_attribution(backend, rows, cull):
 
 
 
-@pytest.mark.parametrize("rows,cull", [(1, 0), (2, 1)])
-def test_blend_loop_forms_are_bit_identical(backend, rows, cull):
+@pytest.mark.parametrize("rows,cull,log_s", [(1, 0, math.log(0.03)), (2, 1, math.log(0.03)), (2, 1, math.log(0.006))])
+def test_blend_loop_forms_are_bit_identical(backend, rows, cull, log_s):
     """GS2M_OPT_BLEND_MODE 0 / 1 / 2 are three loop forms of the same arithmetic (raster_blend.h): lane masks in scalar
     registers, execution masks, and "all four quadrants + flag-free runs" (round 5).  On `synthetic.trained_like` -- 30 % of
     the opacities at the alpha cap (the general path of every mode), saturating pixels, near-singular conics, lists longer
     than one staging batch -- the three images must be equal bit for bit, at both binning tile sizes."""
     W, H, f = 200, 136, 180.0
-    g = synthetic.trained_like(5000, 23, math.log(0.03), focal=f)
+    g = synthetic.trained_like(5000, 23, log_s, focal=f)
     s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
     shs = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
     pose = synthetic.ring_pose(0.3, 3.5)
@@ -947,16 +947,22 @@ def test_blend_loop_forms_are_bit_identical(backend, rows, cull):
     be = backend
     d = be.dev
     imgs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):     # 3 = mode 2 through the instrumented build (phase counters)
         r = Rasterizer(0, lib=be.lib)
         r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
         r.set_option(_lib.OPT_TILE_ROWS, rows)
-        r.set_option(_lib.OPT_BLEND_MODE, mode)
+        r.set_option(_lib.OPT_BLEND_MODE, min(mode, 2))
+        if mode == 3:
+            r.set_option(_lib.OPT_BLEND_PROFILE, 1)
         img, _ = r.forward(d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
                            d(bg), W, H, cam.tanfovx, cam.tanfovy, shs=d(shs), scales=d(s), rotations=d(q))
         imgs.append(np.array(be.host(img)))
+        if mode == 3:
+            c = r.blend_cycles()
     assert np.array_equal(imgs[0], imgs[1])
     assert np.array_equal(imgs[0], imgs[2])
+    assert np.array_equal(imgs[0], imgs[3])
+    assert c["batches"] > 0 and 0 < c["staged_instances"] <= c["listed_instances"] * (2 if rows == 2 else 1)
     assert (imgs[0] != bg[:, None, None]).any()
 
 
