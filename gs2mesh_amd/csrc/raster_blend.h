@@ -152,7 +152,7 @@ GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
 k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
                const GeomRecs recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
                float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
-               const unsigned* __restrict__ order, unsigned long long* __restrict__ prof = nullptr) {
+               const unsigned* __restrict__ order, unsigned long long* __restrict__ prof = nullptr, int nv_x = 0) {
     unsigned long long pt_wait = 0, pt_stage = 0, pt_issue = 0, pt_loop = 0, pn_batches = 0, pn_staged = 0;
     // Phase stamps of the profile build: the interval since the previous stamp is added to the phase that ENDS here.
     unsigned long long pt_pro = 0, pt_epi = 0;
@@ -173,11 +173,15 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     __shared__ float4 s_raw[WPB][3][64];   // DMA landing zone: the three 16-B vectors of the next batch's GeomRecs
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int v = (int)blockIdx.y;
+    // Views interleaved along blockIdx.x (nv_x > 1, MODE 2): per XCD the dispatch order is chunk rank major, view
+    // minor, so the heavy chunks of ALL views of the launch start first.  With the views along blockIdx.y the heavy
+    // chunks of the last view were dispatched in the last quarter of a 4-view launch and the kernel ended on them.
+    const int nvx = gs2m_uniform(nv_x);   // > 1: that many views interleaved along blockIdx.x
+    const int v = nvx > 1 ? (int)((blockIdx.x / 8u) % (unsigned)nvx) : (int)blockIdx.y;
     const CamUniform& cam = cams[v];
     const int W = cam.W, H = cam.H, gx = cam.gx;
     const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);    // instance lists
-    const unsigned bid = blockIdx.x;
+    const unsigned bid = nvx > 1 ? (blockIdx.x / 8u / (unsigned)nvx) * 8u + blockIdx.x % 8u : blockIdx.x;
     int tx, ty;
     {
         // k_tile_scan's schedule: chunks of GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring lists ranked by descending weight; rank p is

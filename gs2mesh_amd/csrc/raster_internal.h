@@ -38,7 +38,7 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
 int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx, int gy, const unsigned long long* keys,
                       const unsigned* tile_start, GeomRecs recs, const CamUniform* cams, int P,
                       unsigned cap, float* out_color, unsigned char* out_rgb8, const int* rank, const unsigned* order,
-                      int mode, unsigned long long* prof);
+                      int mode, unsigned long long* prof, int interleave_views);
 
 // error plumbing (common_api.hip)
 void gs2m_set_error(const char* fmt, ...);
