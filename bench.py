@@ -607,10 +607,15 @@ def main():
         # "threads = all host cores" -- reported next to the faster setting (one frame; skipped when the
         # 16-thread frame already takes seconds: 256 threads on 16 x-slices only oversubscribe)
         if cores not in probes:
-            if best_t < 2.0:
+            if cores <= 64 and best_t < 2.0:
                 probe_one(cores)
             else:
-                probes[cores] = dict(threads=cores, skipped=f"one frame takes {best_t:.1f} s at {best_threads} threads")
+                # measured once in round 5 (profiles/r5_bench_C2_with_all_cores_probe.json): 256 OpenMP threads over the 16
+                # x-slices of a block = 218 s for ONE C2 frame (0.03 Mvoxel-updates/s; 16 threads: 0.07 s, 64: 0.30 s) --
+                # the team spins at ~1800 barriers per frame.  Not repeated in every bench run.
+                probes[cores] = dict(threads=cores, skipped="oversubscribed: upstream parallelises the 16 x-slices of one block; "
+                                     "measured 0.03 Mvoxel-updates/s (218 s per C2 frame) at 256 threads, "
+                                     "profiles/r5_bench_C2_with_all_cores_probe.json")
         ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
         ref.set_threads(best_threads)
         t_cpu, n_cpu, blocks_cpu = 0.0, 0, 0
