@@ -41,6 +41,7 @@ OPT_PAIR_BATCH = 8
 OPT_BIN_WORKGROUPS = 9      # tuning options: results never change
 OPT_BIN_WG_THREADS = 10
 OPT_BLEND_MODE = 11
+TSDF_MAP_HEADER_BYTES = 32
 OPT_BLEND_PROFILE = 12
 BLEND_PROF_COUNTERS = ("waves", "wave_cycles", "dma_wait", "staging", "prefetch_issue", "loop", "epilogue", "batches",
                        "staged_instances", "listed_instances")
@@ -89,6 +90,10 @@ _PROTOS = {
     "gs2m_tsdf_pack_sum": (i32, [vp, vp, i64, vp, vp]),
     "gs2m_tsdf_unpack_sum": (i32, [vp, vp, i64, vp, i32, vp]),
     "gs2m_tsdf_pack": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "gs2m_tsdf_replace": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "gs2m_tsdf_map_bytes": (i64, [C.POINTER(C.c_int32), i32]),
+    "gs2m_tsdf_block_map": (i32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32, i32, i64, i64, i32, vp, vp]),
+    "gs2m_tsdf_map_keys": (i32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32, vp, vp, i64, C.POINTER(C.c_uint8), vp]),
     "gs2m_tsdf_unpack": (i32, [vp, vp, i64, i32, vp, vp, i32, vp]),
 }
 

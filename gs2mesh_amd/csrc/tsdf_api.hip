@@ -87,15 +87,17 @@ static bool invert4x4(const double* m, double* inv) {
 }
 
 // `whole_pool`: at creation (hipMalloc'ed memory is not zero); later resets only clear the slots that were handed out
-static int zero_state(gs2m_tsdf* t, hipStream_t st, bool whole_pool) {
+static int zero_state(gs2m_tsdf* t, hipStream_t st, bool whole_pool, long long keep_first = -1) {
     TsdfVolume& V = t->V;
     if (whole_pool) {
         HIPCHK(hipMemsetAsync(V.tsdf, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
         HIPCHK(hipMemsetAsync(V.weight, 0, sizeof(float) * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
         if (V.rgb) HIPCHK(hipMemsetAsync(V.rgb, 0, sizeof(unsigned) * 3 * (size_t)V.max_blocks * GS2M_TSDF_VOX, st));
         HIPCHK(hipMemsetAsync(V.halo, 0, (size_t)V.max_blocks, st));
-    } else {
+    } else if (keep_first < 0) {
         gs2m_launch_tsdf_clear_used(st, V);   // reads counters[0] on the device: no host sync
+    } else {
+        gs2m_launch_tsdf_clear_from(st, V, (unsigned)keep_first);   // gs2m_tsdf_replace: slots [0, keep_first) are overwritten next
     }
     HIPCHK(hipMemsetAsync(V.hash_keys, 0xff, sizeof(unsigned long long) * (size_t)V.hash_cap, st));
     HIPCHK(hipMemsetAsync(V.hash_vals, 0xff, sizeof(int) * (size_t)V.hash_cap, st));
@@ -459,6 +461,63 @@ extern "C" int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m
     return 0;
 }
 
+// bytes of the exchange buffer of a window of dim[0] x dim[1] x dim[2] blocks and `world` ranks: the cells (one byte per block,
+// rounded up to 16 so the header is aligned), then the header
+static int64_t map_bytes(const int32_t* dim, int world, unsigned* n_cells_out) {
+    if (!dim || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0 || world <= 0) return -1;
+    const int64_t cells = (int64_t)dim[0] * dim[1] * dim[2];
+    if (cells > ((int64_t)1 << 30)) return -1;
+    const unsigned nc = (unsigned)((cells + 15) / 16 * 16);
+    if (n_cells_out) *n_cells_out = nc;
+    return (int64_t)nc + GS2M_TSDF_MAP_HEADER_BYTES + 8 * (int64_t)world;
+}
+
+static unsigned window_hash(const int32_t* lo, const int32_t* dim) {
+    unsigned h = 2166136261u;
+    for (int k = 0; k < 3; ++k) {
+        h = (h ^ (unsigned)lo[k]) * 16777619u;
+        h = (h ^ (unsigned)dim[k]) * 16777619u;
+    }
+    return h;
+}
+
+extern "C" int64_t gs2m_tsdf_map_bytes(const int32_t* dim, int world) { return map_bytes(dim, world, nullptr); }
+
+extern "C" int gs2m_tsdf_block_map(gs2m_tsdf* t, const int32_t* lo, const int32_t* dim, int rank, int world, int64_t frames_local,
+                                   int64_t frames_base, int flags, uint8_t* cells, gs2m_stream stream) {
+    unsigned nc = 0;
+    const int64_t total = map_bytes(dim, world, &nc);
+    if (!t || !lo || !cells || total < 0 || rank < 0 || rank >= world || frames_local < 0 || frames_base < 0 ||
+        frames_local > 0x7fffffff || frames_base > 0x7fffffff) {
+        gs2m_set_error("gs2m_tsdf_block_map: bad argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(cells, 0, (size_t)total, st));
+    gs2m_launch_tsdf_block_map(st, t->V, lo, dim, cells, nc, (unsigned)flags, window_hash(lo, dim), rank, (unsigned)frames_local,
+                               (unsigned)frames_base);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_map_keys(gs2m_tsdf* t, const int32_t* lo, const int32_t* dim, int world, uint8_t* cells, int32_t* keys,
+                                  int64_t max_keys, uint8_t* header_host, gs2m_stream stream) {
+    unsigned nc = 0;
+    const int64_t total = map_bytes(dim, world, &nc);
+    if (!t || !lo || !cells || total < 0 || max_keys < 0 || (max_keys > 0 && !keys) || !header_host) {
+        gs2m_set_error("gs2m_tsdf_map_keys: bad argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    gs2m_launch_tsdf_map_keys(st, lo, dim, cells, nc, keys, (unsigned)(max_keys > 0x7fffffff ? 0x7fffffff : max_keys));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(header_host, cells + nc, (size_t)(total - nc), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
 extern "C" int gs2m_tsdf_download(gs2m_tsdf* t, gs2m_stream stream, int64_t n, int32_t* keys, float* tsdf,
                                   float* weight, uint32_t* rgb_sum) {
     if (!t || n < 0) {
@@ -531,6 +590,20 @@ extern "C" int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, in
     HIPCHK(hipSetDevice(t->device));
     gs2m_launch_tsdf_unpack((hipStream_t)stream, (unsigned)n, t->V, keys, form, buf_f32, (const long long*)buf_i64, halo);
     return 0;
+}
+
+extern "C" int gs2m_tsdf_replace(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, const float* buf_f32, const int64_t* buf_i64,
+                                 gs2m_stream stream) {
+    if (!t || n < 0 || n > (int64_t)t->V.max_blocks || (n > 0 && (!keys || !buf_f32))) {
+        gs2m_set_error("gs2m_tsdf_replace: bad argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    // a reset that leaves the voxel state of the first n slots alone (they are overwritten by the unpack below, which hands out
+    // exactly the slots [0, n) to n distinct in-range keys), then the unpack
+    if (zero_state(t, (hipStream_t)stream, false, n)) return 1;
+    if (n == 0) return 0;
+    return gs2m_tsdf_unpack(t, keys, n, form, buf_f32, buf_i64, 0, stream);
 }
 
 extern "C" int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream) {

@@ -13,7 +13,11 @@ void gs2m_launch_tsdf_clear_used(hipStream_t st, const TsdfVolume& V);
 void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, float* buf, long long* ibuf);
 void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, const float* buf,
                              const long long* ibuf, int halo);
+void gs2m_launch_tsdf_clear_from(hipStream_t st, const TsdfVolume& V, unsigned first);
 void gs2m_launch_tsdf_owned_keys(hipStream_t st, unsigned n, const TsdfVolume& V, int* keys);
+void gs2m_launch_tsdf_block_map(hipStream_t st, const TsdfVolume& V, const int* lo, const int* dim, unsigned char* cells, unsigned n_cells,
+                                unsigned flags, unsigned win_hash, int rank, unsigned frames_local, unsigned frames_base);
+void gs2m_launch_tsdf_map_keys(hipStream_t st, const int* lo, const int* dim, unsigned char* cells, unsigned n_cells, int* keys, unsigned max_keys);
 // marching cubes (tsdf_extract.h)
 struct McDevTables;
 size_t gs2m_mc_tables_bytes();

@@ -616,6 +616,28 @@ k_tsdf_clear_used(TsdfVolume V) {
     }
 }
 
+// gs2m_tsdf_replace: the slots [first, counters[0]) back to the clean state (the blocks about to be unpacked overwrite slots
+// [0, first) completely: clearing those as well -- what a reset does -- would write the reduced volume's bytes twice)
+GS2M_KERNEL void __launch_bounds__(256)
+k_tsdf_clear_from(TsdfVolume V, unsigned first) {
+    unsigned n = V.counters[0];
+    if (n > V.max_blocks) n = V.max_blocks;
+    const float4 z = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned slot = first + blockIdx.x; slot < n; slot += gridDim.x) {
+        float4* t4 = reinterpret_cast<float4*>(V.tsdf + (size_t)slot * GS2M_TSDF_VOX);
+        float4* w4 = reinterpret_cast<float4*>(V.weight + (size_t)slot * GS2M_TSDF_VOX);
+        for (int i = (int)threadIdx.x; i < GS2M_TSDF_VOX / 4; i += 256) {
+            t4[i] = z;
+            w4[i] = z;
+        }
+        if (V.has_color) {
+            float4* c4 = reinterpret_cast<float4*>(V.rgb + (size_t)slot * 3 * GS2M_TSDF_VOX);
+            for (int i = (int)threadIdx.x; i < 3 * GS2M_TSDF_VOX / 4; i += 256) c4[i] = z;
+        }
+        if (threadIdx.x == 0) V.halo[slot] = 0;
+    }
+}
+
 // ---- multi-GPU exchange -----------------------------------------------------------------------
 // Exchange forms (GS2M_XFORM_*, include/gs2mesh_amd.h):
 //   0 SUM_F32     one fp32 buffer [n][5][4096]: planes wsum = tsdf * weight, weight, sum r, sum g, sum b -- counts and colour
@@ -729,4 +751,100 @@ k_tsdf_owned_keys(TsdfVolume V, unsigned n, int* __restrict__ keys) {
     keys[3 * (size_t)s] = h ? sentinel : V.block_keys[3 * (size_t)s];
     keys[3 * (size_t)s + 1] = h ? sentinel : V.block_keys[3 * (size_t)s + 1];
     keys[3 * (size_t)s + 2] = h ? sentinel : V.block_keys[3 * (size_t)s + 2];
+}
+
+// ---- block-map key exchange (round 5) -----------------------------------------------------------
+// The union of the ranks' block sets is formed as a dense MAP over a window of block indices: every rank marks its own blocks,
+// ONE all_reduce merges the ranks, and the canonical key list is the marked cells in cell order -- identical on every rank, no
+// gather, no sort, no host pass over keys.  SURVEY 8e asks for a bitmap under a bitwise OR; RCCL (like NCCL) has no bitwise
+// reduction, so the map holds one BYTE per block and the collective is MAX over uint8 (32 KiB for a 32^3-block window, 256 KiB
+// for the default 64^3).  Window: lo[k] <= b[k] < lo[k] + dim[k];
+//   cell = ((bx - lo.x) * dim.y + (by - lo.y)) * dim.z + (bz - lo.z)     (ascending cell = ascending (x, y, z) = packed-key order)
+// The header travels behind the map in the same buffer (GS2M_TSDF_MAP_HEADER bytes + 8 per rank), arranged so that a bytewise MAX
+// reduces it: flags are 0 / 1 bytes; values that must agree are sent as the bytes of x and of ~x (byte + complement byte == 255
+// after the MAX <=> all ranks sent the same byte); every rank writes its frame counts into its OWN slot (the others send zeros).
+//   [0] a block outside the window (every rank then takes the gather path)     [1..4] overflow flags 1, 2, 4, 8 of V.counters[2]
+//   [5] replicated   [6] holds halo copies   [8..11] / [12..15] max_blocks / ~max_blocks   [16..19] / [20..23] window hash / ~hash
+//   [24..27] number of marked cells (written by k_tsdf_map_keys on the reduced buffer)
+//   [32 + 8 r .. +3] frames_local, [36 + 8 r .. +3] frames_base of rank r (little endian)
+#define GS2M_TSDF_MAP_HEADER 32
+GS2M_DEVICE void tsdf_put_u32(unsigned char* p, unsigned v) {
+    p[0] = (unsigned char)(v & 255u);
+    p[1] = (unsigned char)((v >> 8) & 255u);
+    p[2] = (unsigned char)((v >> 16) & 255u);
+    p[3] = (unsigned char)(v >> 24);
+}
+GS2M_KERNEL void __launch_bounds__(256)
+k_tsdf_block_map(TsdfVolume V, int lox, int loy, int loz, int dx, int dy, int dz, unsigned char* __restrict__ cells, unsigned n_cells,
+                 unsigned flags, unsigned win_hash, int rank, unsigned frames_local, unsigned frames_base) {
+    unsigned n = V.counters[0];
+    if (n > V.max_blocks) n = V.max_blocks;
+    unsigned char* hdr = cells + n_cells;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned ov = V.counters[2];
+        for (int b = 0; b < 4; ++b) hdr[1 + b] = (unsigned char)((ov >> b) & 1u);
+        hdr[5] = (unsigned char)(flags & 1u);
+        hdr[6] = (unsigned char)((flags >> 1) & 1u);
+        tsdf_put_u32(hdr + 8, V.max_blocks);
+        tsdf_put_u32(hdr + 12, ~V.max_blocks);
+        tsdf_put_u32(hdr + 16, win_hash);
+        tsdf_put_u32(hdr + 20, ~win_hash);
+        tsdf_put_u32(hdr + GS2M_TSDF_MAP_HEADER + 8 * rank, frames_local);
+        tsdf_put_u32(hdr + GS2M_TSDF_MAP_HEADER + 8 * rank + 4, frames_base);
+    }
+    for (unsigned s = blockIdx.x * 256u + threadIdx.x; s < n; s += gridDim.x * 256u) {
+        if (V.halo[s]) continue;     // a halo copy is another rank's block
+        const int bx = V.block_keys[3 * (size_t)s] - lox, by = V.block_keys[3 * (size_t)s + 1] - loy, bz = V.block_keys[3 * (size_t)s + 2] - loz;
+        if (bx < 0 || by < 0 || bz < 0 || bx >= dx || by >= dy || bz >= dz) {
+            hdr[0] = 1;
+            continue;
+        }
+        cells[((size_t)bx * (unsigned)dy + (unsigned)by) * (unsigned)dz + (unsigned)bz] = 1;
+    }
+}
+
+// Marked cells of the (reduced) map -> keys [n][3] in cell order; header bytes [24..27] = n.  One 1024-thread workgroup: thread t
+// owns the consecutive cells [t * per, (t + 1) * per), per a multiple of 16 (16-byte loads): count, workgroup exclusive scan,
+// emit.  Keys beyond max_keys are counted, not written (the caller compares n with its buffer).
+GS2M_KERNEL void __launch_bounds__(1024)
+k_tsdf_map_keys(int lox, int loy, int loz, int dy, int dz, unsigned char* __restrict__ cells, unsigned n_cells, int* __restrict__ keys,
+                unsigned max_keys) {
+    __shared__ unsigned wave_sum[16];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned per = ((n_cells + 1023u) / 1024u + 15u) & ~15u;
+    const unsigned c0 = (unsigned)tid * per < n_cells ? (unsigned)tid * per : n_cells;
+    const unsigned c1 = c0 + per < n_cells ? c0 + per : n_cells;
+    unsigned cnt = 0;
+    for (unsigned c = c0; c < c1; c += 16u) {
+        if (c + 16u <= c1) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cells + c);      // the buffer is 16-byte aligned, c0 a multiple of 16
+            // cells are 0 / 1 bytes: the byte sum of a word = its number of marked cells
+            const unsigned t = (v.x & 0x01010101u) + (v.y & 0x01010101u) + (v.z & 0x01010101u) + (v.w & 0x01010101u);
+            cnt += (t & 255u) + ((t >> 8) & 255u) + ((t >> 16) & 255u) + (t >> 24);
+        } else {
+            for (unsigned k = c; k < c1; ++k) cnt += cells[k] ? 1u : 0u;
+        }
+    }
+    unsigned inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = gs2m_shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int k = 0; k < wave; ++k) base += wave_sum[k];
+    unsigned pos = base + inc - cnt;
+    if (tid == 1023) tsdf_put_u32(cells + n_cells + 24, base + inc);
+    if (cnt == 0u) return;
+    for (unsigned c = c0; c < c1; ++c) {
+        if (!cells[c]) continue;
+        if (pos < max_keys) {
+            const unsigned z = c % (unsigned)dz, xy = c / (unsigned)dz;
+            keys[3 * (size_t)pos] = (int)(xy / (unsigned)dy) + lox;
+            keys[3 * (size_t)pos + 1] = (int)(xy % (unsigned)dy) + loy;
+            keys[3 * (size_t)pos + 2] = (int)z + loz;
+        }
+        ++pos;
+    }
 }

@@ -38,8 +38,21 @@ void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, co
     else if (form == GS2M_XF_RAW_F32) GS2M_LAUNCH(k_tsdf_unpack<GS2M_XF_RAW_F32>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf, halo);
     else GS2M_LAUNCH(k_tsdf_unpack<GS2M_XF_SUM_F32>, dim3(n), dim3(256), 0, st, V, keys, buf, ibuf, halo);
 }
+void gs2m_launch_tsdf_clear_from(hipStream_t st, const TsdfVolume& V, unsigned first) {
+    GS2M_LAUNCH(k_tsdf_clear_from, dim3(1024), dim3(256), 0, st, V, first);
+}
 void gs2m_launch_tsdf_owned_keys(hipStream_t st, unsigned n, const TsdfVolume& V, int* keys) {
     GS2M_LAUNCH(k_tsdf_owned_keys, dim3((n + 255u) / 256u), dim3(256), 0, st, V, n, keys);
+}
+
+void gs2m_launch_tsdf_block_map(hipStream_t st, const TsdfVolume& V, const int* lo, const int* dim, unsigned char* cells, unsigned n_cells,
+                                unsigned flags, unsigned win_hash, int rank, unsigned frames_local, unsigned frames_base) {
+    const unsigned wg = (V.max_blocks + 255u) / 256u;
+    GS2M_LAUNCH(k_tsdf_block_map, dim3(wg < 256u ? (wg ? wg : 1u) : 256u), dim3(256), 0, st, V, lo[0], lo[1], lo[2], dim[0], dim[1], dim[2], cells,
+                n_cells, flags, win_hash, rank, frames_local, frames_base);
+}
+void gs2m_launch_tsdf_map_keys(hipStream_t st, const int* lo, const int* dim, unsigned char* cells, unsigned n_cells, int* keys, unsigned max_keys) {
+    GS2M_LAUNCH(k_tsdf_map_keys, dim3(1), dim3(1024), 0, st, lo[0], lo[1], lo[2], dim[1], dim[2], cells, n_cells, keys, max_keys);
 }
 
 size_t gs2m_mc_tables_bytes() { return sizeof(McDevTables); }

@@ -98,6 +98,10 @@ class ScalableTSDFVolume:
         self.frames_local = 0
         self.replicated = False      # the state is the all-reduced volume (every rank holds it: summing it again would count it R times)
         self.has_halo = False        # holds neighbour-only copies of other ranks' blocks (exchange_halo): their keys read as the sentinel
+        # window of block indices of the block-map key exchange (gs2mesh_amd.parallel): (lo[3], dim[3]); the default covers a
+        # 1024^3-voxel volume around the origin (64^3 blocks = a 256 KiB byte map).  A block outside it sends the exchange through
+        # the gather path (same result); `set_exchange_window` for scenes elsewhere.
+        self.exchange_window = ((-32, -32, -32), (64, 64, 64))
         self._xbuf = {}              # persistent, grow-only exchange buffers (gs2mesh_amd.parallel)
 
     def close(self):
@@ -113,6 +117,9 @@ class ScalableTSDFVolume:
 
     def reset(self, stream=None):
         _lib.check(self._lib.gs2m_tsdf_reset(self._h, stream or C.c_void_p(0)), self._lib)
+        self._reset_bookkeeping()
+
+    def _reset_bookkeeping(self):
         self.frames_base = self.frames_local = 0
         self.replicated = False
         self.has_halo = False
@@ -280,6 +287,36 @@ class ScalableTSDFVolume:
         """where the exchange buffers of this volume live: the GPU, or the host for the emulator build (CPU tests)"""
         return _lib.MEMORY.buffer_device(self.device)
 
+    def set_exchange_window(self, lo, dim):
+        """Window of BLOCK indices (units of 16 voxels) the multi-GPU key exchange covers with its block map; every rank must set
+        the same one."""
+        lo, dim = tuple(int(x) for x in lo), tuple(int(x) for x in dim)
+        if len(lo) != 3 or len(dim) != 3 or min(dim) <= 0 or dim[0] * dim[1] * dim[2] > (1 << 30):
+            raise ValueError(f"bad exchange window {lo} {dim}")
+        self.exchange_window = (lo, dim)
+
+    def map_bytes(self, world):
+        dim = (C.c_int32 * 3)(*self.exchange_window[1])
+        return int(self._lib.gs2m_tsdf_map_bytes(dim, int(world)))
+
+    def block_map(self, cells, rank, world, flags, stream=None):
+        """``gs2m_tsdf_block_map``: this rank's blocks + header into ``cells`` (device uint8 [map_bytes(world)]); async."""
+        lo = (C.c_int32 * 3)(*self.exchange_window[0])
+        dim = (C.c_int32 * 3)(*self.exchange_window[1])
+        _lib.check(self._lib.gs2m_tsdf_block_map(self._h, lo, dim, int(rank), int(world), int(self.frames_local),
+                                                 int(self.frames_base), int(flags), _ptr(cells), _stream_of(cells, stream)),
+                   self._lib)
+
+    def map_keys(self, cells, world, keys_out, stream=None):
+        """``gs2m_tsdf_map_keys`` on the reduced buffer: canonical keys into ``keys_out`` [max,3] + the header bytes (numpy
+        uint8 [32 + 8 * world]).  Synchronises (the one host read of the key exchange)."""
+        lo = (C.c_int32 * 3)(*self.exchange_window[0])
+        dim = (C.c_int32 * 3)(*self.exchange_window[1])
+        hdr = (C.c_uint8 * (_lib.TSDF_MAP_HEADER_BYTES + 8 * int(world)))()
+        _lib.check(self._lib.gs2m_tsdf_map_keys(self._h, lo, dim, int(world), _ptr(cells), _ptr(keys_out), int(keys_out.shape[0]),
+                                                hdr, _stream_of(cells, stream)), self._lib)
+        return np.frombuffer(hdr, dtype=np.uint8).copy()
+
     def block_keys(self, like=None, stream=None, raise_on_overflow=True, out=None, n=None):
         """Keys of the allocated blocks, slot order (halo copies: sentinel key).  ``out`` / ``n``: write the first n rows of a
         caller buffer (n from a status() the caller already paid for: no synchronisation here)."""
@@ -309,6 +346,15 @@ class ScalableTSDFVolume:
             self.has_halo = self.has_halo or n > 0
         else:
             self._inherit(frames)
+
+    def replace(self, keys, form, buf_f32, buf_i64=None, stream=None, frames=None):
+        """``gs2m_tsdf_replace``: reset + unpack of the DISTINCT blocks ``keys`` in one call (the reduced blocks' bytes are
+        written once, not cleared first)."""
+        n = int(keys.shape[0])
+        _lib.check(self._lib.gs2m_tsdf_replace(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
+                                               _stream_of(keys, stream)), self._lib)
+        self._reset_bookkeeping()
+        self._inherit(frames)
 
     def _inherit(self, frames):
         bound = int(frames) if frames is not None else _lib.XFORM_PACKED_MAX_FRAMES + 1

@@ -37,6 +37,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+_MAP_HEADER = 32                 # = _lib.TSDF_MAP_HEADER_BYTES (include/gs2mesh_amd.h)
 _SENTINEL = (1 << 20) - 1          # block index nobody owns (outside the +-2^20 key range of the volume)
 _OVERFLOW_TEXT = ((1, "block pool exhausted (raise max_blocks)"), (2, "hash table full"),
                   (4, "block index out of the +-2^20 range"),
@@ -93,8 +94,9 @@ def _as_tensor(keys):
     return keys if torch.is_tensor(keys) else torch.from_numpy(np.ascontiguousarray(keys))
 
 
-def canonical_keys(volume, group=None, always_collective: bool = False, marks=None):
-    """Union of the block keys of all ranks in canonical order, on the local device, + the OR of the ranks'
+def _canonical_keys_gather(volume, group=None, always_collective: bool = False, marks=None):
+    """(Fallback of `canonical_keys` for blocks outside the bitmap window; the round-4 exchange.)
+    Union of the block keys of all ranks in canonical order, on the local device, + the OR of the ranks'
     overflow flags + an upper bound of every voxel weight of the SUM over the ranks + whether any rank holds an already
     all-reduced (replicated) state.  One fixed-size all_gather (persistent buffers); one host read (of the gathered header
     rows).  Halo copies held by a volume are not its blocks (sentinel keys).
@@ -142,8 +144,61 @@ def canonical_keys(volume, group=None, always_collective: bool = False, marks=No
     return _lex_unique(body), ov_any, 1, frames_total, replicated
 
 
+
+def canonical_keys(volume, group=None, always_collective: bool = False, marks=None, keys_via: str = "map"):
+    """Union of the block keys of all ranks in canonical order (ascending (x, y, z)), on the local device, + the OR of the ranks'
+    overflow flags + the number of collectives used + an upper bound of every voxel weight of the SUM over the ranks + whether
+    any rank holds an already all-reduced (replicated) state.
+
+    Block-map exchange: ``gs2m_tsdf_block_map`` marks this rank's blocks in a dense map over the
+    volume's exchange window, one BYTE per block (RCCL has no bitwise reduction: 256 KiB for the default 64^3-block window), with
+    the header bytes behind it; ONE ``all_reduce(MAX)`` over uint8 merges the ranks; ``gs2m_tsdf_map_keys`` turns the marked
+    cells into the key list in cell order -- identical on every rank by construction: no gather of key lists, no sort / unique,
+    no host pass over keys; one host read (the 32 + 8 R header bytes with the key count).  A block outside the window on ANY
+    rank shows in the reduced header: every rank then takes the gather path (`_canonical_keys_gather`) together.
+    Weight bound: a rank's state = a part it inherited (`frames_base`: a reduce-scatter leaves the ranks with DISJOINT parts of
+    one reduced volume, so across ranks the inherited bounds do not add up -- their maximum holds) + the frames it integrated
+    since (`frames_local`: these do add up)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    collective = world > 1 or (always_collective and dist.is_initialized())
+    if not collective or keys_via == "gather":
+        return _canonical_keys_gather(volume, group, always_collective, marks)
+    K = int(volume.max_blocks)
+    dev = volume.exchange_device()
+    nb = volume.map_bytes(world)
+    cells = volume.exchange_buffer("block_map", (nb,), torch.uint8, dev)
+    flags = int(bool(volume.replicated)) | (2 if volume.has_halo else 0)
+    volume.block_map(cells, rank, world, flags)
+    _mark(marks, "keys: local block map")
+    dist.all_reduce(cells, op=dist.ReduceOp.MAX, group=group)
+    _mark(marks, "keys: all_reduce(MAX, u8)")
+    n_cells = nb - _MAP_HEADER - 8 * world
+    kbuf = volume.exchange_buffer("keys_union", (min(world * K, n_cells), 3), torch.int32, dev)
+    head = volume.map_keys(cells, world, kbuf).astype(np.int64)
+    _mark(marks, "keys: map -> keys + header read")
+
+    def u32(off):
+        return int(head[off]) | int(head[off + 1]) << 8 | int(head[off + 2]) << 16 | int(head[off + 3]) << 24
+
+    if any(int(head[8 + i]) + int(head[12 + i]) != 255 for i in range(4)):
+        raise RuntimeError("reduce_volume: every rank must create its volume with the same max_blocks")
+    if any(int(head[16 + i]) + int(head[20 + i]) != 255 for i in range(4)):
+        raise RuntimeError("reduce_volume: every rank must use the same exchange window (set_exchange_window)")
+    if head[0]:
+        # some rank holds a block outside the window: everybody saw the same byte, everybody gathers
+        keys, ov_any, n_coll, frames_total, replicated = _canonical_keys_gather(volume, group, always_collective, marks)
+        return keys, ov_any, n_coll + 1, frames_total, replicated
+    frames_total = sum(u32(_MAP_HEADER + 8 * r) for r in range(world)) + max(u32(_MAP_HEADER + 8 * r + 4) for r in range(world))
+    n = u32(24)
+    if n > kbuf.shape[0]:
+        raise RuntimeError(f"reduce_volume: the union holds {n} blocks, more than the ranks' pools together")
+    ov_any = sum((1 << b) for b in range(4) if head[1 + b])
+    return kbuf[:n], ov_any, 1, frames_total, bool(head[5]) and world > 1
+
+
 def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_collective: bool = False,
-                  payload: str = "auto", algo: str = "rccl", marks=None):
+                  payload: str = "auto", algo: str = "rccl", marks=None, keys_via: str = "map"):
     """Sum-reduce the TSDF accumulators of all ranks into `volume`.
 
     mode "reduce_scatter": rank r ends with blocks [lo_r, hi_r) of the canonical list only (use `exchange_halo`
@@ -161,8 +216,10 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
     if mode not in ("reduce_scatter", "allreduce") or payload not in ("auto", "packed", "f32") or algo not in ("rccl", "direct"):
         raise ValueError((mode, payload, algo))
     _mark(marks, "start")
-    keys, ov_any, n_coll, frames_total, replicated = canonical_keys(volume, group, always_collective, marks)
-    _mark(marks, "keys: union (pack, unique, unpack)")
+    if keys_via not in ("map", "gather"):
+        raise ValueError(keys_via)
+    keys, ov_any, n_coll, frames_total, replicated = canonical_keys(volume, group, always_collective, marks, keys_via)
+    _mark(marks, "keys: union")
     if replicated:
         # identical on every rank (it travelled in the gathered header): all of them raise
         raise RuntimeError("reduce_volume: a rank holds an all-reduced (replicated) volume -- summing it again would count its "
@@ -229,16 +286,27 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
     _mark(marks, "collectives")
     if packed:
         # device-side check of the packed form (k_tsdf_pack): a local weight / colour sum that did not fit its field means the
-        # frame bound was wrong (state injected through the C API).  Checked AFTER the collectives, so that a rank that
-        # raises leaves nobody waiting in one.
+        # frame bound was wrong (state injected through the C API).  The flag is LOCAL to the rank that packed the voxel, the
+        # corrupted (field-carry) sums reach every rank: the verdict is made global with one 4-byte MAX all_reduce AFTER the
+        # payload collectives, and every rank raises together -- none goes on to unpack, none waits in a later collective
+        # (exchange_halo) for a rank that left.
         _, _, ov_pack = volume.status(raise_on_overflow=False)
-        if ov_pack & 8:
-            raise RuntimeError("reduce_volume: " + _OVERFLOW_TEXT[3][1] + " -- the reduced buffers are invalid; use payload='f32'")
+        bad = 1 if (ov_pack & 8) else 0
+        if collective and world > 1:
+            flag = torch.tensor([bad], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            n_coll += 1
+            bad = int(flag.item())
+        if bad:
+            raise RuntimeError("reduce_volume: " + _OVERFLOW_TEXT[3][1] + " (on at least one rank) -- the reduced buffers are "
+                               "invalid; use payload='f32'")
     # replace the local state by the reduced blocks (reset only clears the slots in use)
-    volume.reset()
     cnt = max(0, hi - lo)
     if cnt:
-        volume.unpack(kpad[:cnt].contiguous(), form, fbuf[:cnt], ibuf[:cnt] if packed else None, frames=frames_total)
+        # reset + unpack in one call: the slots the reduced blocks land in are not cleared first (C4: 1.2 GB of writes less)
+        volume.replace(kpad[:cnt].contiguous(), form, fbuf[:cnt], ibuf[:cnt] if packed else None, frames=frames_total)
+    else:
+        volume.reset()
     volume.status()
     _mark(marks, "reset + unpack + status")
     volume.frames_base, volume.frames_local = frames_total, 0     # every weight of the reduced state is bounded by the total

@@ -362,6 +362,33 @@ int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf,
 int gs2m_tsdf_unpack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, const float* buf, int halo,
                          gs2m_stream stream);
 
+/*
+ * Block-map key exchange (multi-GPU): the union of the ranks' block sets as a dense map over a WINDOW of
+ * block indices lo[k] <= b[k] < lo[k] + dim[k] (host int32[3] each; the same on every rank).  SURVEY asks for a bitmap under a
+ * bitwise OR; RCCL has no bitwise reduction, so the map holds one BYTE per block and the caller's collective is MAX over uint8.
+ *   gs2m_tsdf_map_bytes    bytes of the exchange buffer: the cells (dim0 * dim1 * dim2 rounded up to 16)
+ *                          + GS2M_TSDF_MAP_HEADER_BYTES + 8 * world header bytes (-1: bad window).
+ *   gs2m_tsdf_block_map    clears `cells` (device, 16-byte aligned) and marks this rank's blocks (halo copies are not its
+ *                          blocks); the header behind the cells carries, in a form a bytewise MAX reduces: [0] a block outside the
+ *                          window, [1..4] the volume's overflow flags 1 / 2 / 4 / 8, [5] / [6] bits 0 / 1 of `flags` (caller-defined),
+ *                          [8..11] / [12..15] the bytes of max_blocks and of its complement (byte + complement byte == 255 after
+ *                          the MAX <=> the ranks agree), [16..23] the same for a hash of the window, [32 + 8 r ..] frames_local and
+ *                          frames_base of rank r as little-endian u32 (zeros in the other ranks' slots).  Asynchronous, no host
+ *                          read.  The caller all-reduces the buffer with MAX.
+ *   gs2m_tsdf_map_keys     on the reduced buffer: marked cells -> keys[n][3] (device) in cell order = ascending (x, y, z), the
+ *                          canonical order of the exchange, identical on every rank; header bytes [24..27] = n (keys beyond
+ *                          max_keys are counted, not written); copies the header to header_host[GS2M_TSDF_MAP_HEADER_BYTES + 8 * world]
+ *                          and synchronises -- the one host read of the key exchange.
+ * Replaces round 4's "gather every rank's key list, sort, unique" (gs2mesh_amd/parallel.py keeps it as the fallback for blocks
+ * outside the window).
+ */
+#define GS2M_TSDF_MAP_HEADER_BYTES 32
+int64_t gs2m_tsdf_map_bytes(const int32_t* dim, int world);
+int gs2m_tsdf_block_map(gs2m_tsdf* t, const int32_t* lo, const int32_t* dim, int rank, int world, int64_t frames_local,
+                        int64_t frames_base, int flags, uint8_t* cells, gs2m_stream stream);
+int gs2m_tsdf_map_keys(gs2m_tsdf* t, const int32_t* lo, const int32_t* dim, int world, uint8_t* cells, int32_t* keys,
+                       int64_t max_keys, uint8_t* header_host, gs2m_stream stream);
+
 /* The same with a choice of exchange form (pack_sum / unpack_sum = form GS2M_XFORM_SUM_F32):
  *   GS2M_XFORM_SUM_F32     buf_f32[n,5,4096] in SUM form as above (one fp32 SUM collective), buf_i64 unused;
  *   GS2M_XFORM_RAW_F32     buf_f32[n,5,4096] with the planes verbatim {tsdf, weight, sum r, sum g, sum b}: for copies of blocks
@@ -377,6 +404,11 @@ int gs2m_tsdf_pack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, float
                    gs2m_stream stream);
 int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, const float* buf_f32,
                      const int64_t* buf_i64, int halo, gs2m_stream stream);
+/* gs2m_tsdf_reset + gs2m_tsdf_unpack(halo = 0) of n DISTINCT in-range keys in one call, without writing the reduced blocks' bytes
+ * twice: the reset leaves the voxel state of the first n slots alone (the unpack overwrites exactly those), and clears the rest
+ * of the slots that were in use.  The tail of the multi-GPU reduction (gs2mesh_amd.parallel.reduce_volume). */
+int gs2m_tsdf_replace(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, const float* buf_f32, const int64_t* buf_i64,
+                      gs2m_stream stream);
 
 /*
  * Replaces volume.extract_triangle_mesh() (tsdf_utils.py:108; Open3D ScalableTSDFVolume::

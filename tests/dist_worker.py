@@ -36,6 +36,43 @@ def main():
     intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
     for d, c, E in frs[lo:hi]:
         vol.integrate(RGBDImage(c, d), intr, E)
+    opts = set(filter(None, os.environ.get("GS2M_TEST_OPTS", "").split(",")))
+    if "window=small" in opts:
+        # a 2^3-block window: most of the scene's blocks lie outside it -> every rank takes the gather path together
+        vol.set_exchange_window((-1, -1, -1), (2, 2, 2))
+    if "window=mismatch" in opts and rank == 1:
+        vol.set_exchange_window((-31, -32, -32), (64, 64, 64))      # same size (a collective needs that), other origin
+    keys_via = "gather" if "keys=gather" in opts else "map"
+    if "badpack" in opts:
+        # state injected through the C API with a LYING frame bound on rank 0 only: one voxel weight of 2000 does not fit the
+        # packed form.  Only rank 0's pack kernel sees it; the verdict must reach every rank (the others used to
+        # unpack the corrupted sums and walk into the next collective alone).
+        import torch
+        from gs2mesh_amd import _lib
+        if rank == 0:
+            k0 = torch.tensor([[0, 0, 0]], dtype=torch.int32)
+            b0 = torch.zeros((1, 5, 4096), dtype=torch.float32)
+            b0[0, 1, 7] = 2000.0
+            vol.unpack(k0, _lib.XFORM_RAW_F32, b0, frames=1)
+        try:
+            reduce_volume(vol, mode="reduce_scatter", payload="packed", algo=algo)
+            raise SystemExit(f"rank {rank}: reduce_volume accepted a voxel that does not fit the packed form")
+        except RuntimeError as e:
+            assert "packed exchange form" in str(e), e
+        dist.barrier()          # every rank got here: nobody is stuck in a collective
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), refused=1)
+        dist.destroy_process_group()
+        return
+    if "window=mismatch" in opts:
+        try:
+            reduce_volume(vol, mode="reduce_scatter", payload=payload, algo=algo)
+            raise SystemExit("mismatching exchange windows were accepted")
+        except RuntimeError as e:
+            assert "exchange window" in str(e), e
+        dist.barrier()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), refused=1)
+        dist.destroy_process_group()
+        return
     again = mode.endswith("+again")
     mode = mode.replace("+again", "")
     twice = mode.endswith("+twice")
@@ -54,7 +91,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    info = reduce_volume(vol, mode=mode.replace("+mesh", ""), payload=payload, algo=algo)
+    info = reduce_volume(vol, mode=mode.replace("+mesh", ""), payload=payload, algo=algo, keys_via=keys_via)
+    if "window=small" in opts:
+        assert info["collectives"] >= 3          # bitmap (says: outside) + gather + payload
     assert info["payload"] == ("f32" if payload == "f32" or total > 1023 else "packed") and info["frames_total"] == total
     assert vol.frames_integrated == total
     # a second reduction must be able to re-use the persistent exchange buffers (same objects, no growth)
@@ -67,7 +106,8 @@ def main():
         m = vol.extract_triangle_mesh()
         extra["tri_xyz"] = m.vertices[m.triangles] if len(m.triangles) else np.zeros((0, 3, 3))
         extra["owned_keys"] = owned_keys
-        assert info["collectives"] == (2 if info["payload"] == "f32" else 3)
+        # bitmap all_reduce + the payload collective(s) + (packed form) the 4-byte verdict on the pack overflow flag
+        assert info["collectives"] == (2 if info["payload"] == "f32" else 4) + (1 if "window=small" in opts else 0)
         assert all(vol._xbuf[k].data_ptr() == p for k, p in ids.items())
     if twice:
         try:

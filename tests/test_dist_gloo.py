@@ -32,13 +32,13 @@ def test_shard_range_is_a_balanced_contiguous_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def run_world(tmp_path, world, mode):
+def run_world(tmp_path, world, mode, opts=""):
     for attempt in range(3):   # the rendezvous port is picked, released and re-bound by rank 0: retry if it was taken
         port = free_port()
         procs = []
         for rank in range(world):
             env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                       MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+                       MASTER_PORT=str(port), OMP_NUM_THREADS="2", GS2M_TEST_OPTS=opts)
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path), mode],
                                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
@@ -104,6 +104,42 @@ def test_sharded_fusion_equals_single_process(tmp_path, world, mode):
         np.testing.assert_array_equal(z["rgb"], cf[idx])
         np.testing.assert_allclose(z["tsdf"], tf[idx], atol=1e-5, rtol=0)
     assert seen == set(ref)
+
+
+@pytest.mark.parametrize("opts", ["window=small", "keys=gather"])
+def test_key_exchange_paths_agree(tmp_path, opts):
+    """The block-bitmap exchange (default), its fallback when a block lies outside the window (a 2^3-block window: every rank
+    sees the `outside` word of the reduced header and gathers), and the gather path asked for directly: the same canonical
+    union, the same reduced volume."""
+    world = 3
+    run_world(tmp_path, world, "reduce_scatter:packed:direct", opts)
+    kf, tf, wf, cf = single_process_reference()
+    ref = {tuple(k): i for i, k in enumerate(kf.tolist())}
+    seen = set()
+    for rank in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{rank}.npz"))
+        assert int(z["union"]) == len(ref)
+        keys = list(map(tuple, z["keys"].tolist()))
+        assert not (set(keys) & seen)
+        seen |= set(keys)
+        idx = np.array([ref[k] for k in keys], dtype=int)
+        np.testing.assert_array_equal(z["weight"], wf[idx])
+        np.testing.assert_array_equal(z["rgb"], cf[idx])
+    assert seen == set(ref)
+
+
+def test_a_pack_overflow_on_one_rank_raises_on_every_rank(tmp_path):
+    """the packed-form overflow flag is set by the LOCAL pack kernel; the verdict is all-reduced, every rank
+    raises, and all of them reach the barrier behind it."""
+    run_world(tmp_path, 3, "reduce_scatter:packed", "badpack")
+    for rank in range(3):
+        assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
+
+
+def test_mismatching_exchange_windows_are_refused_on_every_rank(tmp_path):
+    run_world(tmp_path, 2, "reduce_scatter", "window=mismatch")
+    for rank in range(2):
+        assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
 
 
 def test_eight_ranks_reduce_scatter_direct_and_owner_side_mesh(tmp_path):

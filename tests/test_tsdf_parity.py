@@ -175,6 +175,92 @@ def test_pack_unpack_round_trip_and_merge(backend):
     np.testing.assert_allclose(tm[order], tf, atol=1e-6)
 
 
+@pytest.mark.parametrize("lo,dim", [((-32, -32, -32), (64, 64, 64)), ((-5, -4, -3), (11, 9, 7)), ((0, -2, -1), (3, 5, 4))])
+def test_block_map_key_exchange_primitives(backend, lo, dim):
+    """``gs2m_tsdf_block_map`` / ``gs2m_tsdf_map_keys`` (the key exchange of gs2mesh_amd.parallel): the bytewise MAX of two
+    ranks' maps gives the sorted set union of their in-window keys in canonical order, the header carries the flags, the frame
+    counts per rank and the count; a block outside the window raises the `outside` byte; a too-small key buffer is reported
+    through the count, not overrun.  Windows whose cell count is not a multiple of 16 included."""
+    be = backend
+    frs, K = frames(4, 128, 96, 140.0)
+    voxel, trunc = 2.0 / 96, 0.1
+    a, _ = run_both(be, frs[:2], K, voxel, trunc)
+    b, _ = run_both(be, frs[2:], K, voxel, trunc)
+    world = 2
+    maps = []
+    for r, v in enumerate((a, b)):
+        v.set_exchange_window(lo, dim)
+        nb = v.map_bytes(world)
+        cells = be.dev(np.full(nb, 7, np.uint8))        # garbage in: block_map clears the buffer itself
+        v.frames_base = 3 * r
+        v.block_map(cells, r, world, flags=2 if r else 1)
+        be.sync()
+        maps.append(be.host(cells).copy())
+    n_cells = (dim[0] * dim[1] * dim[2] + 15) // 16 * 16
+    assert maps[0].shape[0] == n_cells + 32 + 8 * world
+    red = np.maximum(maps[0], maps[1])                   # what all_reduce(MAX) over uint8 computes
+    ka, kb = be.host(a.block_keys()), be.host(b.block_keys())
+    allk = np.unique(np.concatenate([ka, kb]), axis=0).astype(np.int64)
+    lo_a, dim_a = np.array(lo), np.array(dim)
+    inside = np.all((allk >= lo_a) & (allk < lo_a + dim_a), axis=1)
+    want = allk[inside].astype(np.int32)                 # np.unique rows: lexicographic (x, y, z) order
+    kbuf = be.dev(np.zeros((max(len(want), 1), 3), np.int32))
+    head = a.map_keys(be.dev(red), world, kbuf)
+    n = int(head[24]) | int(head[25]) << 8 | int(head[26]) << 16 | int(head[27]) << 24
+    assert n == len(want)
+    assert np.array_equal(be.host(kbuf)[:n], want)
+    assert int(head[0]) == int(not inside.all())         # a block outside the window
+    assert head[1:5].tolist() == [0, 0, 0, 0] and head[5] == 1 and head[6] == 1      # flags: rank 0 sent bit 0, rank 1 bit 1
+    assert all(int(head[8 + i]) + int(head[12 + i]) == 255 for i in range(4))      # max_blocks agrees
+    assert all(int(head[16 + i]) + int(head[20 + i]) == 255 for i in range(4))     # the window agrees
+    u32 = lambda o: int(head[o]) | int(head[o + 1]) << 8 | int(head[o + 2]) << 16 | int(head[o + 3]) << 24
+    assert [u32(32), u32(36), u32(40), u32(44)] == [2, 0, 2, 3]                   # frames_local / frames_base per rank
+    if len(want) > 3:
+        small = be.dev(np.full((3, 3), -99, np.int32))
+        head2 = a.map_keys(be.dev(red), world, small)
+        assert (int(head2[24]) | int(head2[25]) << 8) == len(want) & 0xffff and np.array_equal(be.host(small), want[:3])
+    # ranks that disagree on the window: the hash bytes no longer complement each other
+    b.set_exchange_window((lo[0] + 1, lo[1], lo[2]), dim)
+    cells = be.dev(np.zeros(b.map_bytes(world), np.uint8))
+    b.block_map(cells, 1, world, flags=0)
+    be.sync()
+    red2 = np.maximum(maps[0], be.host(cells))
+    assert any(int(red2[n_cells + 16 + i]) + int(red2[n_cells + 20 + i]) != 255 for i in range(4))
+
+
+def test_replace_equals_reset_plus_unpack_and_leaves_clean_slots(backend):
+    """``gs2m_tsdf_replace`` (the tail of reduce_volume): same state as reset + unpack, and the slots it did not refill are
+    clean -- frames integrated afterwards allocate them and must give the volume a fresh handle gives."""
+    from gs2mesh_amd import _lib
+    be = backend
+    frs, K = frames(6, 128, 96, 140.0)
+    voxel, trunc = 2.0 / 96, 0.1
+    W, H, fx, fy, cx, cy = K
+    intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
+    src, _ = run_both(be, frs[:4], K, voxel, trunc)
+    keys = np.unique(be.host(src.block_keys()), axis=0).astype(np.int32)
+    half = np.ascontiguousarray(keys[: len(keys) // 2])
+    buf = be.dev(np.zeros((len(half), 5, 4096), np.float32))
+    src.pack(be.dev(half), _lib.XFORM_RAW_F32, buf)
+    be.sync()
+    vols = []
+    for how in ("replace", "reset+unpack"):
+        v, _ = run_both(be, frs[:4], K, voxel, trunc)            # a volume with MORE blocks in use than it is about to keep
+        if how == "replace":
+            v.replace(be.dev(half), _lib.XFORM_RAW_F32, buf, frames=4)
+        else:
+            v.reset()
+            v.unpack(be.dev(half), _lib.XFORM_RAW_F32, buf, frames=4)
+        for d, c, E in frs[4:]:
+            v.integrate(RGBDImage(be.dev(c), be.dev(d)), intr, E)
+        vols.append(v.download())
+    (k0, t0, w0, c0), (k1, t1, w1, c1) = vols
+    i1 = {tuple(k): i for i, k in enumerate(k1.tolist())}
+    assert set(map(tuple, k0.tolist())) == set(i1) and len(k0) > len(half)
+    o = np.array([i1[tuple(k)] for k in k0.tolist()])
+    assert np.array_equal(t0, t1[o]) and np.array_equal(w0, w1[o]) and np.array_equal(c0, c1[o])
+
+
 def test_packed_exchange_form_flags_values_that_do_not_fit_its_fields(backend):
     """XFORM_SUM_PACKED holds w in 10 bits and the colour sums in 18: state injected through unpack_sum with larger
     weights (a C-API user, or a volume whose frame bound was lost) must not carry silently between the fields.

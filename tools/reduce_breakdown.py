@@ -68,6 +68,7 @@ def install_legacy_keys():
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--keys-via", default="map", choices=["map", "gather"], help="key exchange: block map + all_reduce(MAX) (round 5) or gathered key lists (round 4)")
     ap.add_argument("--legacy-keys", action="store_true")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--frames", type=int, default=20)
@@ -111,22 +112,22 @@ def main():
     if args.legacy_keys:
         install_legacy_keys()
     fill()
-    reduce_volume(vol, always_collective=True, payload=args.payload, algo=args.algo)      # communicator + buffers
+    reduce_volume(vol, always_collective=True, payload=args.payload, algo=args.algo, keys_via=args.keys_via)      # communicator + buffers
     phases, plain = {}, []
     info = None
     for it in range(args.repeats):
         fill()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        info = reduce_volume(vol, always_collective=True, payload=args.payload, algo=args.algo)
+        info = reduce_volume(vol, always_collective=True, payload=args.payload, algo=args.algo, keys_via=args.keys_via)
         torch.cuda.synchronize()
         plain.append(time.perf_counter() - t0)
         fill()
         marks = []
-        reduce_volume(vol, always_collective=True, payload=args.payload, algo=args.algo, marks=marks)
+        reduce_volume(vol, always_collective=True, payload=args.payload, algo=args.algo, marks=marks, keys_via=args.keys_via)
         for (_, ta), (name, tb) in zip(marks[:-1], marks[1:]):
             phases.setdefault(name, []).append(tb - ta)
-    out = dict(keys="legacy (round 3)" if args.legacy_keys else "current", config=args.config, frames=args.frames, union_blocks=int(info["n_blocks_union"]), bytes_per_rank=int(info["bytes_per_rank"]),
+    out = dict(keys="legacy (round 3)" if args.legacy_keys else ("block map (round 5)" if args.keys_via == "map" else "gathered lists (round 4)"), config=args.config, frames=args.frames, union_blocks=int(info["n_blocks_union"]), bytes_per_rank=int(info["bytes_per_rank"]),
                payload=info["payload"], algo=info["algo"], collectives=int(info["collectives"]),
                plain_ms=round(1e3 * statistics.median(plain), 4),
                phases_ms={k: round(1e3 * statistics.median(v), 4) for k, v in phases.items()},
