@@ -466,7 +466,8 @@ def main():
                 scale = upl / max(1, int(ent.get("pairs_per_launch", 1)))
                 traffic = int(ent["hbm_bytes_per_launch"] * scale)
                 traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 2')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                  f"passes of tools/profile_round.sh, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')} "
+                                  f"passes of tools/profile_round.sh, ({ent.get('read_factor', 2.0)} * FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')} "
+                                  f"[read factor per access pattern: streams 2, gathers 1, profiles/r5_gather_fetch_calibration.json] "
                                   f"({ent.get('pairs_per_launch', 1)} stereo pair(s) per launch there, {upl} here); "
                                   "committed profile, not measured in this run")
                 if ent.get("valu_insts_per_launch"):

@@ -1,8 +1,13 @@
 """Summarise a tools/profile_round.sh output directory into profiles/:
    <tag>_kernel_stats.csv (rocprofv3 --stats), <tag>_pmc.json (per-kernel averages of every counter) and
    profiles/pmc_traffic.json (HBM bytes per launch, read by bench.py for roofline.traffic).
-HBM bytes follow the guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports half of a wide coalesced read stream, so reads are doubled: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
+HBM bytes follow the guide (MI355X_MICROARCH.md, HBM) and this repo's own calibration of the counter for gathers
+(tools/ubench/gather_fetch.hip -> profiles/r5_gather_fetch_calibration.json, round 5): FETCH_SIZE / WRITE_SIZE are in KiB;
+FETCH_SIZE = read requests x 64 B.  A coalesced STREAM (4, 8 or 16 B per lane) travels as 128-B requests: the counter shows
+exactly HALF the bytes -> x2.  A GATHER (4- to 64-byte pieces at scattered places, or a wave's 8x8-pixel patch of an image)
+travels as 64-B requests, one per line touched: the counter IS the bytes moved (64 B per line, however little of it is used)
+-> x1.  Per stage: READ_FACTOR below; a stage that mixes both is bracketed (x1 = lower bound, x2 = upper bound) and the
+midpoint is quoted.  bytes = (factor * FETCH_SIZE + WRITE_SIZE) * 1024."""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
@@ -36,6 +41,11 @@ json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_{cfg}.json"), "w"), indent
 prefix_of = (("k_project", "project"), ("k_count_tiles", "count_tiles"), ("k_hist_colscan", "hist_colscan"), ("k_tile_scan", "tile_scan"),
              ("k_scatter", "scatter"), ("k_sort_tiles", "sort_tiles"), ("k_tsdf_touch", "tsdf_touch"),
              ("k_tsdf_integrate", "tsdf_integrate"), ("k_blend", "blend"))
+# what the reads of a stage are (see the module docstring): streams are doubled, gathers are not
+READ_FACTOR = {"project": 2.0, "count_tiles": 2.0, "hist_colscan": 2.0, "tile_scan": 2.0, "scatter": 2.0, "sort_tiles": 2.0,
+               "blend": 1.0,            # record DMA = 16-byte pieces gathered by id (the 8-byte key stream is <= 1/6 of the reads)
+               "tsdf_touch": 1.0,       # every 4th pixel of every 4th row
+               "tsdf_integrate": 1.5}   # state planes stream (x2), depth / colour are patch gathers (x1): bracketed [1, 2]
 stage_of = {}
 for k in summary:
     for pre, st in prefix_of:
@@ -50,7 +60,7 @@ for k, cs in sorted(summary.items()):
         if stage in traffic:      # a stage made of several kernels (the per-tile sort: one kernel per size class): sums
             t = traffic[stage]
             t["kernel"] += " + " + k
-            t["hbm_bytes_per_launch"] += int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
+            t["hbm_bytes_per_launch"] += int((READ_FACTOR[stage] * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)
             t["fetch_kib"] += cs["FETCH_SIZE"]
             t["write_kib"] += cs["WRITE_SIZE"]
             for name, key in (("valu_insts_per_launch", "SQ_INSTS_VALU"), ("salu_insts_per_launch", "SQ_INSTS_SALU"),
@@ -58,7 +68,9 @@ for k, cs in sorted(summary.items()):
                 if key in cs and t.get(name) is not None:
                     t[name] += int(cs[key])
             continue
-        traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+        traffic[stage] = dict(kernel=k, hbm_bytes_per_launch=int((READ_FACTOR[stage] * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+                              read_factor=READ_FACTOR[stage],
+                              hbm_bytes_bracket=[int((cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024), int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024)],
                               fetch_kib=cs["FETCH_SIZE"], write_kib=cs["WRITE_SIZE"],
                               valu_insts_per_launch=int(cs["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in cs else None,
                               valu_trans_per_launch=int(cs["SQ_INSTS_VALU_TRANS_F32"]) if "SQ_INSTS_VALU_TRANS_F32" in cs else None,
