@@ -544,6 +544,27 @@ def main():
                 blocks_per_frame=round(blocks_frame, 1), updated_voxels_per_frame=round(U_frame, 1),
                 allocated_blocks=int(n_blocks), voxel_length=cfg.voxel_length, sdf_trunc=cfg.sdf_trunc,
                 unit="Mvoxel-updates/s (4096 per touched 16^3 block per frame)")
+    if rank == 0 and world == 1:
+        # mesh extraction of the fused volume, OUTSIDE the timed metric (once per scene, tsdf_utils.py:108 + :133): marching cubes
+        # + vertex welding on the device, indexed mesh over PCIe, connected components on the device
+        try:
+            torch.cuda.synchronize()
+            tm0 = time.perf_counter()
+            mesh = vol.extract_triangle_mesh()
+            tm1 = time.perf_counter()
+            m_labels, m_counts, _ = mesh.cluster_connected_triangles()
+            tm2 = time.perf_counter()
+            tsdf["mesh"] = dict(triangles=int(mesh.triangles.shape[0]), vertices=int(mesh.vertices.shape[0]),
+                                clusters=int(len(m_counts)), largest_cluster=int(m_counts.max()) if len(m_counts) else 0,
+                                extract_weld_ms=round(1e3 * (tm1 - tm0), 2), cluster_ms=round(1e3 * (tm2 - tm1), 2),
+                                bytes_over_pcie=int(mesh.vertices.nbytes + mesh.vertex_colors.nbytes + mesh.edge_index.nbytes +
+                                                    mesh.triangles.nbytes + m_labels.nbytes + m_counts.nbytes),
+                                soup_bytes_round4=int(mesh.triangles.shape[0]) * (2 * 72 + 48),
+                                note="gs2m_tsdf_extract_mesh + gs2m_tsdf_mesh_copy, gs2m_mesh_cluster; wall times incl. the "
+                                     "host allocations and copies; not part of `value`")
+            del mesh
+        except Exception as e:   # the mesh is an extra of the line, never a reason to lose it
+            tsdf["mesh"] = dict(error=str(e)[:200])
     if red is not None:
         tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
                               union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),

@@ -90,6 +90,9 @@ _PROTOS = {
     "gs2m_tsdf_pack_sum": (i32, [vp, vp, i64, vp, vp]),
     "gs2m_tsdf_unpack_sum": (i32, [vp, vp, i64, vp, i32, vp]),
     "gs2m_tsdf_pack": (i32, [vp, vp, i64, i32, vp, vp, vp]),
+    "gs2m_tsdf_extract_mesh": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "gs2m_tsdf_mesh_copy": (i32, [vp, vp, vp, vp, vp, vp]),
+    "gs2m_mesh_cluster": (i32, [i32, vp, i64, vp, vp, vp, C.POINTER(i64)]),
     "gs2m_tsdf_replace": (i32, [vp, vp, i64, i32, vp, vp, vp]),
     "gs2m_tsdf_map_bytes": (i64, [C.POINTER(C.c_int32), i32]),
     "gs2m_tsdf_block_map": (i32, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), i32, i32, i64, i64, i32, vp, vp]),

@@ -32,6 +32,12 @@ struct gs2m_tsdf {
     McDevTables* d_mc = nullptr;          // marching-cubes case table (generated at create)
     unsigned* d_blk_tris = nullptr;       // [max_blocks] per-block triangle counts / offsets
     unsigned long long* d_ntri = nullptr; // [1]
+    // the last mesh gs2m_tsdf_extract_mesh produced, welded, on the device (read with gs2m_tsdf_mesh_copy)
+    double* mesh_v = nullptr;      // [mesh_nv][3]
+    double* mesh_c = nullptr;      // [mesh_nv][3]
+    int* mesh_e = nullptr;         // [mesh_nv][4]
+    int* mesh_tri = nullptr;       // [mesh_nt][3]
+    int64_t mesh_nv = 0, mesh_nt = 0;
     int timing = 0;
     struct EvPair {
         int stage;
@@ -206,6 +212,10 @@ extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
     (void)hipFree(t->d_mc);
     (void)hipFree(t->d_blk_tris);
     (void)hipFree(t->d_ntri);
+    (void)hipFree(t->mesh_v);
+    (void)hipFree(t->mesh_c);
+    (void)hipFree(t->mesh_e);
+    (void)hipFree(t->mesh_tri);
     (void)hipHostFree(t->h_counters);
     (void)hipHostFree(t->h_totals);
     for (auto& p : t->ev_live) {
@@ -657,5 +667,152 @@ extern "C" int gs2m_tsdf_extract_indexed(gs2m_tsdf* t, gs2m_stream stream, int64
     if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
     gs2m_launch_mc_emit((hipStream_t)stream, t->V, t->d_mc, (unsigned)nb, t->d_blk_tris, (unsigned long long)max_triangles,
                         t->voxel_length, t->unit_length, vertices, colors, edge_index);
+    return 0;
+}
+
+// ---- device-side mesh: extraction + welding, connected components ----------------------------------------------------------------
+namespace {
+struct DevBuf {      // scoped device allocation of the one-off mesh passes
+    void* p = nullptr;
+    ~DevBuf() { (void)hipFree(p); }
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+unsigned pow2_at_least(unsigned long long n) {
+    unsigned c = 1024u;
+    while ((unsigned long long)c < n && c < 0x80000000u) c <<= 1;
+    return c;
+}
+}  // namespace
+
+static void drop_mesh(gs2m_tsdf* t) {
+    (void)hipFree(t->mesh_v);
+    (void)hipFree(t->mesh_c);
+    (void)hipFree(t->mesh_e);
+    (void)hipFree(t->mesh_tri);
+    t->mesh_v = t->mesh_c = nullptr;
+    t->mesh_e = t->mesh_tri = nullptr;
+    t->mesh_nv = t->mesh_nt = 0;
+}
+
+extern "C" int gs2m_tsdf_extract_mesh(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_vertices, int64_t* n_triangles) {
+    if (!t || !n_vertices || !n_triangles) {
+        gs2m_set_error("gs2m_tsdf_extract_mesh: NULL argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    drop_mesh(t);
+    *n_vertices = *n_triangles = 0;
+    int64_t nt = 0;
+    if (gs2m_tsdf_extract_count(t, stream, &nt)) return 1;
+    if (nt == 0) return 0;
+    if (nt > 0x2aaaaaaa) {
+        gs2m_set_error("gs2m_tsdf_extract_mesh: %lld triangles exceed the 32-bit vertex numbering", (long long)nt);
+        return 1;
+    }
+    const unsigned n = (unsigned)(3 * nt);
+    const unsigned cap = pow2_at_least(2ull * n);
+    const unsigned m = (n + 4095u) / 4096u;
+    DevBuf soup_v, soup_c, soup_e, hkeys, hfirst, cell_of, flag, pos, scratch, small;
+    if (!soup_v.alloc(sizeof(double) * 3 * (size_t)n) || !soup_c.alloc(sizeof(double) * 3 * (size_t)n) || !soup_e.alloc(sizeof(int) * 4 * (size_t)n) ||
+        !hkeys.alloc(sizeof(unsigned long long) * (size_t)cap) || !hfirst.alloc(sizeof(unsigned) * (size_t)cap) ||
+        !cell_of.alloc(sizeof(unsigned) * (size_t)n) || !flag.alloc(sizeof(unsigned) * (size_t)n) || !pos.alloc(sizeof(unsigned) * (size_t)n) ||
+        !scratch.alloc(sizeof(unsigned) * ((size_t)m + 2)) || !small.alloc(sizeof(int) * 4) ||
+        hipMalloc((void**)&t->mesh_tri, sizeof(int) * (size_t)n) != hipSuccess) {
+        gs2m_set_error("gs2m_tsdf_extract_mesh: out of device memory for %lld triangles", (long long)nt);
+        drop_mesh(t);
+        return 1;
+    }
+    int64_t nb = 0;
+    if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
+    gs2m_launch_mc_emit(st, t->V, t->d_mc, (unsigned)nb, t->d_blk_tris, (unsigned long long)nt, t->voxel_length, t->unit_length,
+                        soup_v.as<double>(), soup_c.as<double>(), soup_e.as<int>());
+    const int init[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0};      // mins[3], bad
+    HIPCHK(hipMemcpyAsync(small.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
+    HIPCHK(hipMemsetAsync(hfirst.p, 0xff, sizeof(unsigned) * (size_t)cap, st));
+    // the compact arrays cannot be sized before the scan: first the flags, the scan and its total, then the allocation and the emit
+    {
+        int* mins = small.as<int>();
+        unsigned* bad = reinterpret_cast<unsigned*>(mins + 3);
+        gs2m_launch_mesh_weld_count(st, n, soup_e.as<int>(), mins, hkeys.as<unsigned long long>(), hfirst.as<unsigned>(), cap, cell_of.as<unsigned>(),
+                                    flag.as<unsigned>(), pos.as<unsigned>(), scratch.as<unsigned>(), bad);
+        unsigned total = 0;
+        int hb[4];
+        HIPCHK(hipMemcpyAsync(&total, scratch.as<unsigned>() + m, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hb, small.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hb[3]) {
+            gs2m_set_error("gs2m_tsdf_extract_mesh: the surface spans more than 2^20 voxels along an axis (62-bit weld key)");
+            drop_mesh(t);
+            return 1;
+        }
+        if (hipMalloc((void**)&t->mesh_v, sizeof(double) * 3 * (size_t)total) != hipSuccess ||
+            hipMalloc((void**)&t->mesh_c, sizeof(double) * 3 * (size_t)total) != hipSuccess ||
+            hipMalloc((void**)&t->mesh_e, sizeof(int) * 4 * (size_t)total) != hipSuccess) {
+            gs2m_set_error("gs2m_tsdf_extract_mesh: out of device memory for %u vertices", total);
+            drop_mesh(t);
+            return 1;
+        }
+        gs2m_launch_mesh_weld_emit(st, n, hfirst.as<unsigned>(), cell_of.as<unsigned>(), pos.as<unsigned>(), soup_v.as<double>(),
+                                   t->V.has_color ? soup_c.as<double>() : nullptr, soup_e.as<int>(), t->mesh_v, t->mesh_c, t->mesh_e, t->mesh_tri);
+        HIPCHK(hipStreamSynchronize(st));     // the scoped temporaries are freed on return
+        HIPCHK(hipGetLastError());
+        t->mesh_nv = (int64_t)total;
+        t->mesh_nt = nt;
+    }
+    *n_vertices = t->mesh_nv;
+    *n_triangles = t->mesh_nt;
+    return 0;
+}
+
+extern "C" int gs2m_tsdf_mesh_copy(gs2m_tsdf* t, gs2m_stream stream, double* vertices, double* colors, int32_t* edge_index, int32_t* triangles) {
+    if (!t) {
+        gs2m_set_error("null handle");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (t->mesh_nv > 0) {
+        if (vertices) HIPCHK(hipMemcpyAsync(vertices, t->mesh_v, sizeof(double) * 3 * (size_t)t->mesh_nv, hipMemcpyDefault, st));
+        if (colors) HIPCHK(hipMemcpyAsync(colors, t->mesh_c, sizeof(double) * 3 * (size_t)t->mesh_nv, hipMemcpyDefault, st));
+        if (edge_index) HIPCHK(hipMemcpyAsync(edge_index, t->mesh_e, sizeof(int) * 4 * (size_t)t->mesh_nv, hipMemcpyDefault, st));
+    }
+    if (t->mesh_nt > 0 && triangles) HIPCHK(hipMemcpyAsync(triangles, t->mesh_tri, sizeof(int) * 3 * (size_t)t->mesh_nt, hipMemcpyDefault, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int gs2m_mesh_cluster(int device, gs2m_stream stream, int64_t n_triangles, const int32_t* triangles, int32_t* labels,
+                                 int64_t* cluster_n_triangles, int64_t* n_clusters) {
+    if (n_triangles < 0 || n_triangles > 0x7fffffff || !n_clusters || (n_triangles > 0 && (!triangles || !labels || !cluster_n_triangles))) {
+        gs2m_set_error("gs2m_mesh_cluster: bad argument");
+        return 1;
+    }
+    *n_clusters = 0;
+    if (n_triangles == 0) return 0;
+    HIPCHK(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned nt = (unsigned)n_triangles;
+    const unsigned cap = pow2_at_least(6ull * nt);
+    const unsigned m = (nt + 4095u) / 4096u;
+    DevBuf hkeys, hval, parent, root, flag, pos, scratch;
+    if (!hkeys.alloc(sizeof(unsigned long long) * (size_t)cap) || !hval.alloc(sizeof(unsigned) * (size_t)cap) || !parent.alloc(sizeof(unsigned) * (size_t)nt) ||
+        !root.alloc(sizeof(unsigned) * (size_t)nt) || !flag.alloc(sizeof(unsigned) * (size_t)nt) || !pos.alloc(sizeof(unsigned) * (size_t)nt) ||
+        !scratch.alloc(sizeof(unsigned) * ((size_t)m + 2))) {
+        gs2m_set_error("gs2m_mesh_cluster: out of device memory for %u triangles", nt);
+        return 1;
+    }
+    HIPCHK(hipMemsetAsync(hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
+    HIPCHK(hipMemsetAsync(hval.p, 0xff, sizeof(unsigned) * (size_t)cap, st));
+    HIPCHK(hipMemsetAsync(cluster_n_triangles, 0, sizeof(int64_t) * (size_t)nt, st));
+    gs2m_launch_mesh_cluster(st, triangles, nt, hkeys.as<unsigned long long>(), hval.as<unsigned>(), cap, parent.as<unsigned>(), root.as<unsigned>(),
+                             flag.as<unsigned>(), pos.as<unsigned>(), scratch.as<unsigned>(), labels, reinterpret_cast<unsigned long long*>(cluster_n_triangles));
+    unsigned total = 0;
+    HIPCHK(hipMemcpyAsync(&total, scratch.as<unsigned>() + m, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    *n_clusters = (int64_t)total;
     return 0;
 }

@@ -27,4 +27,13 @@ void gs2m_launch_mc_count(hipStream_t st, const TsdfVolume& V, const McDevTables
 void gs2m_launch_mc_emit(hipStream_t st, const TsdfVolume& V, const McDevTables* T, unsigned n_blocks,
                          const unsigned* blk_off, unsigned long long max_tris, double voxel_length, double unit_length,
                          double* vertices, double* colors, int* edge_index);
+// mesh post-processing (mesh_kernels.h)
+void gs2m_launch_scan_u32(hipStream_t st, const unsigned* in, unsigned n, unsigned* out, unsigned* scratch);
+void gs2m_launch_mesh_weld_count(hipStream_t st, unsigned n, const int* edge_index, int* mins, unsigned long long* hkeys, unsigned* hfirst,
+                                 unsigned cap, unsigned* cell_of, unsigned* flag, unsigned* pos, unsigned* scratch, unsigned* bad);
+void gs2m_launch_mesh_weld_emit(hipStream_t st, unsigned n, const unsigned* hfirst, const unsigned* cell_of, const unsigned* pos, const double* verts,
+                                const double* cols, const int* edge_index, double* out_v, double* out_c, int* out_e, int* out_tri);
+void gs2m_launch_mesh_cluster(hipStream_t st, const int* tri, unsigned n_tri, unsigned long long* hkeys, unsigned* hval, unsigned cap,
+                              unsigned* parent, unsigned* root, unsigned* flag, unsigned* pos, unsigned* scratch, int* labels,
+                              unsigned long long* cluster_n);
 void gs2m_set_error(const char* fmt, ...);

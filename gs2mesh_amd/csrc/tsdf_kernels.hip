@@ -1,6 +1,7 @@
 // tsdf_kernels.hip -- TSDF integration stage (compiled with -ffp-contract=off).
 #include "tsdf_kernels.h"
 #include "tsdf_extract.h"
+#include "mesh_kernels.h"
 #include "tsdf_internal.h"
 #include <math.h>
 
@@ -79,4 +80,40 @@ void gs2m_launch_mc_emit(hipStream_t st, const TsdfVolume& V, const McDevTables*
         for (int a = 0; a < 3; ++a) G.edge[e][a] = mc_edge[e][a];
     GS2M_LAUNCH(k_mc_emit, dim3(n_blocks), dim3(256), 0, st, V, T, G, n_blocks, blk_off, max_tris, voxel_length,
                 unit_length, vertices, colors, edge_index);
+}
+
+// ---- mesh post-processing (mesh_kernels.h) ----------------------------------------------------------------------------------
+static unsigned grid_for(unsigned n) {
+    const unsigned g = (n + 255u) / 256u;
+    return g < 1u ? 1u : (g > 4096u ? 4096u : g);
+}
+// exclusive scan of in[n] -> out[n]; scratch >= ceil(n / 4096) + 1 words; the total -> scratch[ceil(n / 4096)]
+void gs2m_launch_scan_u32(hipStream_t st, const unsigned* in, unsigned n, unsigned* out, unsigned* scratch) {
+    const unsigned m = (n + GS2M_SCAN_TILE - 1u) / GS2M_SCAN_TILE;
+    GS2M_LAUNCH(k_scan_tile_sums, dim3(m), dim3(1024), 0, st, in, n, scratch);
+    GS2M_LAUNCH(k_scan_sums, dim3(1), dim3(1024), 0, st, scratch, m, scratch + m);
+    GS2M_LAUNCH(k_scan_apply, dim3(m), dim3(1024), 0, st, in, n, scratch, out);
+}
+// weld, first half: key minima, table, "first carrier" flags and their exclusive scan (total -> scratch[ceil(n / 4096)])
+void gs2m_launch_mesh_weld_count(hipStream_t st, unsigned n, const int* edge_index, int* mins, unsigned long long* hkeys, unsigned* hfirst,
+                                 unsigned cap, unsigned* cell_of, unsigned* flag, unsigned* pos, unsigned* scratch, unsigned* bad) {
+    GS2M_LAUNCH(k_mesh_key_min, dim3(grid_for(n)), dim3(256), 0, st, edge_index, n, mins);
+    GS2M_LAUNCH(k_mesh_weld_insert, dim3(grid_for(n)), dim3(256), 0, st, edge_index, n, mins, hkeys, hfirst, cap, cell_of, bad);
+    GS2M_LAUNCH(k_mesh_weld_flag, dim3(grid_for(n)), dim3(256), 0, st, n, hfirst, cell_of, flag);
+    gs2m_launch_scan_u32(st, flag, n, pos, scratch);
+}
+// second half, once the caller has sized the compact arrays
+void gs2m_launch_mesh_weld_emit(hipStream_t st, unsigned n, const unsigned* hfirst, const unsigned* cell_of, const unsigned* pos, const double* verts,
+                                const double* cols, const int* edge_index, double* out_v, double* out_c, int* out_e, int* out_tri) {
+    GS2M_LAUNCH(k_mesh_weld_emit, dim3(grid_for(n)), dim3(256), 0, st, n, hfirst, cell_of, pos, verts, cols, edge_index, out_v, out_c, out_e,
+                out_tri);
+}
+void gs2m_launch_mesh_cluster(hipStream_t st, const int* tri, unsigned n_tri, unsigned long long* hkeys, unsigned* hval, unsigned cap,
+                              unsigned* parent, unsigned* root, unsigned* flag, unsigned* pos, unsigned* scratch, int* labels,
+                              unsigned long long* cluster_n) {
+    GS2M_LAUNCH(k_mesh_uf_init, dim3(grid_for(n_tri)), dim3(256), 0, st, n_tri, parent);
+    GS2M_LAUNCH(k_mesh_uf_edges, dim3(grid_for(n_tri)), dim3(256), 0, st, tri, n_tri, hkeys, hval, cap, parent);
+    GS2M_LAUNCH(k_mesh_uf_roots, dim3(grid_for(n_tri)), dim3(256), 0, st, n_tri, parent, root, flag);
+    gs2m_launch_scan_u32(st, flag, n_tri, pos, scratch);
+    GS2M_LAUNCH(k_mesh_uf_labels, dim3(grid_for(n_tri)), dim3(256), 0, st, n_tri, root, pos, labels, cluster_n);
 }

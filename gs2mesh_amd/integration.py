@@ -261,26 +261,28 @@ class ScalableTSDFVolume:
         return keys, tsdf, weight, rgb
 
     def extract_triangle_mesh(self, stream=None):
-        """``volume.extract_triangle_mesh()`` (tsdf_utils.py:108): marching cubes on the GPU
-        (``gs2m_tsdf_extract_indexed``), vertices welded on the host by their cut edge -> ``gs2mesh_amd.mesh.TriangleMesh``."""
+        """``volume.extract_triangle_mesh()`` (tsdf_utils.py:108): marching cubes AND the welding of its vertices on the GPU
+        (``gs2m_tsdf_extract_mesh``: Open3D's edge -> vertex identity, first-appearance order); the indexed mesh is what crosses
+        PCIe (vertices, colours, cut edges, triangle indices), and a device copy of the triangle indices stays attached for
+        ``cluster_connected_triangles`` -> ``gs2mesh_amd.mesh.TriangleMesh``."""
         from .mesh import TriangleMesh
         st = stream or C.c_void_p(0)
-        n = C.c_int64(0)
-        _lib.check(self._lib.gs2m_tsdf_extract_count(self._h, st, C.byref(n)), self._lib)
-        nt = int(n.value)
+        nv, nt = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._lib.gs2m_tsdf_extract_mesh(self._h, st, C.byref(nv), C.byref(nt)), self._lib)
+        nv, nt = int(nv.value), int(nt.value)
+        self.status(stream)
         if nt == 0:
             return TriangleMesh()
-        verts = _lib.MEMORY.zeros((nt, 3, 3), np.float64, self.device)
-        cols = _lib.MEMORY.zeros((nt, 3, 3), np.float64, self.device)
-        eidx = _lib.MEMORY.zeros((nt, 3, 4), np.int32, self.device)
-        got = C.c_int64(0)
-        _lib.check(self._lib.gs2m_tsdf_extract_indexed(self._h, _stream_of(verts, stream), nt, _ptr(verts), _ptr(cols),
-                                                       _ptr(eidx), C.byref(got)), self._lib)
-        self.status(stream)
-        verts, cols, eidx = _lib.MEMORY.download(verts), _lib.MEMORY.download(cols), _lib.MEMORY.download(eidx)
-        has_color = self.color_type == TSDFVolumeColorType.RGB8
-        # welded by Open3D's vertex identity (the cut edge), not by position
-        return TriangleMesh.from_triangle_soup(verts, cols if has_color else None, edge_index=eidx)
+        verts, cols = np.empty((nv, 3), np.float64), np.empty((nv, 3), np.float64)
+        eidx, tri = np.empty((nv, 4), np.int32), np.empty((nt, 3), np.int32)
+        hp = lambda a: C.c_void_p(a.ctypes.data)      # gs2m_tsdf_mesh_copy takes host or device destinations
+        _lib.check(self._lib.gs2m_tsdf_mesh_copy(self._h, st, hp(verts), hp(cols), hp(eidx), hp(tri)), self._lib)
+        tri_dev = _lib.MEMORY.zeros((nt, 3), np.int32, self.device)
+        _lib.check(self._lib.gs2m_tsdf_mesh_copy(self._h, st, None, None, None, _ptr(tri_dev)), self._lib)
+        m = TriangleMesh(verts, tri, cols if self.color_type == TSDFVolumeColorType.RGB8 else None)
+        m.edge_index = eidx                      # [n_vertices, 4]: Open3D's vertex keys
+        m.attach_device_triangles(tri_dev, self._lib, self.device)
+        return m
 
     # -- multi-GPU exchange (gs2mesh_amd.parallel) -------------------------------------------
     def exchange_device(self):

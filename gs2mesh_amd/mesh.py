@@ -1,8 +1,9 @@
-"""Host-side triangle mesh with the Open3D calls ``gs2mesh_utils/tsdf_utils.py:108-142`` makes
-(``scale``, ``compute_vertex_normals``, ``cluster_connected_triangles``, ``remove_triangles_by_mask``,
-``remove_unreferenced_vertices``, ``o3d.io.write_triangle_mesh``).  The extraction itself runs on the GPU
-(``gs2m_tsdf_extract``); what is left here is the one-off post-processing the reference also does on
-the host, in numpy / scipy.sparse instead of Open3D."""
+"""Triangle-mesh container with the Open3D calls ``gs2mesh_utils/tsdf_utils.py:108-142`` makes (``scale``,
+``compute_vertex_normals``, ``cluster_connected_triangles``, ``remove_triangles_by_mask``, ``remove_unreferenced_vertices``,
+``o3d.io.write_triangle_mesh``).  Extraction, vertex welding (``gs2m_tsdf_extract_mesh``) and the connected components
+(``gs2m_mesh_cluster``) run on the GPU; what is left here is the container, O(n) numpy bookkeeping on the final arrays
+(scale, normals, mask / compaction) and the PLY writer.  ``from_triangle_soup`` is the host statement of the weld that the
+device path is tested against."""
 from __future__ import annotations
 
 import numpy as np
@@ -68,29 +69,46 @@ class TriangleMesh:
         self.vertex_normals = vn / np.where(ln > 0, ln, 1.0)
         return self
 
-    def cluster_connected_triangles(self):
-        """-> (triangle_clusters[n_tri], cluster_n_triangles[n_clusters], cluster_area[n_clusters]);
-        triangles are connected when they share an edge (Open3D ClusterConnectedTriangles)."""
-        from scipy.sparse import coo_matrix
-        from scipy.sparse.csgraph import connected_components
-        t = self.triangles.astype(np.int64)
-        n = t.shape[0]
+    # ---- device attachment -------------------------------------------------------------------
+    def attach_device_triangles(self, tri_dev, lib, device):
+        """Keep the device copy of ``triangles`` the extraction left behind (valid while ``self.triangles`` is that array)."""
+        self._dev = (tri_dev, lib, int(device), self.triangles)
+
+    def __deepcopy__(self, memo):
+        import copy
+        m = TriangleMesh(self.vertices.copy(), self.triangles.copy(), self.vertex_colors.copy())
+        m.vertex_normals, m.triangle_normals, m.edge_index = (copy.deepcopy(self.vertex_normals, memo),
+                                                              copy.deepcopy(self.triangle_normals, memo), self.edge_index.copy())
+        return m                                   # the device attachment belongs to the original
+
+    def cluster_connected_triangles(self, lib=None, device=0):
+        """-> (triangle_clusters[n_tri], cluster_n_triangles[n_clusters], cluster_area[n_clusters]); triangles are connected
+        when they share an edge (Open3D ClusterConnectedTriangles; clusters numbered by their first triangle).  The components
+        are found on the GPU (``gs2m_mesh_cluster``: union-find over an edge hash table) -- on the triangle indices the
+        extraction left on the device when this mesh still is that mesh, else on an upload of ``triangles`` (12 B each);
+        the areas are one numpy bincount over the labels."""
+        import ctypes as C
+        from . import _lib
+        n = int(self.triangles.shape[0])
         if n == 0:
             return np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.float64)
-        e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]], axis=0)
-        e.sort(axis=1)
-        owner = np.tile(np.arange(n), 3)
-        key = e[:, 0] * (int(self.vertices.shape[0]) + 1) + e[:, 1]
-        order = np.argsort(key, kind="stable")
-        key, owner = key[order], owner[order]
-        same = key[1:] == key[:-1]
-        a, b = owner[:-1][same], owner[1:][same]
-        g = coo_matrix((np.ones(a.size, np.int8), (a, b)), shape=(n, n))
-        n_comp, labels = connected_components(g, directed=False)
-        counts = np.bincount(labels, minlength=n_comp).astype(np.int64)
-        v = self.vertices
+        dev = getattr(self, "_dev", None)
+        if dev is not None and dev[3] is self.triangles and lib in (None, dev[1]):
+            tri_dev, lib, device = dev[0], dev[1], dev[2]
+        else:
+            lib = lib if lib is not None else _lib.get()
+            import torch
+            tri_dev = _lib.MEMORY.upload(np.ascontiguousarray(self.triangles, np.int32), torch.int32, device)
+        labels_dev = _lib.MEMORY.zeros((n,), np.int32, device)
+        count_dev = _lib.MEMORY.zeros((n,), np.int64, device)
+        nc = C.c_int64(0)
+        _lib.check(lib.gs2m_mesh_cluster(int(device), C.c_void_p(0), n, _lib.MEMORY.ptr(tri_dev), _lib.MEMORY.ptr(labels_dev),
+                                         _lib.MEMORY.ptr(count_dev), C.byref(nc)), lib)
+        labels = np.asarray(_lib.MEMORY.download(labels_dev), np.int32)
+        counts = np.asarray(_lib.MEMORY.download(count_dev), np.int64)[: int(nc.value)].copy()
+        v, t = self.vertices, self.triangles.astype(np.int64)
         area = 0.5 * np.linalg.norm(np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]]), axis=1)
-        return labels.astype(np.int32), counts, np.bincount(labels, weights=area, minlength=n_comp)
+        return labels, counts, np.bincount(labels, weights=area, minlength=int(nc.value))
 
     def remove_triangles_by_mask(self, mask):
         keep = ~np.asarray(mask, bool)

@@ -429,6 +429,26 @@ int gs2m_tsdf_extract(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, d
 int gs2m_tsdf_extract_indexed(gs2m_tsdf* t, gs2m_stream stream, int64_t max_triangles, double* vertices,
                               double* colors, int32_t* edge_index, int64_t* n_triangles);
 
+/*
+ * Device-side mesh post-processing.  volume.extract_triangle_mesh() (gs2mesh_utils/tsdf_utils.py:108) returns
+ * an INDEXED mesh: Open3D welds the marching-cubes vertices through an edge -> vertex map while it extracts.
+ *   gs2m_tsdf_extract_mesh   count + emit + weld on the device: the vertices are welded by Open3D's vertex identity (the cut edge:
+ *                            global voxel index of its lower corner + axis), numbered by first appearance in the deterministic
+ *                            emission order of gs2m_tsdf_extract_indexed (= what welding that soup on the host gives).  The mesh stays
+ *                            in the handle; *n_vertices / *n_triangles size the caller's buffers.  Synchronises.
+ *   gs2m_tsdf_mesh_copy      copies the cached mesh to the caller: vertices [nv][3] f64, colors [nv][3] f64 (zeros for a colourless
+ *                            volume), edge_index [nv][4] i32, triangles [nt][3] i32.  Each destination may be NULL and may be a
+ *                            HOST or a device pointer (the PLY writer wants it on the host; the clustering below on the device).
+ *   gs2m_mesh_cluster        TriangleMesh::ClusterConnectedTriangles (tsdf_utils.py:133): triangles are connected when they share an
+ *                            edge.  triangles [n][3] i32, labels [n] i32 and cluster_n_triangles [n] i64 (capacity n; the first
+ *                            *n_clusters entries are written) are DEVICE pointers.  Clusters are numbered by their smallest triangle
+ *                            index (the numbering of a sweep from triangle 0 upwards).  Lock-free union-find over an edge hash table.
+ */
+int gs2m_tsdf_extract_mesh(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_vertices, int64_t* n_triangles);
+int gs2m_tsdf_mesh_copy(gs2m_tsdf* t, gs2m_stream stream, double* vertices, double* colors, int32_t* edge_index, int32_t* triangles);
+int gs2m_mesh_cluster(int device, gs2m_stream stream, int64_t n_triangles, const int32_t* triangles, int32_t* labels,
+                      int64_t* cluster_n_triangles, int64_t* n_clusters);
+
 /* ------------------------------------------------------------------------------------ */
 /* stereo post-processing (between the stereo network and the TSDF)                     */
 /* ------------------------------------------------------------------------------------ */

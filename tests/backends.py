@@ -54,7 +54,7 @@ class HostMemory(_lib.DeviceMemory):
         import torch
         if isinstance(a, torch.Tensor):
             return (a if a.dtype == torch_dtype else a.to(torch_dtype)).contiguous()
-        np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8}[torch_dtype]
+        np_dtype = {torch.float32: np.float32, torch.uint8: np.uint8, torch.int32: np.int32, torch.int64: np.int64}[torch_dtype]
         return np.ascontiguousarray(a).astype(np_dtype, copy=False)
 
     def download(self, t):

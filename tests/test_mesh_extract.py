@@ -233,3 +233,101 @@ def test_tsdf_run_save_and_clean_mesh_like_run_single(backend, tmp_path):
     assert clean.triangles.shape[0] == counts[counts >= 2000].sum()
     assert clean.vertices.shape[0] < raw.vertices.shape[0]
     assert t.clean_mesh is not None and not callable(t.clean_mesh)       # the method rebinds itself (tsdf_utils.py:138)
+
+
+# ---- device-side welding and clustering (round 5) against their host statements ------------------------------------------------
+def extract_soup(vol):
+    """the un-welded output of gs2m_tsdf_extract_indexed (what round 4 copied to the host and welded there)"""
+    import ctypes as C
+    from gs2mesh_amd import _lib
+    from gs2mesh_amd.rasterizer import _ptr, _stream_of
+    n = C.c_int64(0)
+    _lib.check(vol._lib.gs2m_tsdf_extract_count(vol._h, C.c_void_p(0), C.byref(n)), vol._lib)
+    nt = int(n.value)
+    verts = _lib.MEMORY.zeros((nt, 3, 3), np.float64, vol.device)
+    cols = _lib.MEMORY.zeros((nt, 3, 3), np.float64, vol.device)
+    eidx = _lib.MEMORY.zeros((nt, 3, 4), np.int32, vol.device)
+    got = C.c_int64(0)
+    _lib.check(vol._lib.gs2m_tsdf_extract_indexed(vol._h, _stream_of(verts, None), nt, _ptr(verts), _ptr(cols), _ptr(eidx), C.byref(got)),
+               vol._lib)
+    vol.status()
+    return _lib.MEMORY.download(verts), _lib.MEMORY.download(cols), _lib.MEMORY.download(eidx)
+
+
+def scipy_clusters(mesh):
+    """the host statement of ClusterConnectedTriangles (what gs2mesh_amd.mesh did until round 4): scipy connected components of
+    the triangle graph whose arcs are shared edges"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    t = mesh.triangles.astype(np.int64)
+    n = t.shape[0]
+    e = np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]], axis=0)
+    e.sort(axis=1)
+    owner = np.tile(np.arange(n), 3)
+    key = e[:, 0] * (int(mesh.vertices.shape[0]) + 1) + e[:, 1]
+    order = np.argsort(key, kind="stable")
+    key, owner = key[order], owner[order]
+    same = key[1:] == key[:-1]
+    g = coo_matrix((np.ones(int(same.sum()), np.int8), (owner[:-1][same], owner[1:][same])), shape=(n, n))
+    n_comp, labels = connected_components(g, directed=False)
+    return labels.astype(np.int32), np.bincount(labels, minlength=n_comp).astype(np.int64)
+
+
+def test_device_weld_equals_the_host_weld_of_the_soup(backend):
+    """gs2m_tsdf_extract_mesh == TriangleMesh.from_triangle_soup(gs2m_tsdf_extract_indexed): same vertices in the same (first
+    appearance) order, same triangle indices, same colours and cut edges -- on the sphere and with a second, detached component."""
+    from gs2mesh_amd.mesh import TriangleMesh
+    vol, r, voxel = fused_sphere(backend, n_views=6)
+    for case in range(2):
+        if case == 1:   # a floating blob in front of the first camera: a second component, other blocks
+            W, H, f = 200, 150, 210.0
+            p = synthetic.ring_poses(6, 3.5)[0]
+            E = np.eye(4)
+            E[:3] = p
+            d = np.zeros((H, W), np.float32)
+            d[60:90, 80:120] = 1.7
+            vol.integrate(RGBDImage(backend.dev(synthetic.color_pattern(W, H)), backend.dev(d)), PinholeCameraIntrinsic(W, H, f, f, W / 2.0, H / 2.0), E)
+        mesh = vol.extract_triangle_mesh()
+        v, c, e = extract_soup(vol)
+        ref = TriangleMesh.from_triangle_soup(v, c, edge_index=e)
+        assert mesh.triangles.shape[0] == v.shape[0] > 3000
+        np.testing.assert_array_equal(mesh.triangles, ref.triangles)
+        np.testing.assert_array_equal(mesh.vertices, ref.vertices)
+        np.testing.assert_array_equal(mesh.vertex_colors, ref.vertex_colors)
+        np.testing.assert_array_equal(mesh.edge_index, ref.edge_index)
+
+
+def test_device_clustering_equals_scipy_connected_components(backend):
+    """gs2m_mesh_cluster: the labels (clusters numbered by their first triangle) and sizes scipy gives, on the extraction's own
+    device copy of the triangles, on an uploaded copy after a mask removed triangles, and on hand-made meshes (a bow tie: two
+    triangles sharing ONE vertex are not connected; a fan sharing edges is; an isolated triangle)."""
+    from gs2mesh_amd.mesh import TriangleMesh
+    vol, r, voxel = fused_sphere(backend, n_views=6)
+    W, H, f = 200, 150, 210.0
+    p = synthetic.ring_poses(6, 3.5)[0]
+    E = np.eye(4)
+    E[:3] = p
+    d = np.zeros((H, W), np.float32)
+    d[60:90, 80:120] = 1.7
+    d[10:20, 10:30] = 2.2
+    vol.integrate(RGBDImage(backend.dev(synthetic.color_pattern(W, H)), backend.dev(d)), PinholeCameraIntrinsic(W, H, f, f, W / 2.0, H / 2.0), E)
+    mesh = vol.extract_triangle_mesh()
+    labels, counts, areas = mesh.cluster_connected_triangles()
+    ref_labels, ref_counts = scipy_clusters(mesh)
+    assert len(counts) >= 3
+    np.testing.assert_array_equal(labels, ref_labels)
+    np.testing.assert_array_equal(counts, ref_counts)
+    assert np.isclose(areas.sum(), 0.5 * np.linalg.norm(np.cross(*(mesh.vertices[mesh.triangles[:, k]] - mesh.vertices[mesh.triangles[:, 0]]
+                                                                  for k in (1, 2))), axis=1).sum())
+    # after an edit the device copy is stale: the triangles are uploaded again
+    mesh.remove_triangles_by_mask(np.arange(mesh.triangles.shape[0]) % 7 == 0)
+    l2, c2, _ = mesh.cluster_connected_triangles(lib=backend.lib)
+    r2, rc2 = scipy_clusters(mesh)
+    np.testing.assert_array_equal(l2, r2)
+    np.testing.assert_array_equal(c2, rc2)
+    # hand-made: bow tie (0-1-2, 2-3-4), a fan of three around vertex 5 sharing edges, an isolated triangle
+    tri = np.array([[0, 1, 2], [2, 3, 4], [5, 6, 7], [5, 7, 8], [5, 8, 9], [10, 11, 12]], np.int32)
+    m = TriangleMesh(np.random.default_rng(2).random((13, 3)), tri)
+    l3, c3, a3 = m.cluster_connected_triangles(lib=backend.lib)
+    assert l3.tolist() == [0, 1, 2, 2, 2, 3] and c3.tolist() == [1, 1, 3, 1] and len(a3) == 4
+    assert TriangleMesh().cluster_connected_triangles(lib=backend.lib)[1].shape == (0,)
