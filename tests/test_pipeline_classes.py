@@ -201,6 +201,39 @@ def test_renderer_end_to_end_writes_the_reference_pngs(tmp_path):
     assert np.abs(img - ref_left(g, left, cfg)).max() < 2e-2 and out["radii"].shape[0] == cfg.P
 
 
+@pytest.mark.gpu
+def test_psnr_vs_ref_tool_on_a_synthetic_colmap_scene(tmp_path):
+    """tools/psnr_vs_ref.py (real-data readiness: the DTU scan24 check of the north star as one command) on a synthetic COLMAP
+    directory + splat PLY: PSNR per GS/utils/image_utils.py:17-19 against the reference's kernels, flip statement checked, and the
+    ground-truth leg (--gt-dir) with the reference's own render as the "photo": the gap to the reference is then the HIP error."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import psnr_vs_ref
+    cfg = synthetic.CONFIGS["C1"]
+    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    ply = tmp_path / "point_cloud.ply"
+    write_gaussian_ply(str(ply), g["xyz"], g["features_dc"], g["features_rest"], g["opacity"], g["scaling"], g["rotation"])
+    poses = synthetic.ring_poses(3, cfg.ring_radius)
+    col = tmp_path / "colmap"
+    write_colmap(str(col), poses, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.width / 2, cfg.height / 2)
+    # "ground truth": the oracle's 8-bit render of the left eye of view 1
+    left, _ = synthetic.stereo_cameras(poses[1], cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline)
+    gt = tmp_path / "gt"
+    os.makedirs(gt)
+    q8 = np.clip(np.rint(ref_left(g, left, cfg).transpose(1, 2, 0) * 255.0), 0, 255).astype(np.uint8)
+    PILImage.fromarray(q8, mode="RGB").save(str(gt / "1.png"))
+    out = tmp_path / "psnr.json"
+    rows, summary = psnr_vs_ref.main([str(col), str(ply), "--pairs", "1", "--baseline-absolute", str(cfg.baseline), "--gt-dir", str(gt),
+                                      "--json", str(out)])
+    assert len(rows) == 2 and os.path.exists(out)
+    assert summary["min_psnr_db_vs_reference"] > 90.0 and summary["unexplained_pixels"] == 0
+    assert all(r["flips_ok"] and r["radii_mismatches"] <= 1 for r in rows)
+    assert abs(rows[0]["psnr_db_gap_to_reference"]) < 0.1            # the north star's bar, on the synthetic stand-in
+
+
 def ref_left(g, cam, cfg):
     s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
     shs = np.concatenate([g["features_dc"], g["features_rest"]], axis=1)
