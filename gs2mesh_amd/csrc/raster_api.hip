@@ -326,6 +326,33 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     const int gx = (W + GS2M_TILE - 1) / GS2M_TILE, gy = (H + GS2M_TILE - 1) / GS2M_TILE;
     const int gys = (gy + r->opt_tile_rows - 1) / r->opt_tile_rows;  // binning rows (tiles of 16 x 16*rows pixels)
     const int tiles = gx * gys;
+    // Advisory hints from the PREVIOUS pass of the same geometry, snapshotted before this pass launches anything: k_tile_scan
+    // writes {num_rendered, class counts} of a pass straight into the pinned, device-mapped mirror, so reading the mirror after
+    // this pass's own launches would race with its writer.  Every value is legal -- the sort falls back exactly when
+    // a class grid is too small, either dispatch order of the compositing grid is correct -- and a slot the previous pass has
+    // not written yet reads as the pass before it (or zero: "no information").
+    int hint[3] = {-1, -1, -1};
+    int interleave = 1;
+    if (r->hint_valid && r->last_tiles == tiles && r->last_nv == nvt) {
+        unsigned nr_max = 0;
+        for (int c = 0; c < 3; ++c) {
+            unsigned m = 0;
+            for (int v = 0; v < nvt; ++v) {
+                const unsigned x = r->h_status[1 + status_slot + v].n_class[c];
+                m = x > m ? x : m;
+            }
+            hint[c] = m > 0x3fffffffu ? -1 : (int)m;
+        }
+        for (int v = 0; v < nvt; ++v) {
+            const unsigned x = r->h_status[1 + status_slot + v].num_rendered;
+            nr_max = x > nr_max ? x : nr_max;
+        }
+        // Dispatch order of a multi-view compositing launch: chunk rank major / view minor ("interleaved": the heavy chunks of
+        // every view start first) pays when the lists are long -- the launch then ends on the heavy chunks of its last view
+        // (C3, ~1700 instances per list: 220 -> 205 us per pair) -- and costs ~2 % when they are short (C2, ~300 per list: four
+        // views' records compete for each XCD's L2).  First pass / no information: interleaved.
+        if (nr_max > 0u && nr_max <= 0x3fffffffu) interleave = (size_t)nr_max >= (size_t)800 * (size_t)tiles;
+    }
     int chunk, n_wg;
     geometry(r, g.P, &chunk, &n_wg, pairs);
     // threads per counting / scatter workgroup: the chunk (<= 1024), halved until the wave staging fits next to the
@@ -384,38 +411,12 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     if (dbg_check(r, st, "scatter")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_SORT);
-        // class-grid hint: what the previous call on this handle (same image size and binning) found, as far as its status
-        // copy has landed in the pinned mirror; -1 = no information (first call, other geometry)
-        int hint[3] = {-1, -1, -1};
-        if (r->hint_valid && r->last_tiles == tiles && r->last_nv == nvt) {
-            for (int c = 0; c < 3; ++c) {
-                unsigned m = 0;
-                for (int v = 0; v < nvt; ++v) {
-                    const unsigned x = r->h_status[1 + status_slot + v].n_class[c];
-                    m = x > m ? x : m;
-                }
-                hint[c] = m > 0x3fffffffu ? -1 : (int)m;
-            }
-        }
+        // class-grid hint: snapshotted at the top of the pass
         gs2m_launch_sort_tiles(st, nvt, r->d_keys, r->d_tmp, r->d_tile_start, tiles, cap, r->d_sort_lists, hint);
     }
     if (dbg_check(r, st, "sort_tiles")) return 1;
     {
         StageTimer tm(r, st, GS2M_STAGE_BLEND);
-        // Dispatch order of a multi-view compositing launch: chunk rank major / view minor ("interleaved": the heavy chunks of
-        // every view start first) pays when the lists are long -- the launch then ends on the heavy chunks of its last view
-        // (C3, ~1700 instances per list: 220 -> 205 us per pair) -- and costs ~2 % when they are short (C2, ~300 per list: four
-        // views' records compete for each XCD's L2).  Decided from the previous pass's instance count as far as its status copy
-        // has landed (advisory like the sort hint above: either order is correct); first pass: interleaved.
-        int interleave = 1;
-        if (r->hint_valid && r->last_tiles == tiles && r->last_nv == nvt) {
-            unsigned m = 0;
-            for (int v = 0; v < nvt; ++v) {
-                const unsigned x = r->h_status[1 + status_slot + v].num_rendered;
-                m = x > m ? x : m;
-            }
-            if (m > 0u && m <= 0x3fffffffu) interleave = (size_t)m >= (size_t)800 * (size_t)tiles;
-        }
         if (gs2m_launch_blend(st, r->opt_blend, r->opt_tile_rows, nvt, gx, gy, r->d_keys, r->d_tile_start, recs, r->d_cams,
                               g.P, cap, out_color, out_rgb8, g.ids ? r->run_rank : nullptr,
                               r->d_sort_lists + (size_t)nvt * GS2M_SORT_CLASSES_API * (tiles + 1), r->opt_blend_mode,

@@ -93,8 +93,13 @@ class ScalableTSDFVolume:
         self._h = h
         self._keep = []  # uploaded frames stay alive until the next synchronising call
         # frames this volume's state carries = an upper bound of every voxel weight (the packed exchange form needs it):
-        # `frames_base` = bound inherited from a reduction / injected state, `frames_local` = frames integrated here since
+        # upper bound of every voxel weight, in three parts (gs2mesh_amd.parallel sums them correctly across ranks):
+        # `frames_base` = inherited from a REDUCTION (a reduce-scatter leaves the ranks with disjoint parts of one reduced
+        # volume: across ranks these bounds do not add up, their maximum holds), `frames_injected` = state the caller put
+        # in with unpack(..., frames=F) (several ranks may inject into the SAME blocks, e.g. one checkpoint loaded everywhere:
+        # these add up), `frames_local` = frames integrated here since (add up)
         self.frames_base = 0
+        self.frames_injected = 0
         self.frames_local = 0
         self.replicated = False      # the state is the all-reduced volume (every rank holds it: summing it again would count it R times)
         self.has_halo = False        # holds neighbour-only copies of other ranks' blocks (exchange_halo): their keys read as the sentinel
@@ -120,13 +125,13 @@ class ScalableTSDFVolume:
         self._reset_bookkeeping()
 
     def _reset_bookkeeping(self):
-        self.frames_base = self.frames_local = 0
+        self.frames_base = self.frames_local = self.frames_injected = 0
         self.replicated = False
         self.has_halo = False
 
     @property
     def frames_integrated(self):
-        return self.frames_base + self.frames_local
+        return self.frames_base + self.frames_injected + self.frames_local
 
     def exchange_buffer(self, name, shape, dtype, device):
         """A persistent, grow-only device buffer owned by the volume (the multi-GPU reduction re-uses its pack / receive
@@ -305,7 +310,7 @@ class ScalableTSDFVolume:
         """``gs2m_tsdf_block_map``: this rank's blocks + header into ``cells`` (device uint8 [map_bytes(world)]); async."""
         lo = (C.c_int32 * 3)(*self.exchange_window[0])
         dim = (C.c_int32 * 3)(*self.exchange_window[1])
-        _lib.check(self._lib.gs2m_tsdf_block_map(self._h, lo, dim, int(rank), int(world), int(self.frames_local),
+        _lib.check(self._lib.gs2m_tsdf_block_map(self._h, lo, dim, int(rank), int(world), int(self.frames_local + self.frames_injected),
                                                  int(self.frames_base), int(flags), _ptr(cells), _stream_of(cells, stream)),
                    self._lib)
 
@@ -356,11 +361,17 @@ class ScalableTSDFVolume:
         _lib.check(self._lib.gs2m_tsdf_replace(self._h, _ptr(keys), n, int(form), _ptr(buf_f32), _ptr(buf_i64),
                                                _stream_of(keys, stream)), self._lib)
         self._reset_bookkeeping()
-        self._inherit(frames)
+        self._inherit(frames, reduced=True)
 
-    def _inherit(self, frames):
+    def _inherit(self, frames, reduced=False):
+        """``reduced``: the state comes out of reduce_volume (bounded by the total of the reduction; the ranks' parts are
+        disjoint or identical copies of ONE reduced volume).  Otherwise it is caller-injected state: counted like frames
+        integrated here -- it adds up across ranks."""
         bound = int(frames) if frames is not None else _lib.XFORM_PACKED_MAX_FRAMES + 1
-        self.frames_base = max(self.frames_base, bound)
+        if reduced:
+            self.frames_base = max(self.frames_base, bound)
+        else:
+            self.frames_injected += bound
 
     def pack_sum(self, keys, buf, stream=None):
         """``gs2m_tsdf_pack_sum``: accumulators of the blocks ``keys`` [n,3] in sum form -> ``buf`` [n,5,4096] f32."""

@@ -118,7 +118,7 @@ def _canonical_keys_gather(volume, group=None, always_collective: bool = False, 
     buf = volume.exchange_buffer("keys_send", (K + 2, 3), torch.int32, volume.exchange_device())
     volume.block_keys(out=buf, n=n_local)
     flags = int(bool(volume.replicated)) | (2 if volume.has_halo else 0)
-    head_local = torch.tensor([[n_local, int(ov), K], [int(volume.frames_local), int(volume.frames_base), flags]], dtype=torch.int32)
+    head_local = torch.tensor([[n_local, int(ov), K], [int(volume.frames_local + volume.frames_injected), int(volume.frames_base), flags]], dtype=torch.int32)
     buf[K:].copy_(head_local)
     gathered = volume.exchange_buffer("keys_recv", (world * (K + 2), 3), torch.int32, buf.device)
     _mark(marks, "keys: local list + header")
@@ -309,7 +309,7 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
         volume.reset()
     volume.status()
     _mark(marks, "reset + unpack + status")
-    volume.frames_base, volume.frames_local = frames_total, 0     # every weight of the reduced state is bounded by the total
+    volume.frames_base, volume.frames_local, volume.frames_injected = frames_total, 0, 0     # every weight of the reduced state is bounded by the total
     volume.replicated = collective and not scatter and world > 1
     return dict(n_blocks_union=n, bytes_per_rank=nbytes, keys=keys, owned=(lo, hi), collectives=n_coll, mode=mode,
                 per=(n_pad // world if scatter else n), seconds=time.perf_counter() - t0,

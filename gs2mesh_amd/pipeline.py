@@ -33,7 +33,7 @@ class RenderFusePipeline:
                              bin_workgroups=_lib.OPT_BIN_WORKGROUPS, bin_wg_threads=_lib.OPT_BIN_WG_THREADS)
 
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None = None,
-                 intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0, fuse_batch=1,
+                 intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0, *, fuse_batch=1,
                  pairs_per_launch: int = 1, spatial_order="auto", bg=(0.0, 0.0, 0.0), raster_options: dict | None = None):
         if inflight < 1:
             raise ValueError("inflight must be >= 1")

@@ -63,6 +63,28 @@ def main():
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), refused=1)
         dist.destroy_process_group()
         return
+    if "checkpoint" in opts:
+        # the SAME state injected on every rank (one checkpoint loaded everywhere) with an honest bound of 600 frames: the
+        # bounds ADD UP across ranks (2 x 600 > 1023), so "auto" must take the f32 payload -- with max() over the ranks (round 4)
+        # it took the packed form and the 10-bit weight field carried into the colour sum
+        import torch
+        from gs2mesh_amd import _lib
+        k0 = torch.tensor([[0, 0, 0]], dtype=torch.int32)
+        b0 = torch.zeros((1, 5, 4096), dtype=torch.float32)
+        b0[0, 1, 7] = 600.0
+        b0[0, 0, 7] = 0.25
+        b0[0, 2, 7] = 600.0 * 200
+        vol.unpack(k0, _lib.XFORM_RAW_F32, b0, frames=600)
+        info = reduce_volume(vol, mode="allreduce", payload="auto", algo=algo)
+        assert info["payload"] == "f32" and info["frames_total"] >= 600 * world, info
+        keys, tsdf, weight, rgb = vol.download()
+        i = [tuple(k) for k in keys.tolist()].index((0, 0, 0))
+        flat = weight[i].reshape(-1)
+        assert flat.max() >= 600.0 * world and int(rgb[i].reshape(3, -1)[0].max()) >= 600 * 200 * world
+        dist.barrier()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), refused=1)
+        dist.destroy_process_group()
+        return
     if "window=mismatch" in opts:
         try:
             reduce_volume(vol, mode="reduce_scatter", payload=payload, algo=algo)

@@ -136,6 +136,13 @@ def test_a_pack_overflow_on_one_rank_raises_on_every_rank(tmp_path):
         assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
 
 
+def test_state_injected_on_every_rank_adds_up_in_the_weight_bound(tmp_path):
+    """one checkpoint loaded on every rank -- the injected bounds add up, `auto` falls back to the f32 payload."""
+    run_world(tmp_path, 2, "allreduce", "checkpoint")
+    for rank in range(2):
+        assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
+
+
 def test_mismatching_exchange_windows_are_refused_on_every_rank(tmp_path):
     run_world(tmp_path, 2, "reduce_scatter", "window=mismatch")
     for rank in range(2):
