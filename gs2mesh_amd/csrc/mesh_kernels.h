@@ -45,6 +45,9 @@ GS2M_DEVICE unsigned mesh_table_cell(unsigned long long* __restrict__ hkeys, uns
 // per-axis minimum of the soup's voxel indices (the keys are made relative to it): mins[3] start at INT_MAX
 GS2M_KERNEL void __launch_bounds__(256)
 k_mesh_key_min(const int* __restrict__ edge_index, unsigned n, int* __restrict__ mins) {
+    __shared__ int s_min[3];
+    if (threadIdx.x < 3) s_min[threadIdx.x] = 0x7fffffff;
+    __syncthreads();
     int m0 = 0x7fffffff, m1 = 0x7fffffff, m2 = 0x7fffffff;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const int x = edge_index[4 * (size_t)i], y = edge_index[4 * (size_t)i + 1], z = edge_index[4 * (size_t)i + 2];
@@ -52,11 +55,12 @@ k_mesh_key_min(const int* __restrict__ edge_index, unsigned n, int* __restrict__
         m1 = y < m1 ? y : m1;
         m2 = z < m2 ? z : m2;
     }
-    if (m0 != 0x7fffffff) {
-        atomicMin(&mins[0], m0);
-        atomicMin(&mins[1], m1);
-        atomicMin(&mins[2], m2);
-    }
+    // one LDS atomic per thread, one global atomic per workgroup (every thread on the three global words: 0.56 ms for 2.6 M keys)
+    atomicMin(&s_min[0], m0);
+    atomicMin(&s_min[1], m1);
+    atomicMin(&s_min[2], m2);
+    __syncthreads();
+    if (threadIdx.x < 3 && s_min[threadIdx.x] != 0x7fffffff) atomicMin(&mins[threadIdx.x], s_min[threadIdx.x]);
 }
 
 // 62-bit key of soup vertex i: 20 bits per axis relative to mins, 2 bits axis; bad[0] |= 1 if the soup spans more than 2^20 voxels
@@ -227,13 +231,27 @@ k_mesh_uf_roots(unsigned n_tri, unsigned* __restrict__ parent, unsigned* __restr
         flag[t] = r == t ? 1u : 0u;
     }
 }
-// labels = rank of the root among the roots (pos = exclusive scan of flag); cluster sizes by atomics
+// labels = rank of the root among the roots (pos = exclusive scan of flag); cluster sizes by atomics, aggregated per wave: the
+// triangles of a wave mostly belong to ONE component (a scene is one big surface + debris), and 0.87 M single atomics on the
+// big component's counter took 10 ms
 GS2M_KERNEL void __launch_bounds__(256)
 k_mesh_uf_labels(unsigned n_tri, const unsigned* __restrict__ root, const unsigned* __restrict__ pos, int* __restrict__ labels,
                  unsigned long long* __restrict__ cluster_n) {
-    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < n_tri; t += gridDim.x * 256u) {
-        const unsigned l = pos[root[t]];
-        labels[t] = (int)l;
-        atomicAdd(&cluster_n[l], 1ull);
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned stride = gridDim.x * 256u;
+    const unsigned rounds = (n_tri + stride - 1u) / stride;      // the same for every lane: the ballots below are collectives
+    for (unsigned r = 0; r < rounds; ++r) {
+        const unsigned t = r * stride + blockIdx.x * 256u + threadIdx.x;
+        const bool have = t < n_tri;
+        const unsigned l = have ? pos[root[t]] : 0xffffffffu;
+        if (have) labels[t] = (int)l;
+        unsigned long long todo = gs2m_ballot(have ? 1 : 0);
+        while (todo != 0ull) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned ll = gs2m_shfl(l, leader);
+            const unsigned long long same = gs2m_ballot(have && l == ll ? 1 : 0);
+            if (lane == leader) atomicAdd(&cluster_n[ll], (unsigned long long)gs2m_popc64(same));
+            todo &= ~same;
+        }
     }
 }
