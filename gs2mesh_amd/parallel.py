@@ -316,6 +316,18 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
                 payload=("packed" if packed else "f32"), algo=(algo if scatter else "rccl"), frames_total=frames_total)
 
 
+def exchange_window_from_cameras(camera_centers, max_depth: float, voxel_length: float, block: int = 16):
+    """Window of block indices for `ScalableTSDFVolume.set_exchange_window` that covers everything the given cameras can put
+    into the volume: the bounding box of the camera centres grown by the depth truncation (TSDF.run: baseline x
+    TSDF_max_depth_baselines / TSDF_scale, tsdf_utils.py:86) plus one block.  Every rank knows every pose (views are sharded by
+    index), so every rank computes the same window without talking to the others.  -> (lo[3], dim[3])"""
+    c = np.asarray(camera_centers, np.float64).reshape(-1, 3)
+    unit = float(voxel_length) * block
+    lo = np.floor((c.min(axis=0) - max_depth) / unit).astype(np.int64) - 1
+    hi = np.floor((c.max(axis=0) + max_depth) / unit).astype(np.int64) + 1
+    return tuple(int(x) for x in lo), tuple(int(x) for x in (hi - lo + 1))
+
+
 def _neighbour_index(packed_sorted: torch.Tensor, keys: torch.Tensor, d):
     """Index in the canonical list of block key + d for every key (-1 where it is not allocated anywhere)."""
     q = _pack_keys(keys + torch.tensor(d, dtype=torch.int32, device=keys.device))

@@ -4,7 +4,7 @@ the sorted set union -- the properties every rank relies on to build the SAME li
 import numpy as np
 import torch
 
-from gs2mesh_amd.parallel import _SENTINEL, _lex_unique, _pack_keys, _unpack_keys, shard_range
+from gs2mesh_amd.parallel import _SENTINEL, _lex_unique, _pack_keys, _unpack_keys, exchange_window_from_cameras, shard_range
 
 B = 1 << 20
 
@@ -49,3 +49,18 @@ def test_shard_range_is_contiguous_balanced_and_complete():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_exchange_window_from_cameras_covers_every_reachable_block():
+    rng = np.random.default_rng(9)
+    centres = rng.normal(size=(40, 3)) * 3.0 + np.array([120.0, -45.0, 7.0])        # a scene far from the origin (DTU-like units)
+    voxel, max_depth = 0.02, 2.5
+    lo, dim = exchange_window_from_cameras(centres, max_depth, voxel)
+    unit = voxel * 16
+    # any point within max_depth (+ truncation slack of half a block) of any camera falls into the window
+    pts = centres[rng.integers(0, 40, 5000)] + rng.uniform(-1, 1, (5000, 3)) * max_depth
+    b = np.floor(pts / unit).astype(np.int64)
+    assert (b >= np.array(lo)).all() and (b < np.array(lo) + np.array(dim)).all()
+    assert max(dim) < 2 * (6 * 3.0 + 2 * max_depth) / unit          # and it is not absurdly large
+    # order of the cameras does not matter: every rank gets the same window
+    assert exchange_window_from_cameras(centres[::-1], max_depth, voxel) == (lo, dim)
