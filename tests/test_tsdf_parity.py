@@ -333,3 +333,37 @@ def test_batch_integrate_is_bit_identical_to_frame_by_frame(backend, color, use_
     np.testing.assert_array_equal(tb[order], ts)
     np.testing.assert_array_equal(cb[order], cs)
     compare(bat, ref, color=color)
+
+
+def test_round5_entry_points_refuse_bad_arguments(backend):
+    """Error behaviour of the new C-ABI functions (block map, replace, device mesh): non-zero return + a message, no crash."""
+    import ctypes as C
+    from gs2mesh_amd import _lib
+    be = backend
+    vol = ScalableTSDFVolume(2.0 / 96, 0.1, max_blocks=64, lib=be.lib)
+    lib = be.lib
+    dim = (C.c_int32 * 3)(4, 4, 4)
+    lo = (C.c_int32 * 3)(0, 0, 0)
+    bad_dim = (C.c_int32 * 3)(4, 0, 4)
+    assert lib.gs2m_tsdf_map_bytes(dim, 2) == 64 + 32 + 16 and lib.gs2m_tsdf_map_bytes(bad_dim, 2) == -1 and lib.gs2m_tsdf_map_bytes(dim, 0) == -1
+    cells = be.dev(np.zeros(64 + 32 + 16, np.uint8))
+    from gs2mesh_amd.rasterizer import _ptr
+    assert lib.gs2m_tsdf_block_map(vol._h, lo, dim, 2, 2, 0, 0, 0, _ptr(cells), None) != 0          # rank >= world
+    assert b"block_map" in lib.gs2m_last_error()
+    assert lib.gs2m_tsdf_block_map(vol._h, lo, bad_dim, 0, 2, 0, 0, 0, _ptr(cells), None) != 0
+    assert lib.gs2m_tsdf_block_map(vol._h, lo, dim, 0, 2, -1, 0, 0, _ptr(cells), None) != 0          # negative frame count
+    hdr = (C.c_uint8 * 48)()
+    assert lib.gs2m_tsdf_map_keys(vol._h, lo, dim, 2, _ptr(cells), None, 5, hdr, None) != 0           # keys missing
+    with pytest.raises(ValueError):
+        vol.set_exchange_window((0, 0, 0), (0, 1, 1))
+    k = be.dev(np.zeros((1, 3), np.int32))
+    assert lib.gs2m_tsdf_replace(vol._h, _ptr(k), 65, _lib.XFORM_RAW_F32, None, None, None) != 0     # more keys than the pool holds
+    assert lib.gs2m_tsdf_replace(vol._h, _ptr(k), 1, _lib.XFORM_RAW_F32, None, None, None) != 0      # no buffer
+    nv, nt = C.c_int64(-1), C.c_int64(-1)
+    assert lib.gs2m_tsdf_extract_mesh(vol._h, None, C.byref(nv), C.byref(nt)) == 0 and nv.value == 0 and nt.value == 0   # empty volume
+    assert lib.gs2m_tsdf_extract_mesh(vol._h, None, None, C.byref(nt)) != 0
+    assert lib.gs2m_tsdf_mesh_copy(vol._h, None, None, None, None, None) == 0                      # nothing cached: a no-op
+    nc = C.c_int64(-1)
+    assert lib.gs2m_mesh_cluster(0, None, -1, None, None, None, C.byref(nc)) != 0
+    assert lib.gs2m_mesh_cluster(0, None, 0, None, None, None, C.byref(nc)) == 0 and nc.value == 0
+    assert lib.gs2m_mesh_cluster(0, None, 3, None, None, None, C.byref(nc)) != 0
