@@ -213,6 +213,7 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
         case GS2M_OPT_BLEND_PROFILE:
             r->opt_blend_profile = value != 0;
             if (value && !r->d_blend_prof) {
+                HIPCHK(hipSetDevice(r->device));
                 HIPCHK(hipMalloc((void**)&r->d_blend_prof, 64 * 16 * sizeof(unsigned long long)));   // 64 copies, one per 128 B
                 HIPCHK(hipMemset(r->d_blend_prof, 0, 64 * 16 * sizeof(unsigned long long)));
             }
