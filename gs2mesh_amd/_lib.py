@@ -33,7 +33,7 @@ class Gaussians(C.Structure):
                 ("xyz", vp), ("scales", vp), ("rotations", vp), ("opacities", vp), ("shs", vp), ("shs_rest", vp)]
 
 
-ABI_VERSION = 401   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
+ABI_VERSION = 600   # GS2M_VERSION of include/gs2mesh_amd.h this binding was written against
 OPT_EXACT_TILE_CULL = 1
 OPT_BLEND_VARIANT = 2
 OPT_TILE_ROWS = 5
@@ -87,6 +87,7 @@ _PROTOS = {
     "gs2m_tsdf_status": (i32, [vp, vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]),
     "gs2m_tsdf_download": (i32, [vp, vp, i64, vp, vp, vp, vp]),
     "gs2m_tsdf_block_keys": (i32, [vp, i64, vp, vp]),
+    "gs2m_tsdf_flags_device": (i32, [vp, vp, vp]),
     "gs2m_tsdf_pack_sum": (i32, [vp, vp, i64, vp, vp]),
     "gs2m_tsdf_unpack_sum": (i32, [vp, vp, i64, vp, i32, vp]),
     "gs2m_tsdf_pack": (i32, [vp, vp, i64, i32, vp, vp, vp]),
@@ -164,6 +165,12 @@ class DeviceMemory:
     def download(self, t):
         """device buffer -> numpy"""
         return t.detach().cpu().numpy()
+
+    def current_stream(self, device):
+        """the stream torch is enqueueing on for ``device``: calls of the C ABI that touch buffers torch just created (zero
+        fills) or that must follow work the caller queued go on it, not on the NULL stream"""
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.buffer_device(device)).cuda_stream)
 
 
 MEMORY = DeviceMemory()

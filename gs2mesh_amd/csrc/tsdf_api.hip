@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/gs2mesh_amd.h"
@@ -38,6 +39,9 @@ struct gs2m_tsdf {
     int* mesh_e = nullptr;         // [mesh_nv][4]
     int* mesh_tri = nullptr;       // [mesh_nt][3]
     int64_t mesh_nv = 0, mesh_nt = 0;
+    size_t mesh_cap_v = 0, mesh_cap_t = 0;   // capacities (vertices / triangles) of the cached-mesh arrays: grow-only
+    char* mesh_scratch = nullptr;            // grow-only arena of the extraction's temporaries (soup, weld table, scan)
+    size_t mesh_scratch_cap = 0;
     int timing = 0;
     struct EvPair {
         int stage;
@@ -212,6 +216,7 @@ extern "C" int gs2m_tsdf_destroy(gs2m_tsdf* t) {
     (void)hipFree(t->d_mc);
     (void)hipFree(t->d_blk_tris);
     (void)hipFree(t->d_ntri);
+    (void)hipFree(t->mesh_scratch);
     (void)hipFree(t->mesh_v);
     (void)hipFree(t->mesh_c);
     (void)hipFree(t->mesh_e);
@@ -460,6 +465,16 @@ extern "C" int gs2m_tsdf_status(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_blo
     return 0;
 }
 
+extern "C" int gs2m_tsdf_flags_device(gs2m_tsdf* t, uint32_t* flags_dev, gs2m_stream stream) {
+    if (!t || !flags_dev) {
+        gs2m_set_error("gs2m_tsdf_flags_device: NULL argument");
+        return 1;
+    }
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipMemcpyAsync(flags_dev, t->V.counters + 2, sizeof(unsigned), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int gs2m_tsdf_block_keys(gs2m_tsdf* t, int64_t n, int32_t* keys, gs2m_stream stream) {
     if (!t || (n > 0 && !keys) || n < 0 || n > (int64_t)t->V.max_blocks) {
         gs2m_set_error("gs2m_tsdf_block_keys: bad argument");
@@ -604,8 +619,12 @@ extern "C" int gs2m_tsdf_unpack(gs2m_tsdf* t, const int32_t* keys, int64_t n, in
 
 extern "C" int gs2m_tsdf_replace(gs2m_tsdf* t, const int32_t* keys, int64_t n, int form, const float* buf_f32, const int64_t* buf_i64,
                                  gs2m_stream stream) {
-    if (!t || n < 0 || n > (int64_t)t->V.max_blocks || (n > 0 && (!keys || !buf_f32))) {
+    if (!t || n < 0 || (n > 0 && (!keys || !buf_f32))) {
         gs2m_set_error("gs2m_tsdf_replace: bad argument");
+        return 1;
+    }
+    if (n > (int64_t)t->V.max_blocks) {
+        gs2m_set_error("gs2m_tsdf_replace: block pool exhausted (%lld blocks to place, max_blocks = %u)", (long long)n, t->V.max_blocks);
         return 1;
     }
     HIPCHK(hipSetDevice(t->device));
@@ -613,7 +632,11 @@ extern "C" int gs2m_tsdf_replace(gs2m_tsdf* t, const int32_t* keys, int64_t n, i
     // exactly the slots [0, n) to n distinct in-range keys), then the unpack
     if (zero_state(t, (hipStream_t)stream, false, n)) return 1;
     if (n == 0) return 0;
-    return gs2m_tsdf_unpack(t, keys, n, form, buf_f32, buf_i64, 0, stream);
+    if (gs2m_tsdf_unpack(t, keys, n, form, buf_f32, buf_i64, 0, stream)) return 1;
+    // keys that repeat / lie outside the key range / do not fit the hash table leave slots [counters[0], n) un-handed-out AND
+    // un-cleared: cleared on the device (no host read; a no-op for n distinct in-range keys)
+    gs2m_launch_tsdf_clear_gap((hipStream_t)stream, t->V, (unsigned)n);
+    return 0;
 }
 
 extern "C" int gs2m_tsdf_pack_sum(gs2m_tsdf* t, const int32_t* keys, int64_t n, float* buf, gs2m_stream stream) {
@@ -672,27 +695,53 @@ extern "C" int gs2m_tsdf_extract_indexed(gs2m_tsdf* t, gs2m_stream stream, int64
 
 // ---- device-side mesh: extraction + welding, connected components ----------------------------------------------------------------
 namespace {
-struct DevBuf {      // scoped device allocation of the one-off mesh passes
-    void* p = nullptr;
-    ~DevBuf() { (void)hipFree(p); }
-    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
-    template <typename T> T* as() { return static_cast<T*>(p); }
+// Grow-only scratch arena of the mesh passes: sub-buffers are carved out of ONE allocation that survives the call (round 5
+// hipMalloc'ed / hipFree'd ten temporaries per call: bench `cluster_ms` 69 for 0.9 ms of kernels).
+struct Arena {
+    char** p;
+    size_t* cap;
+    size_t used = 0;
+    Arena(char** p_, size_t* cap_) : p(p_), cap(cap_) {}
+    static size_t pad(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    bool reserve(size_t bytes) {          // total of pad(size) over the buffers about to be taken
+        used = 0;
+        if (bytes <= *cap && *p) return true;
+        (void)hipFree(*p);                // synchronises: nothing of an earlier call is in flight
+        *p = nullptr;
+        *cap = 0;
+        const size_t n = bytes + bytes / 8 + 256;
+        if (hipMalloc((void**)p, n) != hipSuccess) return false;
+        *cap = n;
+        return true;
+    }
+    template <typename T> T* take(size_t count) {
+        T* r = reinterpret_cast<T*>(*p + used);
+        used += pad(sizeof(T) * count);
+        return r;
+    }
 };
 unsigned pow2_at_least(unsigned long long n) {
     unsigned c = 1024u;
     while ((unsigned long long)c < n && c < 0x80000000u) c <<= 1;
     return c;
 }
+// gs2m_mesh_cluster has no handle: one arena per device, used under a lock (the call synchronises before it returns)
+struct DeviceScratch {
+    char* p = nullptr;
+    size_t cap = 0;
+};
+DeviceScratch g_cluster_scratch[64];
+std::mutex g_cluster_lock;
 }  // namespace
 
-static void drop_mesh(gs2m_tsdf* t) {
-    (void)hipFree(t->mesh_v);
-    (void)hipFree(t->mesh_c);
-    (void)hipFree(t->mesh_e);
-    (void)hipFree(t->mesh_tri);
-    t->mesh_v = t->mesh_c = nullptr;
-    t->mesh_e = t->mesh_tri = nullptr;
-    t->mesh_nv = t->mesh_nt = 0;
+// forget the cached mesh (its arrays stay allocated: grow-only, freed with the handle)
+static void drop_mesh(gs2m_tsdf* t) { t->mesh_nv = t->mesh_nt = 0; }
+template <typename T>
+static bool grow(T** p, size_t have, size_t need) {     // caller updates its capacity on success
+    if (need <= have && *p) return true;
+    (void)hipFree(*p);
+    *p = nullptr;
+    return hipMalloc((void**)p, sizeof(T) * (need + need / 8 + 16)) == hipSuccess;
 }
 
 extern "C" int gs2m_tsdf_extract_mesh(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_vertices, int64_t* n_triangles) {
@@ -714,50 +763,64 @@ extern "C" int gs2m_tsdf_extract_mesh(gs2m_tsdf* t, gs2m_stream stream, int64_t*
     const unsigned n = (unsigned)(3 * nt);
     const unsigned cap = pow2_at_least(2ull * n);
     const unsigned m = (n + 4095u) / 4096u;
-    DevBuf soup_v, soup_c, soup_e, hkeys, hfirst, cell_of, flag, pos, scratch, small;
-    if (!soup_v.alloc(sizeof(double) * 3 * (size_t)n) || !soup_c.alloc(sizeof(double) * 3 * (size_t)n) || !soup_e.alloc(sizeof(int) * 4 * (size_t)n) ||
-        !hkeys.alloc(sizeof(unsigned long long) * (size_t)cap) || !hfirst.alloc(sizeof(unsigned) * (size_t)cap) ||
-        !cell_of.alloc(sizeof(unsigned) * (size_t)n) || !flag.alloc(sizeof(unsigned) * (size_t)n) || !pos.alloc(sizeof(unsigned) * (size_t)n) ||
-        !scratch.alloc(sizeof(unsigned) * ((size_t)m + 2)) || !small.alloc(sizeof(int) * 4) ||
-        hipMalloc((void**)&t->mesh_tri, sizeof(int) * (size_t)n) != hipSuccess) {
+    Arena A(&t->mesh_scratch, &t->mesh_scratch_cap);
+    const size_t need = 2 * Arena::pad(sizeof(double) * 3 * (size_t)n) + Arena::pad(sizeof(int) * 4 * (size_t)n) +
+                        Arena::pad(sizeof(unsigned long long) * (size_t)cap) + Arena::pad(sizeof(unsigned) * (size_t)cap) +
+                        3 * Arena::pad(sizeof(unsigned) * (size_t)n) + Arena::pad(sizeof(unsigned) * ((size_t)m + 2)) + Arena::pad(sizeof(int) * 4);
+    const bool tri_ok = grow(&t->mesh_tri, t->mesh_cap_t, (size_t)n);
+    if (tri_ok && (size_t)n > t->mesh_cap_t) t->mesh_cap_t = (size_t)n + (size_t)n / 8 + 16;
+    if (!tri_ok || !A.reserve(need)) {
         gs2m_set_error("gs2m_tsdf_extract_mesh: out of device memory for %lld triangles", (long long)nt);
+        if (!tri_ok) t->mesh_cap_t = 0;
         drop_mesh(t);
         return 1;
     }
+    double* soup_v = A.take<double>(3 * (size_t)n);
+    double* soup_c = A.take<double>(3 * (size_t)n);
+    int* soup_e = A.take<int>(4 * (size_t)n);
+    unsigned long long* hkeys = A.take<unsigned long long>(cap);
+    unsigned* hfirst = A.take<unsigned>(cap);
+    unsigned* cell_of = A.take<unsigned>(n);
+    unsigned* flag = A.take<unsigned>(n);
+    unsigned* pos = A.take<unsigned>(n);
+    unsigned* scratch = A.take<unsigned>((size_t)m + 2);
+    int* small = A.take<int>(4);
     int64_t nb = 0;
     if (gs2m_tsdf_status(t, stream, &nb, nullptr, nullptr)) return 1;
     gs2m_launch_mc_emit(st, t->V, t->d_mc, (unsigned)nb, t->d_blk_tris, (unsigned long long)nt, t->voxel_length, t->unit_length,
-                        soup_v.as<double>(), soup_c.as<double>(), soup_e.as<int>());
+                        soup_v, soup_c, soup_e);
     const int init[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0};      // mins[3], bad
-    HIPCHK(hipMemcpyAsync(small.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
-    HIPCHK(hipMemsetAsync(hfirst.p, 0xff, sizeof(unsigned) * (size_t)cap, st));
-    // the compact arrays cannot be sized before the scan: first the flags, the scan and its total, then the allocation and the emit
+    HIPCHK(hipMemcpyAsync(small, init, sizeof(init), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(hkeys, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
+    HIPCHK(hipMemsetAsync(hfirst, 0xff, sizeof(unsigned) * (size_t)cap, st));
+    // the compact arrays cannot be sized before the scan: first the flags, the scan and its total, then the (grow-only) arrays and the emit
     {
-        int* mins = small.as<int>();
+        int* mins = small;
         unsigned* bad = reinterpret_cast<unsigned*>(mins + 3);
-        gs2m_launch_mesh_weld_count(st, n, soup_e.as<int>(), mins, hkeys.as<unsigned long long>(), hfirst.as<unsigned>(), cap, cell_of.as<unsigned>(),
-                                    flag.as<unsigned>(), pos.as<unsigned>(), scratch.as<unsigned>(), bad);
+        gs2m_launch_mesh_weld_count(st, n, soup_e, mins, hkeys, hfirst, cap, cell_of, flag, pos, scratch, bad);
         unsigned total = 0;
         int hb[4];
-        HIPCHK(hipMemcpyAsync(&total, scratch.as<unsigned>() + m, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(hb, small.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&total, scratch + m, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hb, small, sizeof(hb), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (hb[3]) {
             gs2m_set_error("gs2m_tsdf_extract_mesh: the surface spans more than 2^20 voxels along an axis (62-bit weld key)");
             drop_mesh(t);
             return 1;
         }
-        if (hipMalloc((void**)&t->mesh_v, sizeof(double) * 3 * (size_t)total) != hipSuccess ||
-            hipMalloc((void**)&t->mesh_c, sizeof(double) * 3 * (size_t)total) != hipSuccess ||
-            hipMalloc((void**)&t->mesh_e, sizeof(int) * 4 * (size_t)total) != hipSuccess) {
-            gs2m_set_error("gs2m_tsdf_extract_mesh: out of device memory for %u vertices", total);
-            drop_mesh(t);
-            return 1;
+        const size_t nv3 = 3 * (size_t)total, nv4 = 4 * (size_t)total;
+        if (nv4 > t->mesh_cap_v) {
+            const bool ok = grow(&t->mesh_v, 0, nv3) && grow(&t->mesh_c, 0, nv3) && grow(&t->mesh_e, 0, nv4);
+            t->mesh_cap_v = ok ? nv4 : 0;
+            if (!ok) {
+                gs2m_set_error("gs2m_tsdf_extract_mesh: out of device memory for %u vertices", total);
+                drop_mesh(t);
+                return 1;
+            }
         }
-        gs2m_launch_mesh_weld_emit(st, n, hfirst.as<unsigned>(), cell_of.as<unsigned>(), pos.as<unsigned>(), soup_v.as<double>(),
-                                   t->V.has_color ? soup_c.as<double>() : nullptr, soup_e.as<int>(), t->mesh_v, t->mesh_c, t->mesh_e, t->mesh_tri);
-        HIPCHK(hipStreamSynchronize(st));     // the scoped temporaries are freed on return
+        gs2m_launch_mesh_weld_emit(st, n, hfirst, cell_of, pos, soup_v, t->V.has_color ? soup_c : nullptr, soup_e, t->mesh_v, t->mesh_c,
+                                   t->mesh_e, t->mesh_tri);
+        HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         t->mesh_nv = (int64_t)total;
         t->mesh_nt = nt;
@@ -797,20 +860,32 @@ extern "C" int gs2m_mesh_cluster(int device, gs2m_stream stream, int64_t n_trian
     const unsigned nt = (unsigned)n_triangles;
     const unsigned cap = pow2_at_least(6ull * nt);
     const unsigned m = (nt + 4095u) / 4096u;
-    DevBuf hkeys, hval, parent, root, flag, pos, scratch;
-    if (!hkeys.alloc(sizeof(unsigned long long) * (size_t)cap) || !hval.alloc(sizeof(unsigned) * (size_t)cap) || !parent.alloc(sizeof(unsigned) * (size_t)nt) ||
-        !root.alloc(sizeof(unsigned) * (size_t)nt) || !flag.alloc(sizeof(unsigned) * (size_t)nt) || !pos.alloc(sizeof(unsigned) * (size_t)nt) ||
-        !scratch.alloc(sizeof(unsigned) * ((size_t)m + 2))) {
+    if (device < 0 || device >= 64) {
+        gs2m_set_error("gs2m_mesh_cluster: device %d not in 0..63", device);
+        return 1;
+    }
+    std::lock_guard<std::mutex> hold(g_cluster_lock);
+    Arena A(&g_cluster_scratch[device].p, &g_cluster_scratch[device].cap);
+    const size_t need = Arena::pad(sizeof(unsigned long long) * (size_t)cap) + Arena::pad(sizeof(unsigned) * (size_t)cap) +
+                        4 * Arena::pad(sizeof(unsigned) * (size_t)nt) + Arena::pad(sizeof(unsigned) * ((size_t)m + 2));
+    if (!A.reserve(need)) {
         gs2m_set_error("gs2m_mesh_cluster: out of device memory for %u triangles", nt);
         return 1;
     }
-    HIPCHK(hipMemsetAsync(hkeys.p, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
-    HIPCHK(hipMemsetAsync(hval.p, 0xff, sizeof(unsigned) * (size_t)cap, st));
+    unsigned long long* hkeys = A.take<unsigned long long>(cap);
+    unsigned* hval = A.take<unsigned>(cap);
+    unsigned* parent = A.take<unsigned>(nt);
+    unsigned* root = A.take<unsigned>(nt);
+    unsigned* flag = A.take<unsigned>(nt);
+    unsigned* pos = A.take<unsigned>(nt);
+    unsigned* scratch = A.take<unsigned>((size_t)m + 2);
+    HIPCHK(hipMemsetAsync(hkeys, 0xff, sizeof(unsigned long long) * (size_t)cap, st));
+    HIPCHK(hipMemsetAsync(hval, 0xff, sizeof(unsigned) * (size_t)cap, st));
     HIPCHK(hipMemsetAsync(cluster_n_triangles, 0, sizeof(int64_t) * (size_t)nt, st));
-    gs2m_launch_mesh_cluster(st, triangles, nt, hkeys.as<unsigned long long>(), hval.as<unsigned>(), cap, parent.as<unsigned>(), root.as<unsigned>(),
-                             flag.as<unsigned>(), pos.as<unsigned>(), scratch.as<unsigned>(), labels, reinterpret_cast<unsigned long long*>(cluster_n_triangles));
+    gs2m_launch_mesh_cluster(st, triangles, nt, hkeys, hval, cap, parent, root, flag, pos, scratch, labels,
+                             reinterpret_cast<unsigned long long*>(cluster_n_triangles));
     unsigned total = 0;
-    HIPCHK(hipMemcpyAsync(&total, scratch.as<unsigned>() + m, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&total, scratch + m, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     *n_clusters = (int64_t)total;

@@ -14,6 +14,7 @@ void gs2m_launch_tsdf_pack(hipStream_t st, unsigned n, const TsdfVolume& V, cons
 void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, const int* keys, int form, const float* buf,
                              const long long* ibuf, int halo);
 void gs2m_launch_tsdf_clear_from(hipStream_t st, const TsdfVolume& V, unsigned first);
+void gs2m_launch_tsdf_clear_gap(hipStream_t st, const TsdfVolume& V, unsigned upto);
 void gs2m_launch_tsdf_owned_keys(hipStream_t st, unsigned n, const TsdfVolume& V, int* keys);
 void gs2m_launch_tsdf_block_map(hipStream_t st, const TsdfVolume& V, const int* lo, const int* dim, unsigned char* cells, unsigned n_cells,
                                 unsigned flags, unsigned win_hash, int rank, unsigned frames_local, unsigned frames_base);

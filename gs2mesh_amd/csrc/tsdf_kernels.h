@@ -638,6 +638,30 @@ k_tsdf_clear_from(TsdfVolume V, unsigned first) {
     }
 }
 
+// gs2m_tsdf_replace, after its unpack: the unpack hands out slots [0, counters[0]) -- exactly [0, upto) for `upto` distinct in-range
+// keys, fewer when a key repeats, lies outside the key range or the hash table is full.  The slots it did NOT hand out,
+// [counters[0], upto), were skipped by k_tsdf_clear_from and still hold the previous volume's state: cleared here, on the device,
+// so that stale voxels never reappear in a block allocated later.  No work in the regular case (counters[0] == upto).
+GS2M_KERNEL void __launch_bounds__(256)
+k_tsdf_clear_gap(TsdfVolume V, unsigned upto) {
+    unsigned first = V.counters[0];
+    if (upto > V.max_blocks) upto = V.max_blocks;
+    const float4 z = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned slot = first + blockIdx.x; slot < upto; slot += gridDim.x) {
+        float4* t4 = reinterpret_cast<float4*>(V.tsdf + (size_t)slot * GS2M_TSDF_VOX);
+        float4* w4 = reinterpret_cast<float4*>(V.weight + (size_t)slot * GS2M_TSDF_VOX);
+        for (int i = (int)threadIdx.x; i < GS2M_TSDF_VOX / 4; i += 256) {
+            t4[i] = z;
+            w4[i] = z;
+        }
+        if (V.has_color) {
+            float4* c4 = reinterpret_cast<float4*>(V.rgb + (size_t)slot * 3 * GS2M_TSDF_VOX);
+            for (int i = (int)threadIdx.x; i < 3 * GS2M_TSDF_VOX / 4; i += 256) c4[i] = z;
+        }
+        if (threadIdx.x == 0) V.halo[slot] = 0;
+    }
+}
+
 // ---- multi-GPU exchange -----------------------------------------------------------------------
 // Exchange forms (GS2M_XFORM_*, include/gs2mesh_amd.h):
 //   0 SUM_F32     one fp32 buffer [n][5][4096]: planes wsum = tsdf * weight, weight, sum r, sum g, sum b -- counts and colour

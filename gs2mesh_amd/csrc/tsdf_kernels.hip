@@ -42,6 +42,9 @@ void gs2m_launch_tsdf_unpack(hipStream_t st, unsigned n, const TsdfVolume& V, co
 void gs2m_launch_tsdf_clear_from(hipStream_t st, const TsdfVolume& V, unsigned first) {
     GS2M_LAUNCH(k_tsdf_clear_from, dim3(1024), dim3(256), 0, st, V, first);
 }
+void gs2m_launch_tsdf_clear_gap(hipStream_t st, const TsdfVolume& V, unsigned upto) {
+    GS2M_LAUNCH(k_tsdf_clear_gap, dim3(256), dim3(256), 0, st, V, upto);
+}
 void gs2m_launch_tsdf_owned_keys(hipStream_t st, unsigned n, const TsdfVolume& V, int* keys) {
     GS2M_LAUNCH(k_tsdf_owned_keys, dim3((n + 255u) / 256u), dim3(256), 0, st, V, n, keys);
 }

@@ -271,11 +271,13 @@ class ScalableTSDFVolume:
         PCIe (vertices, colours, cut edges, triangle indices), and a device copy of the triangle indices stays attached for
         ``cluster_connected_triangles`` -> ``gs2mesh_amd.mesh.TriangleMesh``."""
         from .mesh import TriangleMesh
-        st = stream or C.c_void_p(0)
+        # torch's current stream unless the caller names one: the device buffers below are zero-filled by torch on it, and the
+        # integration work the caller queued there must be ordered before the extraction (ADVICE r5: not the NULL stream)
+        st = C.c_void_p(int(stream)) if stream is not None else _lib.MEMORY.current_stream(self.device)
         nv, nt = C.c_int64(0), C.c_int64(0)
         _lib.check(self._lib.gs2m_tsdf_extract_mesh(self._h, st, C.byref(nv), C.byref(nt)), self._lib)
         nv, nt = int(nv.value), int(nt.value)
-        self.status(stream)
+        self.status(st)
         if nt == 0:
             return TriangleMesh()
         verts, cols = np.empty((nv, 3), np.float64), np.empty((nv, 3), np.float64)
@@ -286,6 +288,7 @@ class ScalableTSDFVolume:
         _lib.check(self._lib.gs2m_tsdf_mesh_copy(self._h, st, None, None, None, _ptr(tri_dev)), self._lib)
         m = TriangleMesh(verts, tri, cols if self.color_type == TSDFVolumeColorType.RGB8 else None)
         m.edge_index = eidx                      # [n_vertices, 4]: Open3D's vertex keys
+        self.status(st)      # the device copy has landed (the clustering may be queued on another stream later)
         m.attach_device_triangles(tri_dev, self._lib, self.device)
         return m
 
@@ -371,7 +374,15 @@ class ScalableTSDFVolume:
         if reduced:
             self.frames_base = max(self.frames_base, bound)
         else:
-            self.frames_injected += bound
+            # unpack REPLACES the state of the blocks it names (k_tsdf_unpack), so within ONE volume the bounds of several
+            # calls do not add up -- a checkpoint loaded in chunks stays bounded by its frame count; what adds up
+            # is the injected state of DIFFERENT ranks (one checkpoint loaded everywhere), and gs2mesh_amd.parallel sums
+            # `frames_injected` across the ranks for exactly that reason
+            self.frames_injected = max(self.frames_injected, bound)
+
+    def flags_device(self, out, stream=None):
+        """``gs2m_tsdf_flags_device``: the overflow flag word of `status` into the device int32 tensor ``out`` [1], async."""
+        _lib.check(self._lib.gs2m_tsdf_flags_device(self._h, _ptr(out), _stream_of(out, stream)), self._lib)
 
     def pack_sum(self, keys, buf, stream=None):
         """``gs2m_tsdf_pack_sum``: accumulators of the blocks ``keys`` [n,3] in sum form -> ``buf`` [n,5,4096] f32."""

@@ -81,7 +81,7 @@ class TriangleMesh:
                                                               copy.deepcopy(self.triangle_normals, memo), self.edge_index.copy())
         return m                                   # the device attachment belongs to the original
 
-    def cluster_connected_triangles(self, lib=None, device=0):
+    def cluster_connected_triangles(self, lib=None, device=None):
         """-> (triangle_clusters[n_tri], cluster_n_triangles[n_clusters], cluster_area[n_clusters]); triangles are connected
         when they share an edge (Open3D ClusterConnectedTriangles; clusters numbered by their first triangle).  The components
         are found on the GPU (``gs2m_mesh_cluster``: union-find over an edge hash table) -- on the triangle indices the
@@ -98,12 +98,16 @@ class TriangleMesh:
         else:
             lib = lib if lib is not None else _lib.get()
             import torch
+            if device is None:      # the caller's current device, not device 0 (a rank whose GPU is not 0)
+                device = torch.cuda.current_device() if torch.cuda.is_available() else 0
             tri_dev = _lib.MEMORY.upload(np.ascontiguousarray(self.triangles, np.int32), torch.int32, device)
         labels_dev = _lib.MEMORY.zeros((n,), np.int32, device)
         count_dev = _lib.MEMORY.zeros((n,), np.int64, device)
         nc = C.c_int64(0)
-        _lib.check(lib.gs2m_mesh_cluster(int(device), C.c_void_p(0), n, _lib.MEMORY.ptr(tri_dev), _lib.MEMORY.ptr(labels_dev),
-                                         _lib.MEMORY.ptr(count_dev), C.byref(nc)), lib)
+        # torch's current stream: the zero fills above were queued on it (the NULL stream is not ordered against a
+        # non-blocking stream)
+        _lib.check(lib.gs2m_mesh_cluster(int(device), _lib.MEMORY.current_stream(device), n, _lib.MEMORY.ptr(tri_dev),
+                                         _lib.MEMORY.ptr(labels_dev), _lib.MEMORY.ptr(count_dev), C.byref(nc)), lib)
         labels = np.asarray(_lib.MEMORY.download(labels_dev), np.int32)
         counts = np.asarray(_lib.MEMORY.download(count_dev), np.int64)[: int(nc.value)].copy()
         v, t = self.vertices, self.triangles.astype(np.int64)

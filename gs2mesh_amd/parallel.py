@@ -166,6 +166,7 @@ def canonical_keys(volume, group=None, always_collective: bool = False, marks=No
         return _canonical_keys_gather(volume, group, always_collective, marks)
     K = int(volume.max_blocks)
     dev = volume.exchange_device()
+    _agree_on_window(volume, group, world, dev)
     nb = volume.map_bytes(world)
     cells = volume.exchange_buffer("block_map", (nb,), torch.uint8, dev)
     flags = int(bool(volume.replicated)) | (2 if volume.has_halo else 0)
@@ -194,7 +195,28 @@ def canonical_keys(volume, group=None, always_collective: bool = False, marks=No
     if n > kbuf.shape[0]:
         raise RuntimeError(f"reduce_volume: the union holds {n} blocks, more than the ranks' pools together")
     ov_any = sum((1 << b) for b in range(4) if head[1 + b])
-    return kbuf[:n], ov_any, 1, frames_total, bool(head[5]) and world > 1
+    # a copy: `kbuf` is the volume's persistent exchange buffer and the next reduction overwrites it in place, while the
+    # result dict of this one (`info["keys"]`: exchange_halo, owner bookkeeping) may be kept (a few KB .. MB)
+    return kbuf[:n].clone(), ov_any, 1, frames_total, bool(head[5]) and world > 1
+
+
+def _agree_on_window(volume, group, world, dev):
+    """The block-map all_reduce needs the SAME buffer size on every rank: windows of different `dim` (or volumes of different
+    `max_blocks`) would enter the collective with mismatched tensors -- a hang or undefined behaviour under RCCL before the
+    window hash in the reduced header could be checked.  One tiny fixed-size collective settles it, once per
+    (window, max_blocks, group): MAX over (x, -x) of the seven integers = their maximum and minimum over the ranks."""
+    key = (volume.exchange_window, int(volume.max_blocks), world, id(group))
+    if getattr(volume, "_window_agreed", None) == key or world <= 1:
+        return
+    lo, dim = volume.exchange_window
+    vals = [int(x) for x in (*lo, *dim, volume.max_blocks)]
+    t = torch.tensor(vals + [-x for x in vals], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    got = t.cpu().tolist()
+    if any(got[i] != -got[7 + i] for i in range(7)):
+        what = "max_blocks" if all(got[i] == -got[7 + i] for i in range(6)) else "exchange window (set_exchange_window)"
+        raise RuntimeError(f"reduce_volume: every rank must use the same {what}")
+    volume._window_agreed = key
 
 
 def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_collective: bool = False,
@@ -290,13 +312,15 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
         # corrupted (field-carry) sums reach every rank: the verdict is made global with one 4-byte MAX all_reduce AFTER the
         # payload collectives, and every rank raises together -- none goes on to unpack, none waits in a later collective
         # (exchange_halo) for a rank that left.
-        _, _, ov_pack = volume.status(raise_on_overflow=False)
-        bad = 1 if (ov_pack & 8) else 0
+        # (round 6: the flag word goes device -> device and is reduced there: ONE host read for the verdict instead of a status
+        # synchronisation followed by the read of the reduced flag)
+        flag = volume.exchange_buffer("pack_flags", (1,), torch.int32, dev)
+        volume.flags_device(flag)
         if collective and world > 1:
-            flag = torch.tensor([bad], dtype=torch.int32, device=dev)
+            flag &= 8
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
             n_coll += 1
-            bad = int(flag.item())
+        bad = int(flag.item()) & 8
         if bad:
             raise RuntimeError("reduce_volume: " + _OVERFLOW_TEXT[3][1] + " (on at least one rank) -- the reduced buffers are "
                                "invalid; use payload='f32'")

@@ -31,8 +31,11 @@
 extern "C" {
 #endif
 
-#define GS2M_VERSION 401 /* 0.4.0: round-4 ABI (masked streams / compositing stream / workgroup cap removed, tuning knobs
-                            as options, pack overflow status); the Python binding checks it at load time */
+#define GS2M_VERSION 600 /* 0.6.0: round-6 ABI = the round-4 ABI (401) + the round-5 entry points that 401 never counted
+                            (gs2m_tsdf_block_map / _map_keys / _map_bytes / _replace / _extract_mesh / _mesh_copy,
+                            gs2m_mesh_cluster, gs2m_raster_blend_cycles, GS2M_OPT_BLEND_MODE / _PROFILE) + round 6
+                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES / _BIN_AGGREGATE / _BLEND_PERSISTENT; blend mode 1
+                            removed).  The Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
 
@@ -337,6 +340,11 @@ int gs2m_tsdf_stage_times(gs2m_tsdf* t, gs2m_stream stream, double* total_ms, in
  * packed fields (weight > 1023 or a colour sum >= 2^18: the summed exchange buffers are invalid, use SUM_F32). */
 int gs2m_tsdf_status(gs2m_tsdf* t, gs2m_stream stream, int64_t* n_blocks,
                      int64_t* block_updates, int* overflow);
+
+/* The overflow flag word of gs2m_tsdf_status (bits 1 / 2 / 4 / 8) copied to a DEVICE word, asynchronously: lets a multi-GPU
+ * caller all-reduce the verdict of a pack on the device and pay ONE host read for it (gs2mesh_amd.parallel.reduce_volume)
+ * instead of a status synchronisation followed by the read of the reduced flag. */
+int gs2m_tsdf_flags_device(gs2m_tsdf* t, uint32_t* flags_dev, gs2m_stream stream);
 
 /* Copy allocated blocks to HOST (any pointer may be NULL): keys[n,3] (block index),
  * tsdf[n,4096], weight[n,4096] (voxel x*256+y*16+z, Open3D IndexOf), rgb_sum[n,4096,3] u32

@@ -60,6 +60,9 @@ class HostMemory(_lib.DeviceMemory):
     def download(self, t):
         return np.asarray(t)
 
+    def current_stream(self, device):
+        return C.c_void_p(0)
+
 
 def use_host_memory(on: bool):
     _lib.MEMORY = HostMemory() if on else _lib.DeviceMemory()

@@ -41,7 +41,11 @@ def main():
         # a 2^3-block window: most of the scene's blocks lie outside it -> every rank takes the gather path together
         vol.set_exchange_window((-1, -1, -1), (2, 2, 2))
     if "window=mismatch" in opts and rank == 1:
-        vol.set_exchange_window((-31, -32, -32), (64, 64, 64))      # same size (a collective needs that), other origin
+        vol.set_exchange_window((-31, -32, -32), (64, 64, 64))      # same size, other origin
+    if "window=mismatch_size" in opts and rank == 1:
+        # another SIZE: the block-map buffers would differ in length -- refused by the fixed-size agreement collective before the
+        # map all_reduce is entered (mismatched tensors in a collective hang or are undefined under RCCL)
+        vol.set_exchange_window((-32, -32, -32), (64, 32, 64))
     keys_via = "gather" if "keys=gather" in opts else "map"
     if "badpack" in opts:
         # state injected through the C API with a LYING frame bound on rank 0 only: one voxel weight of 2000 does not fit the
@@ -85,7 +89,7 @@ def main():
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), refused=1)
         dist.destroy_process_group()
         return
-    if "window=mismatch" in opts:
+    if "window=mismatch" in opts or "window=mismatch_size" in opts:
         try:
             reduce_volume(vol, mode="reduce_scatter", payload=payload, algo=algo)
             raise SystemExit("mismatching exchange windows were accepted")

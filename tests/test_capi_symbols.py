@@ -29,7 +29,7 @@ def test_hip_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/gs2mesh_amd.h but not exported"
     lib.gs2m_version.restype = ctypes.c_int
     from gs2mesh_amd import _lib as binding
-    assert lib.gs2m_version() == binding.ABI_VERSION == 401
+    assert lib.gs2m_version() == binding.ABI_VERSION == 600
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", path], capture_output=True, text=True)
     if out.returncode == 0 and out.stdout:
         pass  # informational only

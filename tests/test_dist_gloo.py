@@ -143,8 +143,9 @@ def test_state_injected_on_every_rank_adds_up_in_the_weight_bound(tmp_path):
         assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
 
 
-def test_mismatching_exchange_windows_are_refused_on_every_rank(tmp_path):
-    run_world(tmp_path, 2, "reduce_scatter", "window=mismatch")
+@pytest.mark.parametrize("opt", ["window=mismatch", "window=mismatch_size"])
+def test_mismatching_exchange_windows_are_refused_on_every_rank(tmp_path, opt):
+    run_world(tmp_path, 2, "reduce_scatter", opt)
     for rank in range(2):
         assert int(np.load(os.path.join(tmp_path, f"rank{rank}.npz"))["refused"]) == 1
 

@@ -261,6 +261,53 @@ def test_replace_equals_reset_plus_unpack_and_leaves_clean_slots(backend):
     assert np.array_equal(t0, t1[o]) and np.array_equal(w0, w1[o]) and np.array_equal(c0, c1[o])
 
 
+def test_replace_with_a_repeated_key_leaves_no_stale_slot_behind(backend):
+    """``gs2m_tsdf_replace`` skips clearing slots [0, n) because its unpack overwrites them -- but a key that repeats
+    (or lies outside the key range) takes no slot of its own, so the unpack hands out fewer than n and the slots above its count
+    kept the PREVIOUS volume's voxels, which reappeared in the next block allocated there.  The follow-up pass (k_tsdf_clear_gap)
+    clears them on the device: frames integrated afterwards must give what reset + unpack of the distinct keys gives."""
+    from gs2mesh_amd import _lib
+    be = backend
+    frs, K = frames(6, 128, 96, 140.0)
+    voxel, trunc = 2.0 / 96, 0.1
+    W, H, fx, fy, cx, cy = K
+    intr = PinholeCameraIntrinsic(W, H, fx, fy, cx, cy)
+    src, _ = run_both(be, frs[:4], K, voxel, trunc)
+    keys = np.unique(be.host(src.block_keys()), axis=0).astype(np.int32)
+    half = np.ascontiguousarray(keys[: len(keys) // 2])
+    dup = np.ascontiguousarray(np.concatenate([half, half[:3]]))         # three repeated keys: n = len(half) + 3 rows
+    buf = be.dev(np.zeros((len(dup), 5, 4096), np.float32))
+    src.pack(be.dev(dup), _lib.XFORM_RAW_F32, buf)
+    be.sync()
+    vols = []
+    for how in ("replace-with-repeats", "reset+unpack"):
+        v, _ = run_both(be, frs[:4], K, voxel, trunc)                    # more blocks in use than it is about to keep
+        if how == "reset+unpack":
+            v.reset()
+            v.unpack(be.dev(half), _lib.XFORM_RAW_F32, buf[: len(half)], frames=4)
+        else:
+            v.replace(be.dev(dup), _lib.XFORM_RAW_F32, buf, frames=4)
+        assert v.status()[0] == len(half)
+        for d, c, E in frs[4:]:
+            v.integrate(RGBDImage(be.dev(c), be.dev(d)), intr, E)
+        vols.append(v.download())
+    (k0, t0, w0, c0), (k1, t1, w1, c1) = vols
+    i1 = {tuple(k): i for i, k in enumerate(k1.tolist())}
+    assert set(map(tuple, k0.tolist())) == set(i1) and len(k0) > len(half)
+    o = np.array([i1[tuple(k)] for k in k0.tolist()])
+    assert np.array_equal(t0, t1[o]) and np.array_equal(w0, w1[o]) and np.array_equal(c0, c1[o])
+    # chunked injection into ONE volume does not add its bounds up (unpack replaces state)
+    v = ScalableTSDFVolume(voxel, trunc, max_blocks=len(keys) + 8, lib=be.lib)
+    for part in (half[: len(half) // 2], half[len(half) // 2:]):
+        pb = be.dev(np.zeros((len(part), 5, 4096), np.float32))
+        v.unpack(be.dev(np.ascontiguousarray(part)), _lib.XFORM_RAW_F32, pb, frames=4)
+    assert v.frames_integrated == 4
+    # the pool-exhausted case names itself
+    small = ScalableTSDFVolume(voxel, trunc, max_blocks=2, lib=be.lib)
+    with pytest.raises(RuntimeError, match="block pool exhausted"):
+        small.replace(be.dev(half[:3]), _lib.XFORM_RAW_F32, buf[:3], frames=4)
+
+
 def test_packed_exchange_form_flags_values_that_do_not_fit_its_fields(backend):
     """XFORM_SUM_PACKED holds w in 10 bits and the colour sums in 18: state injected through unpack_sum with larger
     weights (a C-API user, or a volume whose frame bound was lost) must not carry silently between the fields.
