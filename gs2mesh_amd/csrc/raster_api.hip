@@ -42,6 +42,7 @@ struct gs2m_raster {
     int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_pair_batch = 0;
     int opt_bin_workgroups = 256, opt_bin_wg_threads = 1024, opt_blend_mode = 2;   // tuning options (gs2m_raster_set_option)
     int opt_blend_profile = 0;
+    int opt_bin_lane_tiles = 4;     // rects of at most this many binning tiles are walked by their own lane (round 6)
     unsigned long long* d_blend_prof = nullptr;   // [GS2M_BLEND_PROF_COUNTERS] phase-cycle sums of the profile build (GS2M_OPT_BLEND_PROFILE)
     struct EvPair {
         int stage;
@@ -165,7 +166,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
         return 1;
     }
     switch (option) {
-        case GS2M_OPT_EXACT_TILE_CULL: r->opt_exact_cull = value != 0; return 0;
+        case GS2M_OPT_EXACT_TILE_CULL:
+            if (value < 0 || value > 2) {
+                gs2m_set_error("GS2M_OPT_EXACT_TILE_CULL must be 0, 1 or 2");
+                return 1;
+            }
+            r->opt_exact_cull = value;
+            return 0;
         case GS2M_OPT_BLEND_VARIANT:
             if (value != 0 && value != 4) {
                 gs2m_set_error("GS2M_OPT_BLEND_VARIANT must be 0 or 4");
@@ -209,6 +216,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
                 return 1;
             }
             r->opt_blend_mode = value;
+            return 0;
+        case GS2M_OPT_BIN_LANE_TILES:
+            if (value < 0 || value > 16) {
+                gs2m_set_error("GS2M_OPT_BIN_LANE_TILES must be 0 .. 16");
+                return 1;
+            }
+            r->opt_bin_lane_tiles = value;
             return 0;
         case GS2M_OPT_BLEND_PROFILE:
             r->opt_blend_profile = value != 0;
@@ -359,10 +373,10 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     // threads per counting / scatter workgroup: the chunk (<= 1024), halved until the wave staging fits next to the
     // tile cursors in the 160 KiB LDS (large images)
     int wg_threads = (gs2m_count_threads(chunk, r->opt_bin_wg_threads) + 63) / 64 * 64;
-    while (wg_threads > 64 && gs2m_scatter_lds_bytes(nv, tiles, wg_threads) > 160 * 1024)
+    while (wg_threads > 64 && (gs2m_scatter_lds_bytes(nv, tiles, wg_threads) > 160 * 1024 || gs2m_count_lds_bytes(nv, tiles, wg_threads) > 160 * 1024))
         wg_threads = (wg_threads / 2 + 63) / 64 * 64;  // stays a whole number of waves: the size checked is the size launched
     const size_t lds = gs2m_scatter_lds_bytes(nv, tiles, wg_threads);    // scatter: u32 cursors + wave staging
-    const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, wg_threads);    // count: u16 histogram + staging
+    const size_t lds_p = gs2m_count_lds_bytes(nv, tiles, wg_threads);    // count: u32 histogram + staging
     if (lds > 160 * 1024 || lds_p > 160 * 1024) {
         gs2m_set_error("image %dx%d: %d views x %d tiles do not fit the 160 KiB LDS tile cursors", W, H, nv, tiles);
         return 1;
@@ -389,7 +403,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     {
         StageTimer tm(r, st, GS2M_STAGE_COUNT);
         if (gs2m_launch_count_tiles(nv, pairs, n_wg, wg_threads, lds_p, st, recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tilemask,
-                                    cull_arg_p, g.ids != nullptr))
+                                    cull_arg_p, g.ids != nullptr, r->opt_bin_lane_tiles))
             return 1;
     }
     if (dbg_check(r, st, "count_tiles")) return 1;
@@ -406,7 +420,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     {
         StageTimer tm(r, st, GS2M_STAGE_SCATTER);
         if (gs2m_launch_scatter(nv, pairs, n_wg, wg_threads, lds, st, recs, g.P, r->d_cams, chunk, r->d_hist, r->d_tile_start,
-                                r->d_tilemask, r->d_keys, cap, cull_arg_s, g.ids, g.ids != nullptr))
+                                r->d_tilemask, r->d_keys, cap, cull_arg_s, g.ids, g.ids != nullptr, r->opt_bin_lane_tiles))
             return 1;
     }
     if (dbg_check(r, st, "scatter")) return 1;

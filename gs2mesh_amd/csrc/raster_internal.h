@@ -12,13 +12,13 @@ void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, Ca
                          int exact_cull, const CamUniform* host_cams);
 int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
-                            int exact_cull, int interleave);
+                            int exact_cull, int interleave, int lane_tiles);
 int gs2m_count_threads(int chunk, int max_threads);
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads);
 int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
-                        const int* ids, int interleave);
+                        const int* ids, int interleave, int lane_tiles);
 void gs2m_launch_pack_sh(hipStream_t st, int P, const float* shs, const float* shs_rest, float* packed, const int* order);
 void gs2m_launch_pack_model(hipStream_t st, int P, const int* order, const float* xyz, const float* scales, const float* rots,
                             const float* opac, float* p_xyz, float* p_scales, float* p_rots, float* p_opac, int* rank,

@@ -269,11 +269,18 @@ GS2M_DEVICE bool tile_may_contribute(float mx, float my, float ca, float cb, flo
     const float dx1 = mx - (float)(tx * GS2M_TILE);
     const float dy0 = my - (float)(ty * th + th - 1);
     const float dy1 = my - (float)(ty * th);
-    if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return true;
-    float qmin = edge_min_x(ca, cb, cc, rx, dy0, dx0, dx1);
-    qmin = fminf(qmin, edge_min_x(ca, cb, cc, rx, dy1, dx0, dx1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx0, dy0, dy1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx1, dy0, dy1));
+    const bool in_x = dx0 <= 0.0f && dx1 >= 0.0f, in_y = dy0 <= 0.0f && dy1 >= 0.0f;   // the centre's column / row of tiles
+    if (in_x && in_y) return true;
+    // Round 6: only the edges that FACE the centre are evaluated (two of the four, one when the centre lies in the tile's column
+    // or row).  q is convex with its minimum at the centre, outside the tile: the smallest level ellipse that touches the tile
+    // touches it in a point visible from the centre, i.e. on the vertical edge nearest in x (if the centre is outside the
+    // tile's column) or on the horizontal edge nearest in y (if outside its row); the far edges can only tie.  Half the
+    // arithmetic of the four-edge form (the counting kernel is vector-issue-bound); same decisions (oracle: same form).
+    const float ex = dx0 > 0.0f ? dx0 : dx1;      // d.x on the vertical edge facing the centre
+    const float ey = dy0 > 0.0f ? dy0 : dy1;      // d.y on the horizontal edge facing the centre
+    const float qv = edge_min_y(ca, cb, cc, ry, ex, dy0, dy1);
+    const float qh = edge_min_x(ca, cb, cc, rx, ey, dx0, dx1);
+    const float qmin = in_x ? qh : (in_y ? qv : fminf(qv, qh));
     return qmin <= thresh;
 }
 GS2M_DEVICE float cull_threshold(float opacity) {

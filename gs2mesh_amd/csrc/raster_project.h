@@ -14,24 +14,37 @@
 #pragma once
 #include "raster_math.h"
 
-// Workgroup-private tile histogram of k_count_tiles: two 16-bit counters per LDS word.  Tile t shares its word with tile
-// t + hw (hw = words per view = ceil(tiles / 2)), NOT with tile t + 1: the lanes of a wave walk ADJACENT tiles of the same
-// rect, and two neighbours in one word were a same-address atomic pair on every second lane (0.79 bank-conflict cycles per
-// LDS instruction, PMC round 2); now neighbouring tiles are neighbouring words = different banks.
-GS2M_DEVICE void hist_bump(unsigned* hh, int hw, int t) {
-    const bool hi = t >= hw;
-    atomicAdd(&hh[hi ? t - hw : t], hi ? 0x10000u : 1u);
-}
-GS2M_DEVICE unsigned hist_get(const unsigned* hh, int hw, int t) {
-    const bool hi = t >= hw;
-    return (hh[hi ? t - hw : t] >> (hi ? 16 : 0)) & 0xffffu;
-}
+// Workgroup-private tile histogram of k_count_tiles: one u32 counter per (view, tile) in LDS.  (Rounds 2-5 packed two 16-bit
+// counters per word to halve the LDS; the kernel runs one 1024-thread workgroup per CU either way -- the scatter kernel's u32
+// cursors set the LDS budget of the pair -- and the hi / lo select cost 4 of the 6 vector instructions of a bump in a kernel that
+// is vector-issue-bound.  Round 6 also measured, and dropped, wave-aggregated bumps (one atomic per run of neighbouring lanes
+// with the same tile) and 2 / 4 lane-interleaved copies of the histogram against the same-address serialisation of a spatially
+// ordered model's atomics: C3 count 29.7 -> 36.8 us (aggregated), 30.4 -> 29.6 (copies) -- profiles/r6_experiments.txt.)
+GS2M_DEVICE void hist_bump(unsigned* hh, int t) { atomicAdd(&hh[t], 1u); }
 
-// A rect of the binning grid that is one tile wide or one tile high and has at most GS2M_THIN_MAX tiles: handled by its own lane
-// in k_count_tiles and k_scatter (both must classify alike).
+// ---- which rects of the binning grid get what (k_count_tiles and k_scatter must agree on `tested`: it decides whether a
+// tile mask exists) ---------------------------------------------------------------------------------------------------------
+// cull = GS2M_OPT_EXACT_TILE_CULL: 0 = every tile of the (reference) rect is an instance; 1 = the rect is the bounding box of the
+// alpha >= 1/255 ellipse and every tile of a rect with corners (>= 2 x 2 tiles) is tested against the ellipse; 2 (round 6) = the
+// same, but rects of at most 4 tiles keep all their tiles -- the test only removes ~2 % of the instances of a small-splat
+// scene (C3: 3.85 M -> 3.77 M per eye) and was 60 % of the vector instructions of the counting kernel, which is VALU-issue-bound
+// (PMC round 5: 12 k vector instructions per wave, 0.8 of the SIMD's issue slots).  Rects of more than 64 tiles are walked by the
+// whole wave and test every tile.  A thin rect (one tile wide or high) is its own bounding box: never tested.
+GS2M_DEVICE bool gs2m_rect_tested(unsigned w, unsigned h, unsigned area, int cull) {
+    return cull != 0 && (area > 64u || (w >= 2u && h >= 2u && (cull == 1 || area > 4u)));
+}
+// A rect of the binning grid that is one tile wide or one tile high and has at most GS2M_THIN_MAX tiles (round 4).
 #define GS2M_THIN_MAX 4u
 GS2M_DEVICE bool gs2m_thin_rect(unsigned w, unsigned h, unsigned area) {
     return area != 0u && area <= GS2M_THIN_MAX && (w == 1u || h == 1u);
+}
+// Rects walked by THEIR OWN LANE (no staging, no item space): the thin ones and, round 6, every rect of at most `lane_max` tiles
+// (GS2M_OPT_BIN_LANE_TILES) -- in the counting kernel only when it is not tested (the test costs ~35 vector instructions per
+// tile: a lane running it 4 times in sequence lost to the staged walk, which spreads the tiles over the lanes; measured), in
+// the scatter kernel always (it replays the mask the counting pass wrote: a bit test per tile).
+#define GS2M_LANE_TILES_MAX 16
+GS2M_DEVICE bool gs2m_lane_rect(unsigned w, unsigned h, unsigned area, unsigned lane_max) {
+    return area != 0u && (area <= lane_max || gs2m_thin_rect(w, h, area));
 }
 
 struct ProjView {
@@ -408,40 +421,60 @@ struct CountIn {
     int x0, y0, x1, y1;
     bool ok;
 };
-// from the stored 16 x 16 tile rect (x0, y0, x1, y1) to rows of the binning grid (tiles of 16 x th pixels)
-GS2M_DEVICE void count_in_set(CountIn& c, int x0, int y0, int x1, int y1, int rows) {
-    c.ok = x1 > x0 && y1 > y0;
-    c.x0 = c.ok ? x0 : 0;
-    c.x1 = c.ok ? x1 : 0;
-    c.y0 = c.ok ? y0 / rows : 0;
-    c.y1 = c.ok ? (y1 + rows - 1) / rows : 0;
+// The tile rect of a record's binning part (16 x 16 tile units) in the binning grid (tiles of 16 x 16 * 2^rs pixels): rs = 0 / 1
+// (a shift: the signed divisions by `rows` this replaces were ~100 of the ~800 vector instructions of a C3 counting step).
+struct BinRect {
+    int x0, y0;
+    unsigned w, h, area;
+};
+GS2M_DEVICE BinRect bin_rect_of(const float4& c, int rs) {
+    const unsigned rect0 = __float_as_uint(c.z), rect1 = __float_as_uint(c.w);
+    const int x0 = (int)(rect0 & 0xffffu), x1 = (int)(rect1 & 0xffffu);
+    const int y0 = (int)(rect0 >> 16), y1 = (int)(rect1 >> 16);
+    const bool ok = x1 > x0 && y1 > y0;
+    BinRect r;
+    r.x0 = x0;
+    r.y0 = y0 >> rs;
+    r.w = ok ? (unsigned)(x1 - x0) : 0u;
+    r.h = ok ? (unsigned)(((y1 + (1 << rs) - 1) >> rs) - r.y0) : 0u;
+    r.area = r.w * r.h;
+    return r;
 }
 
 // The counting step for the 64 Gaussians of one wave step (wave collectives: EVERY lane calls it): balanced
-// (Gaussian, tile) expansion, the workgroup's LDS tile histogram, the kept-tile masks of the small rects.
+// (Gaussian, tile) expansion, the workgroup's LDS tile histogram, the kept-tile masks of the tested rects.
 template <int NV>
-GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, int P, unsigned* lhist, int hw, WaveStage* stage,
-                              unsigned long long* __restrict__ tilemask, int gx, int th, int exact_cull, int lane) {
+GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, int P, unsigned* lhist, int tiles, WaveStage* stage,
+                              unsigned long long* __restrict__ tilemask, int gx, int th, int cull, int lane, unsigned lane_max) {
     // ---- balanced (Gaussian, tile) expansion, one view at a time (wave collectives: every lane) ----
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         const unsigned w = (unsigned)(pv[v].x1 - pv[v].x0), h = (unsigned)(pv[v].y1 - pv[v].y0);
         const unsigned area = (valid && pv[v].ok) ? w * h : 0u;
         if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
-        unsigned* hh = lhist + v * hw;
+        unsigned* hh = lhist + v * tiles;
         const unsigned xy0 = (unsigned)pv[v].x0 | ((unsigned)pv[v].y0 << 16);
-        // ---- thin rects (one tile wide or one tile high, <= GS2M_THIN_MAX tiles; round 4): no corner to cut -- the exact test only
-        // runs for rects of >= 2 x 2 tiles -- so every tile is kept: the lane bumps its own tiles, no staging, no item space, no
-        // tile mask (k_scatter classifies the rect the same way and does not read one).  A 2 M-Gaussian scene of small splats is
-        // ~80 % thin rects (C3: count 68 -> see profiles/r4_experiments.txt); C2's splats span >= 2 x 2 tiles and take the
-        // balanced walk below as before.
-        const bool thin = gs2m_thin_rect(w, h, area);
-        if (thin) {
-            const int t0 = pv[v].y0 * gx + pv[v].x0, dt = w == 1u ? gx : 1;
-            for (unsigned t = 0; t < area; ++t) hist_bump(hh, hw, t0 + (int)t * dt);
+        const bool tested = gs2m_rect_tested(w, h, area, cull);
+        // ---- rects walked by their own lane: thin ones (round 4) and untested ones of <= lane_max tiles (round 6).  Every tile
+        // is kept: no staging, no item space, no tile mask.  A 2 M-Gaussian scene of small splats is 85 % thin + 14 % 2 x 2
+        // rects (C3, 16 x 32 binning tiles).
+        const bool lane_rect = !tested && gs2m_lane_rect(w, h, area, lane_max);
+        if (gs2m_ballot(lane_rect ? 1 : 0) != 0ull) {
+            // row-major walk with a running tile index (no multiplication per tile)
+            const unsigned area_l = lane_rect ? area : 0u;
+            int tile = pv[v].y0 * gx + pv[v].x0;
+            unsigned rx = 0u;
+            for (unsigned t = 0; t < area_l; ++t) {
+                hist_bump(hh, tile);
+                ++tile;
+                if (++rx == w) {
+                    rx = 0u;
+                    tile += gx - (int)w;
+                }
+            }
         }
-        // ---- small rects: flattened item space ----
-        const bool small = area != 0u && area <= 64u && !thin;
+        // ---- the other rects of <= 64 tiles: flattened item space ----
+        const bool small = area != 0u && area <= 64u && !lane_rect;
         const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
         if (smalls != 0ull) {
             const int k = gs2m_popc64(smalls & lanes_lt(lane));
@@ -454,14 +487,16 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
             if (lane < 2) stage->heads[128 + lane] = 0u;
             gs2m_wave_sync();
             if (small) {
-                stage->mx[k] = pv[v].mx;
-                stage->my[k] = pv[v].my;
-                stage->ca[k] = pv[v].ca;
-                stage->cb[k] = pv[v].cb;
-                stage->cc[k] = pv[v].cc;
-                stage->thr[k] = thr;
-                cull_slopes(pv[v].ca, pv[v].cb, pv[v].cc, stage->rx[k], stage->ry[k]);
-                stage->swh[k] = start | (w << 16) | (h << 24);
+                if (tested) {
+                    stage->mx[k] = pv[v].mx;
+                    stage->my[k] = pv[v].my;
+                    stage->ca[k] = pv[v].ca;
+                    stage->cb[k] = pv[v].cb;
+                    stage->cc[k] = pv[v].cc;
+                    stage->thr[k] = thr;
+                    cull_slopes(pv[v].ca, pv[v].cb, pv[v].cc, stage->rx[k], stage->ry[k]);
+                }
+                stage->swh[k] = start | (w << 16) | (h << 23) | (tested ? 0x80000000u : 0u);   // w, h <= 64: 7 bits each
                 stage->xy0[k] = xy0;
                 stage->mlo[k] = 0u;
                 stage->mhi[k] = 0u;
@@ -480,17 +515,17 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
                 unsigned li = 0u;
                 if (act) {
                     const unsigned swh = stage->swh[kk];
-                    const unsigned ow = (swh >> 16) & 0xffu, oh = swh >> 24;
+                    const unsigned ow = (swh >> 16) & 0x7fu;
                     li = item - (swh & 0xffffu);
                     unsigned rx, ry;
                     rect_coords(li, ow, gs2m_fast_rcp((float)ow), rx, ry);
                     const unsigned oxy = stage->xy0[kk];
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
                     keep = true;
-                    if (exact_cull && ow >= 2u && oh >= 2u)  // only rects with corners to cut
+                    if (swh & 0x80000000u)  // only tested rects (corners to cut)
                         keep = tile_may_contribute(stage->mx[kk], stage->my[kk], stage->ca[kk], stage->cb[kk],
                                                    stage->cc[kk], stage->rx[kk], stage->ry[kk], stage->thr[kk], tx, ty, th);
-                    if (keep) hist_bump(hh, hw, ty * gx + tx);
+                    if (keep) hist_bump(hh, ty * gx + tx);
                 }
                 // the first lane of each owner's run in this batch folds the run's keep bits into the owner's mask
                 const unsigned long long kept = gs2m_ballot(keep ? 1 : 0);
@@ -504,7 +539,7 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
                 }
             }
             gs2m_wave_sync();
-            if (small)
+            if (small && tested)   // an untested rect keeps every tile: the scatter does not read a mask for it
                 tilemask[(size_t)v * P + gi] = (unsigned long long)stage->mlo[k] | ((unsigned long long)stage->mhi[k] << 32);
         }
         // ---- rects of more than 64 tiles: the whole wave walks one owner at a time ----
@@ -522,100 +557,119 @@ GS2M_DEVICE void count_expand(const CountIn* pv, float thr, bool valid, int gi, 
                 unsigned rx, ry;
                 rect_coords(li, ow, oinv, rx, ry);
                 const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                if (!exact_cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) hist_bump(hh, hw, ty * gx + tx);
+                if (!cull || tile_may_contribute(omx, omy, oca, ocb, occ, orx, ory, othr, tx, ty, th)) hist_bump(hh, ty * gx + tx);
             }
         }
     }
 }
 
-// Tile counting: same Gaussian -> workgroup assignment as k_scatter.  Re-reads the geometry half of the
-// GeomRecs written by k_project, expands every rect into (Gaussian, tile) pairs with the balanced walk (count_expand),
-// bumps the workgroup-private LDS tile histogram, records the kept tiles of small rects as bit masks and
-// writes the workgroup's histogram row.
+// Tile counting: same Gaussian -> workgroup assignment as k_scatter.  Re-reads the binning part of the GeomRecs written by
+// k_project (and the geometry part of the rects it tests), expands every rect into (Gaussian, tile) pairs (count_expand),
+// bumps the workgroup-private LDS tile histogram, records the kept tiles of tested rects as bit masks and writes the
+// workgroup's histogram row.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(1024)
 k_count_tiles(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
-              unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull, int interleave) {
+              unsigned* __restrict__ hist, unsigned long long* __restrict__ tilemask, int exact_cull, int interleave, int lane_tiles) {
     GS2M_DYN_LDS(unsigned, lds);
     const int tid = (int)threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
+    const int lane = tid & 63, wave = gs2m_uniform(tid >> 6);
+    const int gx = cams[0].gx, th = cams[0].th, rs = GS2M_CAM_ROWS(cams[0]) >> 1;   // rows = 1 / 2 -> shift 0 / 1
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
+    const unsigned lane_max = (unsigned)gs2m_uniform(lane_tiles);
+    const int cull = gs2m_uniform(exact_cull);
     // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH): its own records, masks and histogram rows
     cams += NV * blockIdx.y;
     recs = gs2m_recs_at(recs, (size_t)NV * blockIdx.y * P);
     tilemask += (size_t)NV * blockIdx.y * P;
     hist += (size_t)NV * blockIdx.y * n_wg * tiles;
-    // workgroup-private tile histogram, two 16-bit counters per word (a workgroup owns `chunk` <= 65535
-    // Gaussians and a Gaussian counts at most once per tile): half the LDS -> twice the resident waves
+    // workgroup-private tile histogram: one u32 counter per (view, tile)
     const int nthreads = (int)blockDim.x;
-    const int hw = (tiles + 1) >> 1;  // words per view
     unsigned* lhist = lds;
-    WaveStage* stage = reinterpret_cast<WaveStage*>(lds + ((NV * hw + 3) & ~3)) + wave;
-    for (int i = tid; i < NV * hw; i += nthreads) lhist[i] = 0u;
+    WaveStage* stage = reinterpret_cast<WaveStage*>(lds + ((NV * tiles + 3) & ~3)) + wave;
+    for (int i = tid; i < NV * tiles; i += nthreads) lhist[i] = 0u;
     __syncthreads();
     // histogram row of this workgroup: the workgroups of an XCD own consecutive rows (see k_scatter)
     const int row = (int)gs2m_xcd_contiguous(blockIdx.x, (unsigned)n_wg);
-    // The records of the NEXT wave step are loaded before the current one is expanded (a workgroup of a 2 M-Gaussian model
-    // takes ~8 steps per wave, and every step used to start with two dependent HBM round trips: rect, then geometry).
-    float4 nw0[NV], nw1[NV], nw2[NV];
-    int end = 0;
-    int first = bin_step_begin(0, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
-    auto fetch = [&](int f0, int e0) __attribute__((always_inline)) {
+    // Two-stage prefetch (round 6).  The 16-B binning part of the records (depth + rect) is loaded TWO wave steps ahead; the 32-B
+    // geometry part one step ahead and ONLY for the lanes whose rect is tested -- nothing else of the counting step reads it
+    // (round 5 streamed 48 B per (view, Gaussian) through this kernel, 32 of them unused for the thin rects that make up
+    // 85 % of a small-splat scene).
+    const int nw = nthreads >> 6;
+    auto fetch_c = [&](int f0, int e0, float4* c) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            nw0[v] = nw1[v] = nw2[v] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (f0 >= 0 && f0 + lane < e0) {
-                const size_t ri = (size_t)v * P + f0 + lane;
-                nw2[v] = recs.c[ri];
-                nw0[v] = recs.ab[2 * ri];
-                nw1[v] = recs.ab[2 * ri + 1];
+            c[v] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (f0 >= 0 && f0 + lane < e0) c[v] = recs.c[(size_t)v * P + f0 + lane];
+        }
+    };
+    auto fetch_ab = [&](int f0, int e0, const float4* c, float4* a0, float4* a1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            a0[v] = a1[v] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (cull && f0 >= 0 && f0 + lane < e0) {
+                const BinRect q = bin_rect_of(c[v], rs);
+                if (gs2m_rect_tested(q.w, q.h, q.area, cull)) {
+                    const size_t ri = (size_t)v * P + f0 + lane;
+                    a0[v] = recs.ab[2 * ri];
+                    a1[v] = recs.ab[2 * ri + 1];
+                }
             }
         }
     };
-    fetch(first, end);
+    float4 c_cur[NV], a0_cur[NV], a1_cur[NV], c_nxt[NV], a0_nxt[NV], a1_nxt[NV], c_nn[NV];
+    int end = 0, end_n = 0, end_nn = 0;
+    int first = bin_step_begin(0, wave, nw, row, n_wg, chunk, P, interleave, &end);
+    int first_n = bin_step_begin(1, wave, nw, row, n_wg, chunk, P, interleave, &end_n);
+    fetch_c(first, end, c_cur);
+    fetch_c(first_n, end_n, c_nxt);
+    fetch_ab(first, end, c_cur, a0_cur, a1_cur);
     for (int it = 0;; ++it) {
         if (first < 0) break;   // wave-uniform; the loop body only uses wave collectives
         const int gi = first + lane;
         const bool valid = gi < end;
-        float4 w0[NV], w1[NV], w2[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            w0[v] = nw0[v];
-            w1[v] = nw1[v];
-            w2[v] = nw2[v];
-        }
-        int end_next = 0;
-        const int first_next = bin_step_begin(it + 1, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end_next);
-        fetch(first_next, end_next);
+        const int first_nn = bin_step_begin(it + 2, wave, nw, row, n_wg, chunk, P, interleave, &end_nn);
+        fetch_c(first_nn, end_nn, c_nn);                        // step it + 2: rects
+        fetch_ab(first_n, end_n, c_nxt, a0_nxt, a1_nxt);        // step it + 1: geometry where its rect (loaded a step ago) asks for it
         CountIn pv[NV];
-        float thr = 0.0f;
+        float op = 0.0f;
+        bool any_tested = false;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            count_in_set(pv[v], 0, 0, 0, 0, rows);
+            const BinRect q = bin_rect_of(c_cur[v], rs);
+            pv[v].ok = valid && q.area != 0u;
+            pv[v].x0 = pv[v].ok ? q.x0 : 0;
+            pv[v].y0 = pv[v].ok ? q.y0 : 0;
+            pv[v].x1 = pv[v].ok ? q.x0 + (int)q.w : 0;
+            pv[v].y1 = pv[v].ok ? q.y0 + (int)q.h : 0;
             pv[v].mx = pv[v].my = pv[v].ca = pv[v].cb = pv[v].cc = 0.0f;
-            if (valid) {
-                const unsigned rect0 = __float_as_uint(w2[v].z), rect1 = __float_as_uint(w2[v].w);
-                count_in_set(pv[v], (int)(rect0 & 0xffffu), (int)(rect0 >> 16), (int)(rect1 & 0xffffu), (int)(rect1 >> 16), rows);
-                if (pv[v].ok) {
-                    pv[v].mx = w0[v].x;
-                    pv[v].my = w0[v].y;
-                    pv[v].ca = w0[v].z;
-                    pv[v].cb = w0[v].w;
-                    pv[v].cc = w1[v].x;
-                    if (exact_cull) thr = cull_threshold(w1[v].y);
-                }
+            if (pv[v].ok && gs2m_rect_tested(q.w, q.h, q.area, cull)) {
+                pv[v].mx = a0_cur[v].x;
+                pv[v].my = a0_cur[v].y;
+                pv[v].ca = a0_cur[v].z;
+                pv[v].cb = a0_cur[v].w;
+                pv[v].cc = a1_cur[v].x;
+                op = a1_cur[v].y;          // one opacity per Gaussian, whichever view delivered it
+                any_tested = true;
             }
         }
-        count_expand<NV>(pv, thr, valid, gi, P, lhist, hw, stage, tilemask, gx, th, exact_cull, lane);
-        first = first_next;
-        end = end_next;
+        const float thr = any_tested ? cull_threshold(op) : 0.0f;   // one logarithm per tested Gaussian (it was one per view and record)
+        count_expand<NV>(pv, thr, valid, gi, P, lhist, tiles, stage, tilemask, gx, th, cull, lane, lane_max);
+        first = first_n;
+        end = end_n;
+        first_n = first_nn;
+        end_n = end_nn;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            c_cur[v] = c_nxt[v];
+            a0_cur[v] = a0_nxt[v];
+            a1_cur[v] = a1_nxt[v];
+            c_nxt[v] = c_nn[v];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < NV * tiles; i += nthreads) {
-        const int v = i / tiles, t = i - v * tiles;
-        hist[((size_t)v * n_wg + row) * tiles + t] = hist_get(lhist + v * hw, hw, t);
-    }
+    for (int v = 0; v < NV; ++v)
+        for (int t = tid; t < tiles; t += nthreads) hist[((size_t)v * n_wg + row) * tiles + t] = lhist[v * tiles + t];
 }
 
 struct ScatterStage {
@@ -628,19 +682,22 @@ struct ScatterStage {
 // Instance scatter: same Gaussian -> workgroup assignment as k_count_tiles; cursors start at
 // tile_start[v][t] + (exclusive prefix over workgroups, left in `hist` by k_hist_colscan).
 // Key = depth_bits << 32 | gaussian_id (unique => order after the per-tile sort is deterministic
-// although LDS-atomic arrival order is not).  Same balanced walk as k_count_tiles; rects of <= 64 tiles
-// replay the tile mask written there, larger ones repeat the same per-tile test.
+// although LDS-atomic arrival order is not).  Rects of <= lane_max tiles are emitted by their own lane, the other rects of
+// <= 64 tiles through the balanced walk of k_count_tiles; tested rects replay the tile mask written there, rects of more than
+// 64 tiles repeat the same per-tile test.
 template <int NV>
 GS2M_KERNEL void __launch_bounds__(1024)
 k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, int n_wg,
           const unsigned* __restrict__ hist, const unsigned* __restrict__ tile_start,
           const unsigned long long* __restrict__ tilemask, unsigned long long* __restrict__ keys, unsigned cap,
-          int exact_cull, const int* __restrict__ ids, int interleave) {
+          int exact_cull, const int* __restrict__ ids, int interleave, int lane_tiles) {
     GS2M_DYN_LDS(unsigned, cursor);
     const int tid = (int)threadIdx.x;
     const int nthreads = (int)blockDim.x;
-    const int gx = cams[0].gx, th = cams[0].th, rows = GS2M_CAM_ROWS(cams[0]);
+    const int gx = cams[0].gx, th = cams[0].th, rs = GS2M_CAM_ROWS(cams[0]) >> 1;
     const int tiles = gx * GS2M_CAM_GYS(cams[0]);
+    const unsigned lane_max = (unsigned)gs2m_uniform(lane_tiles);
+    const int cull = gs2m_uniform(exact_cull);
     // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH)
     cams += NV * blockIdx.y;
     recs = gs2m_recs_at(recs, (size_t)NV * blockIdx.y * P);
@@ -652,70 +709,80 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
     // one XCD own consecutive rows, so the segments an XCD writes into a tile are adjacent: its 8-B key stores fill
     // whole lines in ITS L2 instead of leaving 1/8-written lines in eight L2s (4x write amplification, PMC WRITE_SIZE).
     const int row = (int)gs2m_xcd_contiguous(blockIdx.x, (unsigned)n_wg);
-    for (int i = tid; i < NV * tiles; i += nthreads) {
-        const int v = i / tiles, t = i - v * tiles;
-        cursor[i] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + row) * tiles + t];
-    }
+    for (int v = 0; v < NV; ++v)
+        for (int t = tid; t < tiles; t += nthreads)
+            cursor[v * tiles + t] = tile_start[(size_t)v * (tiles + 1) + t] + hist[((size_t)v * n_wg + row) * tiles + t];
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = gs2m_uniform(tid >> 6);
+    const int nw = nthreads >> 6;
     ScatterStage* stage = reinterpret_cast<ScatterStage*>(cursor + ((NV * tiles + 3) & ~3)) + wave;
     // one view after the other: the key lines this XCD is filling at any time belong to ONE view's array (half the L2
     // working set of a walk that alternates between the views)
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        // next-step prefetch (rect + depth vector, id, tile mask) as in k_count_tiles
+        // next-step prefetch (rect + depth vector, id, tile mask) as in k_count_tiles.  (Round 6 measured the counting kernel's
+        // two-stage form here -- the mask one step ahead and only for the lanes that replay one: C3 39.8 -> 48 us per pair; this
+        // kernel is issue-bound and the second rect decode + the longer rotation cost more than the 8 of 28 bytes saved.)
         float4 n_w2;
         unsigned n_kid;
         unsigned long long n_msk;
         int end = 0;
-        int first = bin_step_begin(0, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end);
+        int first = bin_step_begin(0, wave, nw, row, n_wg, chunk, P, interleave, &end);
         auto fetch = [&](int f0, int e0) __attribute__((always_inline)) {
             n_w2 = float4{0.0f, 0.0f, 0.0f, 0.0f};
             n_kid = (unsigned)(f0 + lane);
-            n_msk = 0ull;
+            n_msk = ~0ull;                                       // an untested rect keeps every tile
             if (f0 >= 0 && f0 + lane < e0) {
                 if (ids) n_kid = (unsigned)ids[f0 + lane];
                 n_w2 = recs.c[(size_t)v * P + f0 + lane];   // the 16-B binning part only: contiguous, fully used lines
-                n_msk = tilemask[(size_t)v * P + f0 + lane];   // only meaningful (and only used) for rects of <= 64 tiles
+                if (cull) n_msk = tilemask[(size_t)v * P + f0 + lane];   // only meaningful (and only used) for tested rects of <= 64 tiles
             }
         };
         fetch(first, end);
         for (int it = 0;; ++it) {
             if (first < 0) break;   // wave-uniform
             const int gi = first + lane;
+            const bool valid = gi < end;
             const float4 w2 = n_w2;
-            unsigned kid = n_kid;   // low word of the sort key: the Gaussian's id (ties in depth resolve as in the reference)
-            const unsigned long long msk_pre = n_msk;
+            const unsigned kid = n_kid;   // low word of the sort key: the Gaussian's id (ties in depth resolve as in the reference)
+            unsigned long long msk_pre = n_msk;
             {
                 int end_next = 0;
-                const int first_next = bin_step_begin(it + 1, wave, nthreads >> 6, row, n_wg, chunk, P, interleave, &end_next);
+                const int first_next = bin_step_begin(it + 1, wave, nw, row, n_wg, chunk, P, interleave, &end_next);
                 fetch(first_next, end_next);
                 first = first_next;      // rotated here: the wave-uniform `continue` below skips nothing of the pipeline
                 end = end_next;
             }
-            unsigned rect0 = __float_as_uint(w2.z), rect1 = __float_as_uint(w2.w), dbits = __float_as_uint(w2.y);
-            const int x0 = (int)(rect0 & 0xffffu), x1 = (int)(rect1 & 0xffffu);
-            int y0 = (int)(rect0 >> 16), y1 = (int)(rect1 >> 16);
-            const bool ok = x1 > x0 && y1 > y0;
-            y0 = y0 / rows;                  // rows of the binning grid (tiles of 16 x th pixels)
-            y1 = (y1 + rows - 1) / rows;
-            rect0 = (unsigned)x0 | ((unsigned)y0 << 16);
-            const unsigned w = ok ? (unsigned)(x1 - x0) : 0u, h = ok ? (unsigned)(y1 - y0) : 0u;
-            const unsigned area = w * h;
+            const BinRect rc = bin_rect_of(w2, rs);
+            const unsigned dbits = __float_as_uint(w2.y);
+            const int x0 = rc.x0, y0 = rc.y0;
+            const unsigned rect0 = (unsigned)x0 | ((unsigned)y0 << 16);
+            const unsigned w = rc.w, h = rc.h, area = valid ? rc.area : 0u;
             if (gs2m_ballot(area != 0u ? 1 : 0) == 0ull) continue;  // wave-uniform
+            if (!gs2m_rect_tested(w, h, area, cull)) msk_pre = ~0ull;   // the word loaded for an untested rect is not a mask
             unsigned* cur = cursor + v * tiles;
             unsigned long long* kv = keys + (size_t)v * cap;
-            // thin rects (see k_count_tiles): every tile is kept, the lane emits its own keys
-            const bool thin = gs2m_thin_rect(w, h, area);
-            if (thin) {
+            // rects of <= lane_max tiles (and the thin ones): the lane emits its own keys, replaying its mask (all ones when the
+            // rect was not tested), row-major bits
+            const bool lane_rect = gs2m_lane_rect(w, h, area, lane_max);
+            if (gs2m_ballot(lane_rect ? 1 : 0) != 0ull) {
+                const unsigned area_l = lane_rect ? area : 0u;
                 const unsigned long long key = ((unsigned long long)dbits << 32) | kid;
-                const int t0 = y0 * gx + x0, dt = w == 1u ? gx : 1;
-                for (unsigned t = 0; t < area; ++t) {
-                    const unsigned pos = atomicAdd(&cur[t0 + (int)t * dt], 1u);
-                    if (pos < cap) kv[pos] = key;
+                int tile = y0 * gx + x0;
+                unsigned rx = 0u;
+                for (unsigned t = 0; t < area_l; ++t) {
+                    if ((msk_pre >> t) & 1ull) {
+                        const unsigned pos = atomicAdd(&cur[tile], 1u);
+                        if (pos < cap) kv[pos] = key;
+                    }
+                    ++tile;
+                    if (++rx == w) {
+                        rx = 0u;
+                        tile += gx - (int)w;
+                    }
                 }
             }
-            const bool small = area != 0u && area <= 64u && !thin;
+            const bool small = area != 0u && area <= 64u && !lane_rect;
             const unsigned long long smalls = gs2m_ballot(small ? 1 : 0);
             if (smalls != 0ull) {
                 const unsigned long long msk = small ? msk_pre : 0ull;
@@ -769,7 +836,7 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
                 const unsigned ow = gs2m_shfl(w, o), oa = gs2m_shfl(area, o), oxy = gs2m_shfl(rect0, o);
                 const unsigned long long key = ((unsigned long long)gs2m_shfl(dbits, o) << 32) | gs2m_shfl(kid, o);
                 float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, thr = 0.f;
-                if (exact_cull) {
+                if (cull) {
                     const float4* r4 = recs.ab + 2 * ((size_t)v * P + gs2m_shfl(gi, o));
                     const float4 w0 = r4[0];
                     const float4 w1 = r4[1];
@@ -787,7 +854,7 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
                     unsigned rx, ry;
                     rect_coords(li, ow, oinv, rx, ry);
                     const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                    if (!exact_cull || tile_may_contribute(mx, my, ca, cb, cc, srx, sry, thr, tx, ty, th)) {
+                    if (!cull || tile_may_contribute(mx, my, ca, cb, cc, srx, sry, thr, tx, ty, th)) {
                         const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
                         if (pos < cap) kv[pos] = key;
                     }

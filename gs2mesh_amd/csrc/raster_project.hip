@@ -9,7 +9,7 @@ int gs2m_count_threads(int chunk, int max_threads) {
     return t < 64 ? 64 : t;
 }
 size_t gs2m_count_lds_bytes(int nv, int tiles, int threads) {
-    return (size_t)((nv * ((tiles + 1) / 2) + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_STAGE_BYTES_PER_WAVE;
+    return (size_t)((nv * tiles + 3) & ~3) * sizeof(unsigned) + (size_t)(threads / 64) * GS2M_STAGE_BYTES_PER_WAVE;
 }
 
 size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads) {
@@ -50,7 +50,7 @@ void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, Ca
 
 int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
-                            int exact_cull, int interleave) {
+                            int exact_cull, int interleave, int lane_tiles) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_count_tiles<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -63,17 +63,17 @@ int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds
     }
     if (nv == 2)
         GS2M_LAUNCH((k_count_tiles<2>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
-                    exact_cull, interleave);
+                    exact_cull, interleave, lane_tiles);
     else
         GS2M_LAUNCH((k_count_tiles<1>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist, tilemask,
-                    exact_cull, interleave);
+                    exact_cull, interleave, lane_tiles);
     return 0;
 }
 
 int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                         const CamUniform* cams, int chunk, const unsigned* hist, const unsigned* tile_start,
                         const unsigned long long* tilemask, unsigned long long* keys, unsigned cap, int exact_cull,
-                        const int* ids, int interleave) {
+                        const int* ids, int interleave, int lane_tiles) {
     if (lds_bytes > 64 * 1024) {
         hipError_t e = nv == 2 ? hipFuncSetAttribute((const void*)k_scatter<2>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
@@ -86,10 +86,10 @@ int gs2m_launch_scatter(int nv, int pairs, int n_wg, int threads, size_t lds_byt
     }
     if (nv == 2)
         GS2M_LAUNCH((k_scatter<2>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
-                    tile_start, tilemask, keys, cap, exact_cull, ids, interleave);
+                    tile_start, tilemask, keys, cap, exact_cull, ids, interleave, lane_tiles);
     else
         GS2M_LAUNCH((k_scatter<1>), dim3(n_wg, pairs), dim3(threads), lds_bytes, st, recs, P, cams, chunk, n_wg, hist,
-                    tile_start, tilemask, keys, cap, exact_cull, ids, interleave);
+                    tile_start, tilemask, keys, cap, exact_cull, ids, interleave, lane_tiles);
     return 0;
 }
 

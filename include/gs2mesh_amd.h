@@ -34,8 +34,7 @@ extern "C" {
 #define GS2M_VERSION 600 /* 0.6.0: round-6 ABI = the round-4 ABI (401) + the round-5 entry points that 401 never counted
                             (gs2m_tsdf_block_map / _map_keys / _map_bytes / _replace / _extract_mesh / _mesh_copy,
                             gs2m_mesh_cluster, gs2m_raster_blend_cycles, GS2M_OPT_BLEND_MODE / _PROFILE) + round 6
-                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES / _BIN_AGGREGATE / _BLEND_PERSISTENT; blend mode 1
-                            removed).  The Python binding checks it at load time */
+                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES, GS2M_OPT_EXACT_TILE_CULL level 2).  The Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
 
@@ -58,7 +57,11 @@ enum {
     GS2M_OPT_EXACT_TILE_CULL = 1, /* 0 = reference AABB-of-3-sigma-circle instance list
                                      (DGR/cuda_rasterizer/auxiliary.h:46-56), 1 = also drop
                                      (Gaussian,tile) instances whose alpha < 1/255 on the
-                                     whole tile (image unchanged, num_rendered smaller)   */
+                                     whole tile (image unchanged, num_rendered smaller);
+                                     2 (round 6) = the same, but rects of at most 4 binning tiles
+                                     keep all their tiles (the per-tile test removes ~2 % of the
+                                     instances of a small-splat scene and was 60 % of the vector
+                                     instructions of the counting kernel)                 */
     GS2M_OPT_BLEND_VARIANT = 2,   /* compositing kernel: 4 (default) = one wave per 16x16 tile, 4 pixels per lane;
                                      0 = the reference's structure (16x16 tile per 256-thread workgroup,
                                      1 px/lane; GS2M_OPT_TILE_ROWS 1 only).  Same image (to rounding).
@@ -85,6 +88,10 @@ enum {
                                      1 = execution-mask form of 0 */
     GS2M_OPT_BLEND_PROFILE = 12,  /* 1 = launch the s_memtime-instrumented build of the compositing kernel (mode 2 only) and sum
                                      its per-wave phase cycles in the handle; read with gs2m_raster_blend_cycles */
+    GS2M_OPT_BIN_LANE_TILES = 13, /* tuning (results never change): a tile rect of at most `value` binning tiles (0 .. 16, default 4) is
+                                     walked by its own lane in the counting / scatter kernels -- exact tile test in registers, the kept
+                                     tiles as a small bit mask -- instead of through the wave-balanced staged walk; 0 = only the thin
+                                     rects of round 4 (one tile wide or high, <= 4 tiles) */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and

@@ -173,7 +173,7 @@ def bin_instances(geom, W, H, exact_cull=False):
     gx, gy = (W + 15) // 16, (H + 15) // 16
     ranges = np.zeros((gx * gy, 2), np.uint32)
     n = lib.oracle_bin(P, W, H, _ptr(geom["radii"]), _ptr(geom["means2D"]), _ptr(geom["depths"]),
-                       _ptr(geom["conic_opacity"]), int(bool(exact_cull)), _ptr(pl), _ptr(ranges), cap)
+                       _ptr(geom["conic_opacity"]), int(exact_cull), _ptr(pl), _ptr(ranges), cap)
     return pl[:n].copy(), ranges
 
 
@@ -238,7 +238,7 @@ def rasterize_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, 
     n = lib.oracle_rasterize_forward(P, sh_degree, M, _ptr(bgc), int(W), int(H), _ptr(means3D), _ptr(shs),
                                      _ptr(colors_precomp), _ptr(opacities), _ptr(scales), float(scale_modifier),
                                      _ptr(rotations), _ptr(cov3D_precomp), _ptr(vm), _ptr(pm), _ptr(cp),
-                                     float(tanfovx), float(tanfovy), int(bool(exact_cull)), _ptr(out),
+                                     float(tanfovx), float(tanfovy), int(exact_cull), _ptr(out),
                                      _ptr(radii))
     return out, radii, int(n)
 

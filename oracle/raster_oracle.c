@@ -307,7 +307,8 @@ int oracle_tile_may_contribute(float mx, float my, float ca, float cb, float cc,
 /*
  * Returns num_rendered; fills point_list[num_rendered] (caller sized via tiles_touched sum)
  * and ranges[2*tiles] (zeroed first, rasterizer_impl.cu:310).
- * exact_cull != 0 applies oracle_tile_may_contribute (extension, see above).
+ * exact_cull != 0 applies oracle_tile_may_contribute (extension, see above): 1 = to every rect with corners (>= 2 x 2 tiles),
+ * 2 = only to those of more than 4 tiles.
  */
 int64_t oracle_bin(int P, int W, int H, const int* radii, const float* means2D,
                    const float* depths, const float* conic_opacity, int exact_cull,
@@ -349,6 +350,8 @@ int64_t oracle_bin(int P, int W, int H, const int* radii, const float* means2D,
                 if ((int)rmax[1] > by1) rmax[1] = (uint32_t)(by1 < 0 ? 0 : by1);
                 if (rmax[0] <= rmin[0] || rmax[1] <= rmin[1]) continue;
                 per_tile = (rmax[0] - rmin[0]) >= 2 && (rmax[1] - rmin[1]) >= 2;
+                /* level 2 (round 6): rects of at most 4 tiles keep all their tiles (gs2m_rect_tested, raster_project.h) */
+                if (exact_cull == 2 && (rmax[0] - rmin[0]) * (rmax[1] - rmin[1]) <= 4) per_tile = 0;
             }
             for (uint32_t y = rmin[1]; y < rmax[1]; y++) {
                 for (uint32_t x = rmin[0]; x < rmax[0]; x++) {
@@ -590,9 +593,12 @@ int oracle_tile_may_contribute(float mx, float my, float ca, float cb, float cc,
     const float thresh = logf(opacity * 255.0f) * 1.0001f + 0.001f;
     if (dx0 <= 0.0f && dx1 >= 0.0f && dy0 <= 0.0f && dy1 >= 0.0f) return 1; /* centre inside */
     const float rx = -cb / ca, ry = -cb / cc;
-    float qmin = edge_min_x(ca, cb, cc, rx, dy0, dx0, dx1);
-    qmin = fminf(qmin, edge_min_x(ca, cb, cc, rx, dy1, dx0, dx1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx0, dy0, dy1));
-    qmin = fminf(qmin, edge_min_y(ca, cb, cc, ry, dx1, dy0, dy1));
+    /* only the edges that FACE the centre (q is convex with its minimum at the centre, outside the tile: the constrained
+       minimum lies on the part of the boundary visible from the centre); same form as the kernel (raster_math.h, round 6) */
+    const int in_x = dx0 <= 0.0f && dx1 >= 0.0f, in_y = dy0 <= 0.0f && dy1 >= 0.0f;
+    const float ex = dx0 > 0.0f ? dx0 : dx1, ey = dy0 > 0.0f ? dy0 : dy1;
+    const float qv = edge_min_y(ca, cb, cc, ry, ex, dy0, dy1);
+    const float qh = edge_min_x(ca, cb, cc, rx, ey, dx0, dx1);
+    const float qmin = in_x ? qh : (in_y ? qv : fminf(qv, qh));
     return qmin <= thresh ? 1 : 0;
 }

@@ -121,6 +121,7 @@ static inline float gs2m_fast_log2(float x) { return log2f(x); }
 #define GS2M_SCHED_BARRIER() ((void)0)
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 static inline int __ffsll(unsigned long long m) { return __builtin_ffsll((long long)m); }
+static inline int __clzll(long long m) { return m == 0 ? 64 : __builtin_clzll((unsigned long long)m); }
 static inline int __popc(unsigned m) { return __builtin_popcount(m); }
 static inline int __ffs(int m) { return __builtin_ffs(m); }
 

@@ -182,6 +182,16 @@ def test_exact_tile_cull_preserves_the_image(backend):
     _, _, n_ref = oracle_forward(left, g["xyz"], o, [0, 0, 0], shs=shs, scales=s, rotations=q, exact_cull=True)
     assert n1 < 0.8 * n0
     assert abs(n1 - n_ref) <= max(2, 1e-3 * n_ref)
+    # level 2 (round 6): rects of at most 4 tiles keep all their tiles -- between the two lists, same image
+    r.set_option(_lib.OPT_EXACT_TILE_CULL, 2)
+    img2, radii2 = r.forward(*args, **kw)
+    n2 = r.last_num_rendered
+    np.testing.assert_array_equal(be.host(img0), be.host(img2))
+    np.testing.assert_array_equal(be.host(radii0), be.host(radii2))
+    _, _, n_ref2 = oracle_forward(left, g["xyz"], o, [0, 0, 0], shs=shs, scales=s, rotations=q, exact_cull=2)
+    assert n1 <= n2 < n0 and abs(n2 - n_ref2) <= max(2, 1e-3 * n_ref2)
+    with pytest.raises(RuntimeError):
+        r.set_option(_lib.OPT_EXACT_TILE_CULL, 3)
 
 
 def test_empty_and_fully_culled_scenes(backend):
@@ -583,6 +593,76 @@ def test_thin_rects_take_the_per_lane_path(backend, rows):
             np.testing.assert_array_equal(pl, ref_pl)
         elif rows == 1:
             assert abs(r.last_num_rendered - ref_n) <= max(2, 2e-3 * ref_n)
+
+
+@pytest.mark.parametrize("rows", [1, 2])
+def test_lane_tiles_settings_give_identical_lists(backend, rows):
+    """GS2M_OPT_BIN_LANE_TILES (round 6): rects of at most that many binning tiles are walked by their own lane -- in k_count_tiles
+    when they are not tested, in k_scatter always (it replays the mask) -- instead of through the staged walk.  A tuning
+    option: instance lists, tile ranges and image must be the same bit for bit at 0 (round 5's thin rects only), the default 4,
+    6 and 16, at every level of the exact cull (0, 1, 2 = rects of at most 4 tiles untested) -- on dots, 2 x 2 blobs, needles,
+    3 x 3 .. 6 x 6 blobs and needles longer than 64 tiles (one tile high after the cull: the whole-wave walk tests every tile of
+    those and needs the record's geometry part, which the counting pass now only loads for rects that are tested)."""
+    W, H, f = 1184, 96, 300.0
+    rng = np.random.default_rng(606)
+    P = 2600
+    xyz = np.zeros((P, 3), np.float32)
+    xyz[:, 0] = rng.uniform(-7.5, 7.5, P)
+    xyz[:, 1] = rng.uniform(-0.55, 0.55, P)
+    xyz[:, 2] = rng.uniform(-0.2, 0.2, P)
+    s = np.full((P, 3), 0.004, np.float32)                        # dots
+    kind = rng.integers(0, 6, P)
+    s[kind == 1] = 0.018                                          # ~2 x 2 tiles
+    s[kind == 2, 0] = rng.uniform(0.03, 0.09, (kind == 2).sum())  # needles along x
+    s[kind == 3, 1] = rng.uniform(0.03, 0.09, (kind == 3).sum())  # needles along y
+    s[kind == 4] = rng.uniform(0.03, 0.12, ((kind == 4).sum(), 1)).astype(np.float32)   # blobs
+    long_ones = np.nonzero(kind == 5)[0][:6]
+    s[long_ones, 0] = rng.uniform(2.5, 4.0, len(long_ones))       # needles of > 64 tiles (3 sigma ~ 1000 px), 1 tile high after the cull
+    s[long_ones, 1] = 0.002
+    xyz[long_ones, 0] = rng.uniform(-1.0, 1.0, len(long_ones))
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    o = rng.uniform(0.05, 0.9, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    be = backend
+    d = be.dev
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform, cam.camera_center, W, H,
+                                 cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    tt = geom_ref["tiles_touched"]
+    assert (tt == 1).sum() > 50 and (tt == 4).sum() > 50 and (tt > 64).sum() >= 4, np.bincount(np.minimum(tt, 70))
+    n_tiles = ((W + 15) // 16) * ((H + 16 * rows - 1) // (16 * rows))
+    for cull in (0, 1, 2):
+        base = None
+        for lane_tiles in (0, 4, 6, 16):
+            r = Rasterizer(0, lib=be.lib)
+            r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
+            r.set_option(_lib.OPT_TILE_ROWS, rows)
+            r.set_option(_lib.OPT_BIN_LANE_TILES, lane_tiles)
+            img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
+                                   d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols), scales=d(s),
+                                   rotations=d(q))
+            n = r.last_num_rendered
+            pl, ranges = r.download_binning(0, n, n_tiles)
+            got = (n, pl.copy(), ranges.copy(), be.host(img).copy())
+            if base is None:
+                base = got
+                if rows == 1:
+                    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q,
+                                                               exact_cull=cull)
+                    np.testing.assert_array_equal(be.host(radii), ref_radii)
+                    assert n == ref_n
+                    if cull == 0:
+                        ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+                        np.testing.assert_array_equal(ranges, ref_ranges)
+                        np.testing.assert_array_equal(pl, ref_pl)
+                    assert_image_close(be.host(img), ref_img)
+            else:
+                assert got[0] == base[0], (lane_tiles, cull)
+                np.testing.assert_array_equal(got[2], base[2])
+                np.testing.assert_array_equal(got[1], base[1])
+                np.testing.assert_array_equal(got[3], base[3])
+    with pytest.raises(RuntimeError):
+        Rasterizer(0, lib=be.lib).set_option(_lib.OPT_BIN_LANE_TILES, 17)
 
 
 @pytest.mark.parametrize("cull", [0, 1])

@@ -1,0 +1,83 @@
+"""Development A/B of the binning chain's tuning options (GS2M_OPT_BIN_LANE_TILES, GS2M_OPT_EXACT_TILE_CULL level, GS2M_OPT_BIN_WORKGROUPS)
+at the default launch shape (2 stereo pairs per launch, 16 x 32 binning tiles, exact tile cull): per-stage times per pair, order-
+interleaved in one process (the first kernels of a process run slow), + a check that the instance lists do not change.
+
+    python tools/ab_binning.py --configs C2,C3 --settings "L0X1,L4X1,L4X2,L8X2" --rounds 3
+    setting = L<lane tiles>[X<exact cull level 1 | 2>][W<bin workgroups>]
+"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse, json, re
+import numpy as np
+import torch
+from gs2mesh_amd import _lib, synthetic
+from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--configs", default="C2,C3")
+ap.add_argument("--settings", default="L0X1,L4X1,L4X2,L8X2")
+ap.add_argument("--groups", type=int, default=6)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--scene", default="synth", choices=["synth", "trained"])
+ap.add_argument("--morton", default="auto", choices=["auto", "0", "1"])
+a = ap.parse_args()
+STAGES = ("project", "count_tiles", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend")
+
+
+def parse(s):
+    m = re.fullmatch(r"L(\d+)(?:X(\d))?(?:W(\d+))?", s)
+    return dict(name=s, lane=int(m.group(1)), cull=int(m.group(2) or 1), wg=int(m.group(3) or 0))
+
+
+for cname in a.configs.split(","):
+    cfg = synthetic.CONFIGS[cname]
+    g = (synthetic.trained_like if a.scene == "trained" else synthetic.synth_v1)(cfg.P, cfg.seed, cfg.log_s_mu)
+    gd = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
+    gd["raw"] = True
+    poses = synthetic.ring_poses(2 * a.groups, cfg.ring_radius, 0, cfg.n_pairs)
+    cams = []
+    for p in poses:
+        l, r = synthetic.stereo_cameras(p, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline)
+        cams.append([camera_from(l), camera_from(r)])
+    groups = [cams[i] + cams[i + 1] for i in range(0, len(cams), 2)]
+    out = torch.empty((4, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
+    packed = cfg.P >= 1_000_000 if a.morton == "auto" else a.morton == "1"
+    n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 31) // 32)
+    rast, ref = {}, None
+    for st in [parse(s) for s in a.settings.split(",")]:
+        R = Rasterizer(0)
+        R.set_option(_lib.OPT_EXACT_TILE_CULL, st["cull"])
+        R.set_option(_lib.OPT_TILE_ROWS, 2)
+        R.set_option(_lib.OPT_PAIR_BATCH, 2)
+        R.set_option(_lib.OPT_BIN_LANE_TILES, st["lane"])
+        if st["wg"]:
+            R.set_option(_lib.OPT_BIN_WORKGROUPS, st["wg"])
+        (R.pack_model if packed else R.pack_sh)(gd)
+        res = R.render_views(gd, groups[0], out_color=out)
+        R.reserve(cfg.P, 4, cfg.width, cfg.height, int(max(res["num_rendered"]) * 1.5))
+        res = R.render_views(gd, groups[0], out_color=out)
+        n = int(res["num_rendered"][0])
+        pl, ranges = R.download_binning(0, n, n_tiles)
+        sig = (n, int(pl.astype(np.uint64).sum()), int(ranges.astype(np.uint64).sum()), float(out.double().sum()))
+        if ref is None or ref[3] != st["cull"]:        # lists are compared among the settings of one cull level
+            ref = (sig, pl.copy(), ranges.copy(), st["cull"])
+        same = sig == ref[0] and np.array_equal(pl, ref[1]) and np.array_equal(ranges, ref[2])
+        rast[st["name"]] = (R, same, n)
+    best = {k: {s: None for s in STAGES} for k in rast}
+    for rnd in range(a.rounds):
+        for name, (R, same, n) in rast.items():
+            R.set_option(_lib.OPT_STAGE_TIMING, 1)
+            for grp in groups:
+                R.render_views(gd, grp, out_color=out, sync=False)
+            tms = R.stage_times()
+            R.set_option(_lib.OPT_STAGE_TIMING, 0)
+            for s in STAGES:
+                us = 1e3 * tms[s][0] / max(tms[s][1], 1) / 2
+                best[name][s] = us if best[name][s] is None else min(best[name][s], us)
+    for name, (R, same, n) in rast.items():
+        b = best[name]
+        print(json.dumps(dict(config=cname, scene=a.scene, packed=packed, setting=name, lists_identical=same, num_rendered_eye0=n,
+                              **{s: round(b[s], 2) for s in STAGES},
+                              binning_us=round(sum(b[s] for s in STAGES if s not in ("project", "blend")), 1),
+                              raster_us=round(sum(b.values()), 1))), flush=True)
+        R.close()
