@@ -71,7 +71,9 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     import torch
     from gs2mesh_amd import _lib, synthetic
     from gs2mesh_amd.rasterizer import Rasterizer, camera_from
+    from gs2mesh_amd.rasterizer import auto_cull_level
     cfg = synthetic.CONFIGS[cfg_name]
+    cull = auto_cull_level(cfg.P) if args.cull_arg < 0 else int(args.cull_arg)     # this configuration's own level
     g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
     gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
     gd["raw"] = True
@@ -82,7 +84,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
         l, r = synthetic.stereo_cameras(p, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline)
         cams.append([camera_from(l), camera_from(r)])
     R = Rasterizer(local_rank)
-    R.set_option(_lib.OPT_EXACT_TILE_CULL, int(args.cull))
+    R.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
     R.set_option(_lib.OPT_TILE_ROWS, int(args.tile_rows))
     R.set_option(_lib.OPT_BLEND_VARIANT, int(args.blend))
     ppl = max(1, int(args.pairs_per_launch))
@@ -123,7 +125,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     stages = {k: dict(avg_us=round(1e3 * ms / max(c, 1), 2), frac_hbm=round(alg[k] / max(1e-9, 1e-3 * ms / max(c, 1)) / HBM_PEAK, 4),
                       alg_bytes=int(alg[k]),
                       traffic=(int(tr[k]["hbm_bytes_per_launch"] / max(1, int(tr[k].get("pairs_per_launch", 1))))   # per stereo pair
-                               if tr.get(k, {}).get("cull") == args.cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
+                               if tr.get(k, {}).get("cull") == cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
               for k, (ms, c) in st.items()}
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
     return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {n_pairs} pairs, "
@@ -143,8 +145,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)     # = the driver's command: `python bench.py` reproduces its number
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--cull", type=int, default=int(os.environ.get("GS2M_BENCH_CULL", "1")),
-                    help="exact tile culling (image-preserving); 0 = reference instance lists")
+    ap.add_argument("--cull", type=int, default=int(os.environ.get("GS2M_BENCH_CULL", "-1")),
+                    help="exact tile culling (image-preserving): 0 = reference instance lists, 1 / 2 = GS2M_OPT_EXACT_TILE_CULL levels, "
+                         "-1 (default) = auto by model size (gs2mesh_amd.rasterizer.auto_cull_level: the pipeline's own default)")
     ap.add_argument("--blend", type=int, default=int(os.environ.get("GS2M_BENCH_BLEND", "4")))
     ap.add_argument("--reduce", default="reduce_scatter", choices=["allreduce", "reduce_scatter"])
     ap.add_argument("--payload", default="auto", choices=["auto", "packed", "f32"],
@@ -183,6 +186,11 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 render-only sub-measurement")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the 2K-step job of the steady-state probe")
     args = ap.parse_args()
+    args.cull_arg = args.cull                      # as given (-1 = auto); args.cull = the level the timed configuration runs at
+    if args.cull < 0:
+        from gs2mesh_amd import synthetic as _syn
+        from gs2mesh_amd.rasterizer import auto_cull_level
+        args.cull = auto_cull_level(_syn.CONFIGS[args.config].P)
 
     # --gpus N is the number of ranks of the job.  Under the driver's launcher (torch.distributed.run) WORLD_SIZE says the same;
     # started plainly with --gpus N > 1 the script re-executes itself under that launcher (one rank per GPU, rendezvous on

@@ -147,12 +147,18 @@ struct BlendInst {
 // PROF = 1 (GS2M_OPT_BLEND_PROFILE): the same kernel with s_memtime stamps at the phase boundaries of every wave, summed
 // into prof[GS2M_BLEND_PROF_N] with one atomic per counter per wave (the stamps cost ~10 % themselves: shares, not times).
 #define GS2M_BLEND_PROF_N 10
-template <int WPB, int LROWS, int OCC, int MODE = 0, int PROF = 0>
-GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
-k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
-               const GeomRecs recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
-               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
-               const unsigned* __restrict__ order, unsigned long long* __restrict__ prof = nullptr, int nv_x = 0) {
+
+// One wave composites one 16 x 16 tile (tx, ty) of view v.  MODE 0 = per-pixel decisions as lane masks in scalar registers +
+// per-instance quadrant mask ("reference-structure" loop of rounds 1-4, kept as the cross-check of MODE 2); MODE 2 (round 5,
+// the default) = all four quadrants per staged instance, flag-free runs.  (MODE 1, the execution-mask form of MODE 0, was never
+// the fastest anywhere and was removed in round 6.)
+template <int WPB, int LROWS, int MODE, int PROF>
+GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUniform& cam, const unsigned long long* __restrict__ keys,
+                            const unsigned* __restrict__ tile_start, const GeomRecs recs, const int P, const unsigned cap,
+                            float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
+                            unsigned long long* __restrict__ prof, float4* __restrict__ s_a, float4* __restrict__ s_b,
+                            float2* __restrict__ s_c, float4* __restrict__ s_raw, const int lane) {
+    static_assert(MODE == 0 || MODE == 2, "loop forms: 0 (lane masks in scalar registers), 2 (all quadrants, flag-free runs)");
     unsigned long long pt_wait = 0, pt_stage = 0, pt_issue = 0, pt_loop = 0, pn_batches = 0, pn_staged = 0;
     // Phase stamps of the profile build: the interval since the previous stamp is added to the phase that ENDS here.
     unsigned long long pt_pro = 0, pt_epi = 0;
@@ -165,43 +171,8 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             pt_mark = now;
         }
     };
-    // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
-    // log2 o, r, g}, c = {b, quadrant mask | general << 8 (bits)}; 2 pad slots: the software-pipelined reads run 2
-    // instances ahead.  5.6 KiB of LDS per wave with the DMA landing zone: 7 waves per SIMD fit the 160 KiB.
-    __shared__ float4 s_a[WPB][64 + 2], s_b[WPB][64 + 2];
-    __shared__ float2 s_c[WPB][64 + 2];
-    __shared__ float4 s_raw[WPB][3][64];   // DMA landing zone: the three 16-B vectors of the next batch's GeomRecs
-    const int tid = (int)threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    // Views interleaved along blockIdx.x (nv_x > 1, MODE 2): per XCD the dispatch order is chunk rank major, view
-    // minor, so the heavy chunks of ALL views of the launch start first.  With the views along blockIdx.y the heavy
-    // chunks of the last view were dispatched in the last quarter of a 4-view launch and the kernel ended on them.
-    const int nvx = gs2m_uniform(nv_x);   // > 1: that many views interleaved along blockIdx.x
-    const int v = nvx > 1 ? (int)((blockIdx.x / 8u) % (unsigned)nvx) : (int)blockIdx.y;
-    const CamUniform& cam = cams[v];
     const int W = cam.W, H = cam.H, gx = cam.gx;
     const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);    // instance lists
-    const unsigned bid = nvx > 1 ? (blockIdx.x / 8u / (unsigned)nvx) * 8u + blockIdx.x % 8u : blockIdx.x;
-    int tx, ty;
-    {
-        // k_tile_scan's schedule: chunks of GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring lists ranked by descending weight; rank p is
-        // the (p / 8)-th chunk of XCD p % 8.  Wave slot j of XCD x (= bid % 8) takes half (j % LROWS) of list (j / LROWS) %
-        // CHUNK of that XCD's (j / (CHUNK * LROWS))-th chunk.
-        const int xcd = (int)(bid % 8u);
-        const int j = gs2m_uniform((int)(bid / 8u) * WPB + wave);
-        const int lrows = ltiles / gx, cpr = (gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW;
-        const int nch = cpr * ((lrows + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
-        const int rank_c = (j / (GS2M_SCHED_CHUNK * LROWS)) * 8 + xcd;
-        if (rank_c >= nch) return;
-        const int c = (int)order[(size_t)v * ltiles + rank_c];
-        const int k = (j / LROWS) % GS2M_SCHED_CHUNK;                 // list of the chunk
-        const int crow = c / cpr, lx = (c - crow * cpr) * GS2M_SCHED_CW + k % GS2M_SCHED_CW;
-        const int ly = crow * GS2M_SCHED_CH + k / GS2M_SCHED_CW;
-        if (lx >= gx || ly >= lrows) return;
-        tx = lx;
-        ty = ly * LROWS + j % LROWS;
-        if (ty >= cam.gy) return;
-    }
     const int px0 = tx * GS2M_TILE + (lane & 7), py0 = ty * GS2M_TILE + (lane >> 3);
     float pxf0 = (float)px0, pxf1 = (float)(px0 + 8), pyf0 = (float)py0, pyf1 = (float)(py0 + 8);
     GS2M_KEEP_F32(pxf0);
@@ -209,11 +180,11 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
     GS2M_KEEP_F32(pyf0);
     GS2M_KEEP_F32(pyf1);
     float T[4], C0[4], C1[4], C2[4];
-    unsigned long long dn[4];  // finished (or outside-the-image) pixels of quadrant k: lane mask in scalar registers
-    // MODE 1: no lane masks in scalar registers -- the scalar unit issues ONE instruction per cycle for the four SIMDs of a
+    unsigned long long dn[4];  // MODE 0: finished (or outside-the-image) pixels of quadrant k: lane mask in scalar registers
+    // MODE 2: no lane masks in scalar registers -- the scalar unit issues ONE instruction per cycle for the four SIMDs of a
     // CU (tools/ubench/salu_rates.hip) and the mask bookkeeping of MODE 0 (7 scalar instructions + 3 branches per
-    // contributing quadrant) made the kernel scalar-issue-bound.  A finished pixel raises its own threshold to +inf, the
-    // candidate test is one v_cmp against that threshold and the accumulate path runs under the execution mask.
+    // contributing quadrant) made the kernel scalar-issue-bound.  A finished pixel raises its own threshold, the candidate
+    // test is one v_cmp against that threshold and the accumulate path runs under the execution mask.
     float thr[4];
     const float QMIN_ = -7.99435343685885793770f;
     // threshold of a finished pixel: q <= log2(opacity) <= 0 for every accepted contribution (an inline constant, no register)
@@ -255,12 +226,12 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         }
         if (base + (unsigned)lane < r1) {
             const float4* r4 = rv.ab + 2 * (size_t)gid;
-            gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
-            gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
-            gs2m_global_load_lds16(rv.c + gid, &s_raw[wave][2][0]);
+            gs2m_global_load_lds16(r4, &s_raw[0]);
+            gs2m_global_load_lds16(r4 + 1, &s_raw[64]);
+            gs2m_global_load_lds16(rv.c + gid, &s_raw[128]);
         }
     }
-    stamp(pt_pro);   // prologue: schedule lookup, first ids / ranks / record DMA
+    stamp(pt_pro);   // prologue: first ids / ranks / record DMA
     while (base < r1) {
         unsigned lq = 0u;  // quadrants that still have unfinished pixels
 #pragma unroll
@@ -273,9 +244,8 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         gs2m_wave_sync();      // ... and the previous batch's staged instances have been read by every lane
         int nb_staged = 0;
         unsigned long long gslots = 0ull;   // MODE 2: staged slots that take the general path
-        bool batch_general = false;   // any staged instance of this batch needs the reference's power > 0 test / alpha cap
         {
-            const float4 ra = s_raw[wave][0][lane], rb = s_raw[wave][1][lane], rc = s_raw[wave][2][lane];
+            const float4 ra = s_raw[lane], rb = s_raw[64 + lane], rc = s_raw[128 + lane];
             const bool have = base + (unsigned)lane < r1;
             const float op = have ? rb.y : 1.0f;
             const float lo = gs2m_fast_log2(op);                           // log2 o
@@ -302,9 +272,8 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             }
             // general path (power > 0 test + alpha cap) only where it can matter: opacity near the 0.99 cap, or a conic so
             // close to singular that rounding could make the quadratic form negative
-            // MODE 1 applies the alpha cap to every instance (one v_min) and flags only the conics that need the power > 0 test
             const bool singular = !(ra.z > 0.0f && rb.x > 0.0f && det >= 1.0e-3f * ra.z * rb.x);
-            const bool general = MODE == 1 ? singular : (!(op <= 0.98f) || singular);   // MODE 2: like MODE 0, resolved per RUN of the batch
+            const bool general = !(op <= 0.98f) || singular;   // MODE 2: resolved per RUN of the batch
             BlendInst bi;
             bi.a = ra;
             bi.b = rb;
@@ -314,7 +283,6 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             bi.b.y = lo;
             bi.c.x = rc.x;
             bi.c.y = __uint_as_float(m | (general ? 0x100u : 0u));
-            batch_general = gs2m_ballot_b(general && have && m != 0u) != 0ull;
             if (LROWS > 1 || MODE == 2) {
                 // the list also serves the other half of the 16 x 32 tile: stage only the instances that reach this
                 // half (ballot compaction), so the compositing loop never iterates over the others
@@ -323,9 +291,9 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                 const unsigned long long keep = gs2m_ballot_b(mine);
                 const int slot = gs2m_popc64(keep & ((1ull << lane) - 1ull));
                 if (mine) {
-                    s_a[wave][slot] = bi.a;
-                    s_b[wave][slot] = bi.b;
-                    s_c[wave][slot] = bi.c;
+                    s_a[slot] = bi.a;
+                    s_b[slot] = bi.b;
+                    s_c[slot] = bi.c;
                 }
                 nb_staged = gs2m_popc64(keep);
                 if (MODE == 2) {
@@ -340,9 +308,9 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                     }
                 }
             } else {
-                s_a[wave][lane] = bi.a;
-                s_b[wave][lane] = bi.b;
-                s_c[wave][lane] = bi.c;
+                s_a[lane] = bi.a;
+                s_b[lane] = bi.b;
+                s_c[lane] = bi.c;
             }
         }
         gs2m_wave_sync();   // s_raw has been consumed, the staged batch is complete
@@ -351,9 +319,9 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
         base += 64u;
         if (base + (unsigned)lane < r1) {  // records of the next batch -> LDS while this one is composited
             const float4* r4 = rv.ab + 2 * (size_t)gid_next;
-            gs2m_global_load_lds16(r4, &s_raw[wave][0][0]);
-            gs2m_global_load_lds16(r4 + 1, &s_raw[wave][1][0]);
-            gs2m_global_load_lds16(rv.c + gid_next, &s_raw[wave][2][0]);
+            gs2m_global_load_lds16(r4, &s_raw[0]);
+            gs2m_global_load_lds16(r4 + 1, &s_raw[64]);
+            gs2m_global_load_lds16(rv.c + gid_next, &s_raw[128]);
         }
         if (rank) {
             // both loads are consumed after the next gs2m_wait_dma: the rank of the ids fetched a batch ago, and new ids
@@ -367,104 +335,6 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             pn_batches += 1;
             pn_staged += (unsigned long long)nb;
         }
-        // software-pipelined broadcast reads, unrolled by two with ping-pong registers: instance j+1's
-        // constants are in flight while instance j is composited (no LDS wait on the critical path).
-        auto step_body = [&](auto gen_tag, const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
-            constexpr int GTAG = (int)decltype(gen_tag)::value;   // 0 / 1: compile-time, 2: the instance's flag (bit 8 of qmf)
-            int qm = qmf & (int)lq;
-            GS2M_OPAQUE_SGPR(qm);   // one s_and per instance, then s_bitcmp per quadrant (not an s_and + s_cmp per quadrant)
-            {
-                const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
-                const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
-                const float nbdx[2] = {-(A.w * dx0), -(A.w * dx1)};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box and has unfinished pixels
-                        const float dy = A.y - ((k >> 1) ? pyf1 : pyf0);
-                        // q = e + dy (c' dy - b' dx): two FMAs
-                        const float qv = fmaf(fmaf(B.x, dy, nbdx[k & 1]), dy, e[k & 1]);
-                        if (MODE == 1) {
-                            if (qv >= thr[k]) {   // per-lane: the accumulate path runs under the execution mask
-                                float alpha = fminf(0.99f, gs2m_fast_exp2(qv));   // alpha cap (forward.cu:343), every instance
-                                if (GTAG == 1 || (GTAG == 2 && (qmf & 0x100))) {   // scalar branch (rare; the test fills a hazard slot)
-                                    // the reference's power > 0 skip (forward.cu:336-337), near-singular conics only:
-                                    // a skipped lane gets alpha = 0 (T' = T, not saturating, w = 0: no contribution)
-                                    GS2M_NO_IF_CONVERT();
-                                    alpha = qv > B.y ? 0.0f : alpha;
-                                }
-                                const float test_T = fmaf(-T[k], alpha, T[k]);
-                                float Tn = test_T;
-                                // a pixel saturates once, a quadrant is evaluated thousands of times: the saturation
-                                // bookkeeping sits behind a wave-uniform branch (no scalar ALU op: s_cbranch_vccz)
-                                if (gs2m_any_active_lane(test_T < 0.0001f)) {
-                                    GS2M_NO_IF_CONVERT();
-                                    const bool sat = test_T < 0.0001f;
-                                    thr[k] = sat ? THR_DONE : thr[k];      // finished: never a candidate again
-                                    Tn = sat ? T[k] : test_T;              // T stays the last accepted transmittance
-                                }
-                                const float wT = T[k] - Tn;
-                                C0[k] = fmaf(B.z, wT, C0[k]);
-                                C1[k] = fmaf(B.w, wT, C1[k]);
-                                C2[k] = fmaf(CL.x, wT, C2[k]);
-                                T[k] = Tn;
-                            }
-                            continue;
-                        }
-                        const unsigned long long prem = gs2m_ballot_b(qv >= QMIN) & ~dn[k];   // v_cmp + s_andn2
-                        if (prem != 0ull) {
-                            float alpha = gs2m_fast_exp2(qv);
-                            unsigned long long candm = prem;
-                            if (GTAG == 1 || (GTAG == 2 && (qmf & 0x100))) {  // scalar branch: general path (rare)
-                                GS2M_NO_IF_CONVERT();
-                                candm = prem & ~gs2m_ballot_b(qv > B.y);       // power > 0: skipped (forward.cu:336-337)
-                                alpha = fminf(0.99f, alpha);
-                            }
-                            const float test_T = fmaf(-T[k], alpha, T[k]);
-                            const unsigned long long satm = gs2m_ballot_b(test_T < 0.0001f) & candm;
-                            const float Tn = gs2m_lanes(candm & ~satm) ? test_T : T[k];
-                            const float wT = T[k] - Tn;  // = alpha * T for an accepted contribution, else 0
-                            C0[k] = fmaf(B.z, wT, C0[k]);
-                            C1[k] = fmaf(B.w, wT, C1[k]);
-                            C2[k] = fmaf(CL.x, wT, C2[k]);
-                            T[k] = Tn;
-                            dn[k] |= satm;
-                        }
-                    }
-                }
-            }
-        };
-        // The reference's power > 0 test and alpha cap are valid for every instance but only matter for the flagged ones
-        // (opacity near the cap, near-singular conic): a batch with a flagged instance runs the general copy of the loop,
-        // every other batch the short one -- one scalar branch per 64 instances instead of one per contributing quadrant.
-        // Software-pipelined broadcast reads, unrolled by two with ping-pong registers.  The quadrant mask is read (= the
-        // LDS wait) BEFORE the next instance's reads are issued, so the wait never covers a read that was just issued.
-        auto run_loop = [&](auto gen_tag) __attribute__((always_inline)) {
-            const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
-            const float2* spc = &s_c[wave][0];
-            float4 A0 = spa[0], B0 = spb[0], A1, B1;
-            float2 K0 = spc[0], K1;
-            int j = 0;
-            for (; j + 1 < nb; j += 2) {
-                const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
-                GS2M_SCHED_BARRIER();
-                A1 = spa[j + 1];
-                B1 = spb[j + 1];
-                K1 = spc[j + 1];
-                GS2M_SCHED_BARRIER();
-                if (qm0 & (int)lq) step_body(gen_tag, qm0, K0, A0, B0);
-                const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
-                GS2M_SCHED_BARRIER();
-                A0 = spa[j + 2];
-                B0 = spb[j + 2];
-                K0 = spc[j + 2];
-                GS2M_SCHED_BARRIER();
-                if (qm1 & (int)lq) step_body(gen_tag, qm1, K1, A1, B1);
-            }
-            if (j < nb) {
-                const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
-                if (qm0 & (int)lq) step_body(gen_tag, qm0, K0, A0, B0);
-            }
-        };
         if (MODE == 2) {
             // ---- MODE 2 (round 5): "evaluate all four quadrants".  The loop of MODE 0 spends more scalar than vector issue
             // (per instance-wave on C2: 134 vector cycles per SIMD, but 28 scalar-ALU instructions at ~4.2 SIMD-cycles each
@@ -524,8 +394,8 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
                     }
                 }
             };
-            const float4 *spa = &s_a[wave][0], *spb = &s_b[wave][0];
-            const float2* spc = &s_c[wave][0];
+            const float4 *spa = s_a, *spb = s_b;
+            const float2* spc = s_c;
             int j0 = 0;
             while (j0 < nb) {
                 // next flagged slot at or after j0 (nb if none)
@@ -561,13 +431,73 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             }
             continue;
         }
-        // one copy of the loop: the instance's flag (bit 8 of the mask word) selects the general path inside the body
-        // (a second copy of the loop for flagged batches costs ~12 registers: spills at 7 waves per SIMD)
-        (void)batch_general;
-        run_loop(std::integral_constant<int, 2>{});
+        // ---- MODE 0: per-pixel decisions as lane masks in scalar registers, per-instance quadrant mask, the instance's flag
+        // (bit 8 of the mask word) selects the general path inside the body.  Software-pipelined broadcast reads, unrolled by
+        // two with ping-pong registers; the quadrant mask is read (= the LDS wait) BEFORE the next instance's reads are issued.
+        auto step_body = [&](const int qmf, const float2 CL, const float4 A, const float4 B) __attribute__((always_inline)) {
+            int qm = qmf & (int)lq;
+            GS2M_OPAQUE_SGPR(qm);   // one s_and per instance, then s_bitcmp per quadrant (not an s_and + s_cmp per quadrant)
+            const float dx0 = A.x - pxf0, dx1 = A.x - pxf1;
+            const float e[2] = {fmaf(A.z * dx0, dx0, B.y), fmaf(A.z * dx1, dx1, B.y)};
+            const float nbdx[2] = {-(A.w * dx0), -(A.w * dx1)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (qm & (1 << k)) {  // scalar branch: quadrant k intersects the splat's box and has unfinished pixels
+                    const float dy = A.y - ((k >> 1) ? pyf1 : pyf0);
+                    // q = e + dy (c' dy - b' dx): two FMAs
+                    const float qv = fmaf(fmaf(B.x, dy, nbdx[k & 1]), dy, e[k & 1]);
+                    const unsigned long long prem = gs2m_ballot_b(qv >= QMIN) & ~dn[k];   // v_cmp + s_andn2
+                    if (prem != 0ull) {
+                        float alpha = gs2m_fast_exp2(qv);
+                        unsigned long long candm = prem;
+                        if (qmf & 0x100) {  // scalar branch: general path (rare)
+                            GS2M_NO_IF_CONVERT();
+                            candm = prem & ~gs2m_ballot_b(qv > B.y);       // power > 0: skipped (forward.cu:336-337)
+                            alpha = fminf(0.99f, alpha);
+                        }
+                        const float test_T = fmaf(-T[k], alpha, T[k]);
+                        const unsigned long long satm = gs2m_ballot_b(test_T < 0.0001f) & candm;
+                        const float Tn = gs2m_lanes(candm & ~satm) ? test_T : T[k];
+                        const float wT = T[k] - Tn;  // = alpha * T for an accepted contribution, else 0
+                        C0[k] = fmaf(B.z, wT, C0[k]);
+                        C1[k] = fmaf(B.w, wT, C1[k]);
+                        C2[k] = fmaf(CL.x, wT, C2[k]);
+                        T[k] = Tn;
+                        dn[k] |= satm;
+                    }
+                }
+            }
+        };
+        {
+            const float4 *spa = s_a, *spb = s_b;
+            const float2* spc = s_c;
+            float4 A0 = spa[0], B0 = spb[0], A1, B1;
+            float2 K0 = spc[0], K1;
+            int j = 0;
+            for (; j + 1 < nb; j += 2) {
+                const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
+                GS2M_SCHED_BARRIER();
+                A1 = spa[j + 1];
+                B1 = spb[j + 1];
+                K1 = spc[j + 1];
+                GS2M_SCHED_BARRIER();
+                if (qm0 & (int)lq) step_body(qm0, K0, A0, B0);
+                const int qm1 = gs2m_uniform((int)__float_as_uint(K1.y));
+                GS2M_SCHED_BARRIER();
+                A0 = spa[j + 2];
+                B0 = spb[j + 2];
+                K0 = spc[j + 2];
+                GS2M_SCHED_BARRIER();
+                if (qm1 & (int)lq) step_body(qm1, K1, A1, B1);
+            }
+            if (j < nb) {
+                const int qm0 = gs2m_uniform((int)__float_as_uint(K0.y));
+                if (qm0 & (int)lq) step_body(qm0, K0, A0, B0);
+            }
+        }
     }
     stamp(pt_loop);
-    gs2m_wait_dma();   // never leave with a DMA write to this workgroup's LDS in flight
+    gs2m_wait_dma();   // never leave (or re-use the landing zone) with a DMA write to this wave's LDS in flight
     stamp(pt_wait);
     const size_t plane = (size_t)H * W;
 #pragma unroll
@@ -607,4 +537,57 @@ k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __re
             atomicAdd(&pc[9], (unsigned long long)(r1 - r0));
         }
     }
+}
+
+// Wave slot j of XCD x of view v -> tile, by k_tile_scan's schedule (`order`): chunks of GS2M_SCHED_CW x GS2M_SCHED_CH neighbouring
+// lists ranked by descending weight; rank p is the (p / 8)-th chunk of XCD p % 8; slot j takes half (j % LROWS) of list
+// (j / LROWS) % CHUNK of that XCD's (j / (CHUNK * LROWS))-th chunk.  false: no such tile.
+template <int LROWS>
+GS2M_DEVICE bool blend_slot_tile(const CamUniform& cam, const unsigned* __restrict__ order, const int v, const int xcd, const int j,
+                                 int& tx, int& ty) {
+    const int gx = cam.gx;
+    const int ltiles = gx * ((cam.gy + LROWS - 1) / LROWS);
+    const int lrows = ltiles / gx, cpr = (gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW;
+    const int nch = cpr * ((lrows + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
+    const int rank_c = (j / (GS2M_SCHED_CHUNK * LROWS)) * 8 + xcd;
+    if (rank_c >= nch) return false;
+    const int c = (int)order[(size_t)v * ltiles + rank_c];
+    const int k = (j / LROWS) % GS2M_SCHED_CHUNK;                 // list of the chunk
+    const int crow = c / cpr, lx = (c - crow * cpr) * GS2M_SCHED_CW + k % GS2M_SCHED_CW;
+    const int ly = crow * GS2M_SCHED_CH + k / GS2M_SCHED_CW;
+    if (lx >= gx || ly >= lrows) return false;
+    tx = lx;
+    ty = ly * LROWS + j % LROWS;
+    return ty < cam.gy;
+}
+
+// One wave per tile; the grid covers the schedule (block b runs on XCD b % 8, blocks are dispatched in order).  Round 6 measured a
+// RESIDENT grid whose waves pull the slots of their XCD's schedule from a ticket counter (dynamic hand-out): C2
+// 174 -> 207 us per pair, C3 205 -> 253, trained-like 191 -> 231, pipelined step 0.272 -> 0.300 ms, images bit-identical
+// (profiles/r6_traces/ab_blend_persistent.jsonl) -- as in round 2 (+30 %), the hardware's dispatch order IS the better dealer;
+// removed again.
+template <int WPB, int LROWS, int OCC, int MODE = 0, int PROF = 0>
+GS2M_KERNEL void __launch_bounds__(64 * WPB, OCC)
+k_blend_wave4e(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ tile_start,
+               const GeomRecs recs, const CamUniform* __restrict__ cams, int P, unsigned cap,
+               float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
+               const unsigned* __restrict__ order, unsigned long long* __restrict__ prof = nullptr, int nv_x = 0) {
+    // staged instance (40 B in three arrays): a = {mx, my, a' = -0.5 log2e ca, b' = log2e cb}, b = {c' = -0.5 log2e cc,
+    // log2 o, r, g}, c = {b, quadrant mask | general << 8 (bits)}; 2 pad slots: the software-pipelined reads run 2
+    // instances ahead.  5.6 KiB of LDS per wave with the DMA landing zone: 7 waves per SIMD fit the 160 KiB.
+    __shared__ float4 s_a[WPB][64 + 2], s_b[WPB][64 + 2];
+    __shared__ float2 s_c[WPB][64 + 2];
+    __shared__ float4 s_raw[WPB][3 * 64];   // DMA landing zone: the three 16-B vectors of the next batch's GeomRecs
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    // Views interleaved along the schedule (nv_x > 1, MODE 2): per XCD the order is chunk rank major, view minor, so the heavy
+    // chunks of ALL views of the launch start first.  With the views one after the other the heavy chunks of the last view
+    // were dispatched in the last quarter of a 4-view launch and the kernel ended on them.
+    const int nvx = gs2m_uniform(nv_x);   // > 1: that many views interleaved
+    const int v = nvx > 1 ? (int)((blockIdx.x / 8u) % (unsigned)nvx) : (int)blockIdx.y;
+    const unsigned bid = nvx > 1 ? (blockIdx.x / 8u / (unsigned)nvx) * 8u + blockIdx.x % 8u : blockIdx.x;
+    int tx, ty;
+    if (!blend_slot_tile<LROWS>(cams[v], order, v, (int)(bid % 8u), gs2m_uniform((int)(bid / 8u) * WPB + wave), tx, ty)) return;
+    blend_tile<WPB, LROWS, MODE, PROF>(v, tx, ty, cams[v], keys, tile_start, recs, P, cap, out_color, out_rgb8, rank, prof, &s_a[wave][0],
+                                       &s_b[wave][0], &s_c[wave][0], &s_raw[wave][0], lane);
 }

@@ -28,11 +28,7 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
             else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 2>), g1, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr, nvx);
             return 0;
         }
-        if (mode == 1) {   // GS2M_OPT_BLEND_MODE 1: execution-mask form of the loop
-            if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 1>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr);
-            else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 1>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr);
-            return 0;
-        }
+        // GS2M_OPT_BLEND_MODE 0: the lane-mask loop of rounds 1-4 (cross-check of mode 2)
         if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr);
         else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7>), g2, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr);
         return 0;

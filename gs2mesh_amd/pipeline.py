@@ -25,12 +25,14 @@ from .rasterizer import Rasterizer
 
 
 class RenderFusePipeline:
-    """``raster_options``: ``gs2m_raster_set_option`` values of every slot's handle, by name -- ``exact_tile_cull`` (default 1),
-    ``tile_rows`` (default 2: 16 x 32 binning tiles, same image, fewer instances), ``blend_variant``."""
+    """``raster_options``: ``gs2m_raster_set_option`` values of every slot's handle, by name -- ``exact_tile_cull`` (default
+    "auto" = ``rasterizer.auto_cull_level``: 1, or 2 for models of >= 1 M Gaussians), ``tile_rows`` (default 2: 16 x 32 binning
+    tiles, same image, fewer instances), ``blend_variant``, ``bin_lane_tiles``."""
 
     RASTER_OPTION_IDS = dict(exact_tile_cull=_lib.OPT_EXACT_TILE_CULL, tile_rows=_lib.OPT_TILE_ROWS,
                              blend_variant=_lib.OPT_BLEND_VARIANT, blend_mode=_lib.OPT_BLEND_MODE,
-                             bin_workgroups=_lib.OPT_BIN_WORKGROUPS, bin_wg_threads=_lib.OPT_BIN_WG_THREADS)
+                             bin_workgroups=_lib.OPT_BIN_WORKGROUPS, bin_wg_threads=_lib.OPT_BIN_WG_THREADS,
+                             bin_lane_tiles=_lib.OPT_BIN_LANE_TILES)
 
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None = None,
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0, *, fuse_batch=1,
@@ -56,8 +58,12 @@ class RenderFusePipeline:
         self._group = []
         self.device = int(device)
         self.bg = bg
-        opts = dict(exact_tile_cull=1, tile_rows=2)
+        opts = dict(exact_tile_cull="auto", tile_rows=2)
         opts.update(raster_options or {})
+        if opts.get("exact_tile_cull") in ("auto", -1):
+            from .rasterizer import auto_cull_level
+            opts["exact_tile_cull"] = auto_cull_level(int(gaussians["xyz"].shape[0]))
+        self.exact_tile_cull = int(opts["exact_tile_cull"] or 0)
         unknown = set(opts) - set(self.RASTER_OPTION_IDS)
         if unknown:
             raise ValueError(f"unknown raster_options {sorted(unknown)}; known: {sorted(self.RASTER_OPTION_IDS)}")

@@ -48,6 +48,15 @@ def _stream_of(x, stream):
     return C.c_void_p(0)
 
 
+def auto_cull_level(P: int) -> int:
+    """``GS2M_OPT_EXACT_TILE_CULL`` level of the pipeline-level callers (image-preserving either way): 1 = every rect with
+    corners is tested tile by tile; 2 = rects of at most 4 binning tiles keep all their tiles.  Level 2 pays on models of small
+    splats, where the test removes ~2 % of the instances at 60 % of the counting kernel's instructions (C3: count 49 -> 28 us per
+    pair, rasteriser 478 -> 452) and costs ~1 % on a scene of larger / anisotropic splats (3 % more instances to composite):
+    chosen by model size, the same rule as ``spatial_order="auto"``."""
+    return 2 if int(P) >= 1_000_000 else 1
+
+
 def make_camera(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, campos) -> _lib.Camera:
     """Host ``gs2m_camera`` from numpy-convertible matrices (transposed row-major like the
     reference's world_view_transform / full_proj_transform)."""

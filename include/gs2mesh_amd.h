@@ -34,7 +34,8 @@ extern "C" {
 #define GS2M_VERSION 600 /* 0.6.0: round-6 ABI = the round-4 ABI (401) + the round-5 entry points that 401 never counted
                             (gs2m_tsdf_block_map / _map_keys / _map_bytes / _replace / _extract_mesh / _mesh_copy,
                             gs2m_mesh_cluster, gs2m_raster_blend_cycles, GS2M_OPT_BLEND_MODE / _PROFILE) + round 6
-                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES, GS2M_OPT_EXACT_TILE_CULL level 2).  The Python binding checks it at load time */
+                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES, GS2M_OPT_EXACT_TILE_CULL level 2; GS2M_OPT_BLEND_MODE 1
+                            removed).  The Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
 
@@ -80,12 +81,13 @@ enum {
     GS2M_OPT_BIN_WORKGROUPS = 9,  /* workgroups of the counting / scatter kernels per stereo pair (default 0 = 256, one per CU: the
                                      per-workgroup histogram rows / cursors scale with their number) */
     GS2M_OPT_BIN_WG_THREADS = 10, /* upper bound of their threads per workgroup, a multiple of 64 (default 0 = 1024) */
-    GS2M_OPT_BLEND_MODE = 11,     /* compositing loop of variant 4 (three forms of the same arithmetic, bit-identical images):
+    GS2M_OPT_BLEND_MODE = 11,     /* compositing loop of variant 4 (two forms of the same arithmetic, bit-identical images):
                                      2 (default, round 5) = every staged instance evaluates all four 8x8 quadrants, candidate
                                      test = one v_cmp against the lane's own threshold, accumulate under the execution mask,
                                      the alpha-cap / power > 0 instances split out per run of the staged batch;
-                                     0 = per-pixel decisions as lane masks in scalar registers + per-instance quadrant mask;
-                                     1 = execution-mask form of 0 */
+                                     0 = per-pixel decisions as lane masks in scalar registers + per-instance quadrant mask
+                                     (the loop of rounds 1-4, kept as the cross-check).  (1, the execution-mask form of 0, was
+                                     never the fastest anywhere and was removed in round 6.) */
     GS2M_OPT_BLEND_PROFILE = 12,  /* 1 = launch the s_memtime-instrumented build of the compositing kernel (mode 2 only) and sum
                                      its per-wave phase cycles in the handle; read with gs2m_raster_blend_cycles */
     GS2M_OPT_BIN_LANE_TILES = 13, /* tuning (results never change): a tile rect of at most `value` binning tiles (0 .. 16, default 4) is

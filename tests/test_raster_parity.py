@@ -821,11 +821,11 @@ def test_hip_path_against_reference_golden(backend):
 @pytest.mark.parametrize("opts", [{_lib.OPT_BIN_WORKGROUPS: 2, _lib.OPT_BIN_WG_THREADS: 128},
                                   {_lib.OPT_BIN_WORKGROUPS: 3, _lib.OPT_BIN_WG_THREADS: 1024},
                                   {_lib.OPT_BIN_WORKGROUPS: 64, _lib.OPT_BIN_WG_THREADS: 64},
-                                  {_lib.OPT_BLEND_MODE: 1}, {_lib.OPT_BLEND_MODE: 2}])
+                                  {_lib.OPT_BLEND_MODE: 0}, {_lib.OPT_BLEND_MODE: 2}])
 def test_tuning_options_do_not_change_results(backend, opts):
     """The tuning options of gs2m_raster_set_option: k_count_tiles / k_scatter with few large workgroup chunks (several loop
-    iterations per workgroup, partial last iteration) and with small workgroups; GS2M_OPT_BLEND_MODE 1 = the compositing loop
-    without lane masks in scalar registers (execution-mask form, raster_blend.h MODE 1).  Same records, instance lists and
+    iterations per workgroup, partial last iteration) and with small workgroups; GS2M_OPT_BLEND_MODE 0 = the compositing loop
+    with lane masks in scalar registers (raster_blend.h MODE 0).  Same records, instance lists and
     image as the reference golden."""
     import os
     be = backend
@@ -1012,10 +1012,10 @@ def test_trained_like_splats_with_flip_attribution(backend, rows, cull):
 
 @pytest.mark.parametrize("rows,cull,log_s", [(1, 0, math.log(0.03)), (2, 1, math.log(0.03)), (2, 1, math.log(0.006))])
 def test_blend_loop_forms_are_bit_identical(backend, rows, cull, log_s):
-    """GS2M_OPT_BLEND_MODE 0 / 1 / 2 are three loop forms of the same arithmetic (raster_blend.h): lane masks in scalar
-    registers, execution masks, and "all four quadrants + flag-free runs" (round 5).  On `synthetic.trained_like` -- 30 % of
-    the opacities at the alpha cap (the general path of every mode), saturating pixels, near-singular conics, lists longer
-    than one staging batch -- the three images must be equal bit for bit, at both binning tile sizes."""
+    """GS2M_OPT_BLEND_MODE 0 / 2 are two loop forms of the same arithmetic (raster_blend.h): lane masks in scalar registers, and
+    "all four quadrants + flag-free runs" (round 5; mode 1, the execution-mask form, was removed in round 6).  On `synthetic.trained_like` --
+    30 % of the opacities at the alpha cap (the general path of every mode), saturating pixels, near-singular conics, lists
+    longer than one staging batch -- the images must be equal bit for bit, at both binning tile sizes."""
     W, H, f = 200, 136, 180.0
     g = synthetic.trained_like(5000, 23, log_s, focal=f)
     s, q, o = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
@@ -1027,11 +1027,11 @@ def test_blend_loop_forms_are_bit_identical(backend, rows, cull, log_s):
     be = backend
     d = be.dev
     imgs = []
-    for mode in (0, 1, 2, 3):     # 3 = mode 2 through the instrumented build (phase counters)
+    for mode in (0, 2, 2, 3):     # 3 = mode 2 through the instrumented build (phase counters)
         r = Rasterizer(0, lib=be.lib)
         r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
         r.set_option(_lib.OPT_TILE_ROWS, rows)
-        r.set_option(_lib.OPT_BLEND_MODE, min(mode, 2))
+        r.set_option(_lib.OPT_BLEND_MODE, 2 if mode else 0)
         if mode == 3:
             r.set_option(_lib.OPT_BLEND_PROFILE, 1)
         img, _ = r.forward(d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
@@ -1044,6 +1044,8 @@ def test_blend_loop_forms_are_bit_identical(backend, rows, cull, log_s):
     assert np.array_equal(imgs[0], imgs[3])
     assert c["batches"] > 0 and 0 < c["staged_instances"] <= c["listed_instances"] * (2 if rows == 2 else 1)
     assert (imgs[0] != bg[:, None, None]).any()
+    with pytest.raises(RuntimeError):
+        Rasterizer(0, lib=be.lib).set_option(_lib.OPT_BLEND_MODE, 1)
 
 
 def test_flip_bounds_count_the_decisions_at_their_thresholds():

@@ -9,12 +9,13 @@ from gs2mesh_amd.rasterizer import Rasterizer, camera_from
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="C2,C3")
-ap.add_argument("--modes", default="0,1,0,1,0,1")
+ap.add_argument("--modes", default="2,0,2,0", help="GS2M_OPT_BLEND_MODE per pass")
+ap.add_argument("--scene", default="synth", choices=["synth", "trained"])
 ap.add_argument("--groups", type=int, default=6)
 a = ap.parse_args()
 for cname in a.configs.split(","):
     cfg = synthetic.CONFIGS[cname]
-    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    g = (synthetic.trained_like if a.scene == "trained" else synthetic.synth_v1)(cfg.P, cfg.seed, cfg.log_s_mu)
     gd = {k: torch.from_numpy(v).cuda() for k, v in g.items()}
     gd["raw"] = True
     poses = synthetic.ring_poses(2 * a.groups, cfg.ring_radius, 0, cfg.n_pairs)
@@ -26,7 +27,8 @@ for cname in a.configs.split(","):
     out = torch.empty((4, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
     ref = None
     torch.cuda.synchronize()
-    for mode in [int(m) for m in a.modes.split(",")]:
+    for mname in a.modes.split(","):
+        mode = int(mname)
         R = Rasterizer(0)
         R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
         R.set_option(_lib.OPT_TILE_ROWS, 2)
@@ -53,6 +55,6 @@ for cname in a.configs.split(","):
             b = 1e3 * st["blend"][0] / max(st["blend"][1], 1) / 2
             best = b if best is None else min(best, b)
         tot = sum(1e3 * ms / max(n, 1) / 2 for ms, n in st.values())
-        print(json.dumps(dict(config=cname, mode=mode, blend_us_per_pair=round(best, 2), raster_us_per_pair=round(tot, 1),
-                              identical_to_mode0=same, max_abs_vs_mode0=dmax)), flush=True)
+        print(json.dumps(dict(config=cname, scene=a.scene, mode=mname, blend_us_per_pair=round(best, 2), raster_us_per_pair=round(tot, 1),
+                              identical_to_first=same, max_abs_vs_first=dmax)), flush=True)
         R.close()
