@@ -65,23 +65,31 @@ def committed_traffic(cfg_name):
         return {}
 
 
-def raster_only(args, cfg_name, dev, local_rank, pairs=12):
+def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", with_parity=False):
     """Render-only sub-measurement (no TSDF, serial on one stream, hipEvents per launch, the default launch shape:
-    `--pairs-per-launch` stereo pairs per chain of launches): used for the C3 sub-line."""
+    `--pairs-per-launch` stereo pairs per chain of launches): the C3 sub-line and (scene "trained_like": anisotropic, saturated
+    opacities, screen-filling background splats, depth ties; `with_parity`: first pair against the CPU oracle with the flip
+    attribution of the compositing stage) the realistic-splat sub-line."""
     import torch
     from gs2mesh_amd import _lib, synthetic
     from gs2mesh_amd.rasterizer import Rasterizer, camera_from
     from gs2mesh_amd.rasterizer import auto_cull_level
     cfg = synthetic.CONFIGS[cfg_name]
     cull = auto_cull_level(cfg.P) if args.cull_arg < 0 else int(args.cull_arg)     # this configuration's own level
-    g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
+    if scene == "trained_like":
+        g = synthetic.trained_like(cfg.P, 4242, cfg.log_s_mu, focal=cfg.focal, ring_radius=cfg.ring_radius)
+    else:
+        g = synthetic.synth_v1(cfg.P, cfg.seed, cfg.log_s_mu)
     gd = {k: torch.from_numpy(v).to(dev) for k, v in g.items()}
     gd["raw"] = True
+    g_par = g if with_parity else None        # host copy of the model: only the parity leg needs it
     del g
     poses = synthetic.ring_poses(pairs, cfg.ring_radius, 0, cfg.n_pairs)
-    cams = []
+    cams, cams_np0 = [], None
     for p in poses:
         l, r = synthetic.stereo_cameras(p, cfg.width, cfg.height, cfg.focal, cfg.focal, cfg.baseline)
+        if cams_np0 is None:
+            cams_np0 = (l, r)
         cams.append([camera_from(l), camera_from(r)])
     R = Rasterizer(local_rank)
     R.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
@@ -98,6 +106,28 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
     rgb8 = torch.empty((2 * ppl, cfg.height, cfg.width, 3), dtype=torch.uint8, device=dev)
     res = R.render_views(gd, cams[0], out_color=color[:2], out_rgb8=rgb8[:2], want_radii=True)
     R.reserve(cfg.P, 2 * ppl, cfg.width, cfg.height, int(max(res["num_rendered"]) * 1.5))
+    par = None
+    if with_parity:
+        res = R.render_views(gd, cams[0], out_color=color[:2], out_rgb8=rgb8[:2], want_radii=True)   # (the reserve above may have moved the arenas the taps read)
+        # the first pair against the reference's own kernels on the CPU (global figures) + the checked flip statement of the
+        # compositing stage on the record THIS pass projected (the fused activations move the record of a 100 : 1 anisotropic
+        # splat by rounding: tests/test_fullsize_gpu.py::test_trained_like_splats_full_size_vs_reference_kernels)
+        try:
+            from oracle import parity
+            c_h, u_h, r_h = color[:2].cpu().numpy(), rgb8[:2].cpu().numpy(), res["radii"].cpu().numpy()
+            par = parity.pair_parity(g_par, cams_np0, cfg.width, cfg.height, c_h, u_h, r_h)
+            comp = []
+            for v in range(2):
+                fa = parity.compositing_attribution(R.download_geometry(v, cfg.P), r_h[v], cfg.width, cfg.height, c_h[v])
+                comp.append({k: fa[k] for k in ("flip_pixels", "ill_conditioned_pixels", "max_abs_clean", "max_abs_flip",
+                                                "unexplained_pixels", "pixels_over_clean_bar", "ok")})
+            par["compositing"] = comp
+            par["what"] = ("first pair, both eyes (worst case): global figures vs the reference's own kernels on the CPU; `compositing` = "
+                           "flip attribution of the compositing stage on the record this pass projected (bar: max_abs_clean <= 2e-4, "
+                           "0 unexplained pixels)")
+        except Exception as e:
+            par = dict(error=str(e)[:300])
+        g_par = None
     # groups of ppl consecutive pairs = one chain of launches each
     cams = [[c for pair in cams[i:i + ppl] for c in pair] for i in range(0, len(cams) - len(cams) % ppl, ppl)]
     n_pairs = len(cams) * ppl
@@ -128,8 +158,9 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12):
                                if tr.get(k, {}).get("cull") == cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
               for k, (ms, c) in st.items()}
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
-    return dict(workload=f"{cfg_name}: {cfg.P} synth_v1 Gaussians, {cfg.width}x{cfg.height}, render only, {n_pairs} pairs, "
+    return dict(workload=f"{cfg_name}: {cfg.P} {scene} Gaussians, {cfg.width}x{cfg.height}, render only, {n_pairs} pairs, "
                          f"serial on one stream, {ppl} stereo pair(s) per launch (stage times per pair)", pairs_per_launch=ppl,
+                exact_tile_cull=cull, parity=par,
                 num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis, overflow=bool(ov),
                 ms_per_pair_wall=round(1e3 * dt, 4), stages=stages,
                 traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 * FETCH + WRITE) KiB per launch)",
@@ -184,7 +215,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 render-only sub-measurement")
+    ap.add_argument("--no-trained-like", action="store_true", help="skip the trained-like (C2-sized) render-only sub-measurement")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the 2K-step job of the steady-state probe")
+    ap.add_argument("--volume-check", action="store_true", help="add an order-independent fingerprint of the fused volume (summed over the ranks) to the line")
+    ap.add_argument("--rehearsal", action="store_true", default=bool(int(os.environ.get("GS2M_BENCH_REHEARSAL", "0"))),
+                    help="run the whole --gpus N control flow (self-spawn, barriers, dt all-reduce, reduce_volume, rank-0-only line) "
+                         "with all N ranks sharing GPU 0 over the gloo backend (RCCL refuses two ranks on one device; the exchange "
+                         "buffers are staged through host memory): a dress rehearsal of the driver's multi-GPU run on a one-GPU "
+                         "box -- the value it prints is NOT a scaling number")
     args = ap.parse_args()
     args.cull_arg = args.cull                      # as given (-1 = auto); args.cull = the level the timed configuration runs at
     if args.cull < 0:
@@ -203,7 +241,7 @@ def main():
         import socket
         import torch
         n_vis = torch.cuda.device_count()
-        if n_vis < args.gpus:
+        if n_vis < args.gpus and not args.rehearsal:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_vis} GPU(s) are visible on this node")
         with socket.socket() as so:
             so.bind(("127.0.0.1", 0))
@@ -235,7 +273,12 @@ def main():
         sys.stdout.flush()
         line_out = os.fdopen(os.dup(1), "w")
         os.dup2(2, 1)
-    if world > 1:
+    if args.rehearsal:
+        local_rank = 0                                  # every rank on GPU 0
+    if world > 1 and args.rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device(f"cuda:{local_rank}"))
@@ -384,7 +427,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=("cpu" if args.rehearsal else dev))
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())                 # identical on every rank -> identical stopping decision
         pipe.finish()    # raises if an instance arena overflowed in ANY pair of the repeat (sticky device flag)
@@ -393,6 +436,26 @@ def main():
             break
     dt = statistics.median(dts)
     t_red = statistics.median(reds) if reds else None
+    volume_check = None
+    if args.volume_check:
+        # order-independent fingerprint of the fused volume of the LAST timed job, summed over the ranks' parts (after a
+        # reduce-scatter every rank holds its share of the blocks): block count, sum of a per-key hash, sum of the weights and of
+        # the colour sums (integers: exact whatever the sharding), sum of tsdf x weight (fp32 reassociation only).  The rehearsal
+        # test compares a 2-rank strong-scaling job with the 1-rank job over the same views.
+        keys_h, tsdf_h, w_h, rgb_h = vol.download()
+        kk = keys_h.astype(np.int64)
+        khash = int(((kk[:, 0] * 73856093) ^ (kk[:, 1] * 19349663) ^ (kk[:, 2] * 83492791)).sum() & ((1 << 62) - 1)) if len(kk) else 0
+        loc = np.array([len(kk), khash, float(w_h.astype(np.float64).sum()), float(rgb_h.astype(np.float64).sum()),
+                        float((tsdf_h.astype(np.float64) * w_h).sum())], np.float64)
+        if world > 1:
+            tt = torch.from_numpy(loc.copy()) if args.rehearsal else torch.from_numpy(loc.copy()).to(dev)
+            th = torch.tensor([khash], dtype=torch.int64, device=tt.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            dist.all_reduce(th, op=dist.ReduceOp.SUM)
+            loc = tt.cpu().numpy()
+            khash = int(th.item()) & ((1 << 62) - 1)
+        volume_check = dict(blocks=int(loc[0]), key_hash=int(khash), weight_sum=float(loc[2]), rgb_sum=float(loc[3]),
+                            tsdf_weight_sum=float(loc[4]), views=int(K_total), scaling=args.scaling)
     halo_blocks = None
     if red is not None and world == 1:
         # owner-side finalisation step that follows a reduce-scatter (outside the timed job: mesh extraction is not part of the
@@ -685,13 +748,39 @@ def main():
     # ---- C3 sub-line: the HBM-bound 2 M-Gaussian configuration, render only ----------------------------------------
     c3 = None
     if rank == 0 and world == 1 and not args.no_c3 and args.config != "C3":
-        del pipe
-        vol.close()
+        try:
+            del pipe
+            vol.close()
+        except Exception:
+            pass
         torch.cuda.empty_cache()
         try:
             c3 = raster_only(args, "C3", dev, local_rank)
         except Exception as e:   # never lose the main line to the sub-measurement
             c3 = dict(error=str(e)[:300])
+
+    # ---- trained-like sub-line: the headline's size (C2) with the statistics of a TRAINED splat -- strongly
+    # anisotropic scales, 30 % of the opacities at the 0.99 cap, screen-filling background splats, depth ties -- render only
+    trained = None
+    if rank == 0 and world == 1 and not args.no_trained_like and args.config == "C2":
+        try:
+            del pipe
+            vol.close()
+        except Exception:
+            pass
+        torch.cuda.empty_cache()
+        try:
+            trained = raster_only(args, "C2", dev, local_rank, scene="trained_like", with_parity=not args.no_parity)
+            t_syn = sum(v["avg_us"] for k, v in per_kernel.items() if not k.startswith("tsdf"))
+            t_tr = trained["raster_roofline"]["t_pair_us"]
+            n_syn, n_tr = sum(N_eye), sum(trained["num_rendered_per_eye"])
+            trained["vs_synth_v1"] = dict(raster_us_per_pair=round(t_tr, 1), synth_v1_raster_us_per_pair=round(t_syn, 1),
+                                          time_ratio=round(t_tr / t_syn, 3), num_rendered_ratio=round(n_tr / n_syn, 3),
+                                          time_per_instance_ratio=round((t_tr / n_tr) / (t_syn / n_syn), 3),
+                                          note="bar (VERDICT r5 item 3): <= 1.25 x the synth_v1 C2 time per pair at equal "
+                                               "num_rendered scale; DESIGN.md section 6 says where the rest goes")
+        except Exception as e:   # never lose the main line to the sub-measurement
+            trained = dict(error=str(e)[:300])
 
     if rank == 0:
         out = dict(
@@ -704,14 +793,15 @@ def main():
                                  f"sphere depth", gaussians=cfg.P, width=Wd, height=Ht, pairs_per_gpu=K,
                         exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, spatial_order=spatial_order_used, pairs_in_flight=args.inflight, pairs_per_launch=pairs_per_launch_used,
                         tsdf_fuse_batch=(fuse_plan if fuse_plan else args.fuse_batch),
-                        parallelism=("1 GPU" if world == 1 else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF")),
+                        parallelism=("1 GPU" if world == 1 else (f"REHEARSAL: {world} ranks on one GPU over gloo (host-staged exchange), not a scaling number"
+                                                                    if args.rehearsal else f"views sharded over {world} GPUs + RCCL {args.reduce} of the TSDF"))),
             steady_state=steady,
             timing=dict(repeats=len(dts), timed_region_s=round(sum(dts), 4), statistic="median over repeats of the K-step job",
                         ms_per_step_min=round(1e3 * min(dts) / K, 4), ms_per_step_max=round(1e3 * max(dts) / K, 4),
                         host_enqueue_ms_per_step=round(1e3 * statistics.median(enq) / K, 4)),   # host side of the K steps: launches only, no sync
             num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis,
             tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, parity=par, cpu_baseline=cpu,
-            c3=c3, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
+            c3=c3, trained_like=trained, volume_check=volume_check, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
             note_stages="`stages` / `roofline` / `instrumented_ms_per_step`: second pass, serial on one stream with hipEvents "
                         "around every launch, `pairs_per_launch` stereo pairs per chain of launches = the launch shapes of the "
                         "timed pass (kernels in isolation; raster `avg_us` = launch_us / pairs_per_launch, TSDF `avg_us` per frame); "

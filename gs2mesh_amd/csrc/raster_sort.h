@@ -322,9 +322,18 @@ GS2M_DEVICE void sort_wave_regs(unsigned long long* __restrict__ kv, int n, int 
 // network (C2: k_sort_tiles_small 31.6 -> see profiles/r3_experiments.txt).  Returns false (nothing written) when a bucket holds
 // more than GS2M_WAVE_BUCKET_MAX keys (clustered or equal depths): the caller then runs the bitonic network.
 #define GS2M_WAVE_BUCKET_MAX 12
+// Round 6: depths that CLUSTER (a trained splat's Gaussians sit on surfaces: a tile's frustum crosses a shell twice, and a third
+// of its keys fall into 2 % of its depth range) overflowed the equal-width buckets -- 43 % of the wave-sorted lists of the
+// C2-sized `synthetic.trained_like` scene (72 % of their keys) fell back to the bitonic network (sort 12.8 -> 35.7 us per pair
+// against `synth_v1`).  A list whose fullest bucket holds more than GS2M_WAVE_BUCKET_REFINE keys is REFINED instead: bucket b with
+// c_b keys is split into c_b equal-width sub-buckets (fine bucket = start_b + floor(frac_b * c_b), frac_b = position inside b:
+// monotone in the depth, n fine buckets in all), a second counting pass places the keys, and the rank loop runs over the fine
+// buckets (measured on that scene by CPU replay: no list overflows any more, fullest fine bucket 3 .. 8 keys).  Same result:
+// the ranks are still a permutation in key order.
+#define GS2M_WAVE_BUCKET_REFINE 6
 template <int E>
 GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int n, const int lane, unsigned long long* s_key,
-                                  unsigned* s_cnt) {
+                                  unsigned* s_cnt, unsigned* s_fine) {
     static_assert(E >= 2 && (E & 1) == 0, "two 16-bit counters per word, E / 2 words per lane");
     constexpr int NB = 64 * E;      // buckets (>= n)
     unsigned long long k[E];
@@ -355,53 +364,84 @@ GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int
         const unsigned b = (unsigned)((float)((unsigned)(key >> 32) - dmin) * scale);
         return b < (unsigned)NB ? b : (unsigned)NB - 1u;
     };
+    // counting pass over `cnt` (two 16-bit counters per word): the returned old value is the key's arrival slot in its bucket;
+    // then lane l owns buckets [l E, (l + 1) E) = words [l E / 2, (l + 1) E / 2): exclusive scan -> starts in place, the
+    // fullest bucket of the list as the return value (wave-uniform)
     unsigned short slot[E];
+    unsigned bk[E];     // bucket of k[r] in the map in force (coarse, then fine)
+    auto count_and_scan = [&](unsigned* cnt) __attribute__((always_inline)) -> unsigned {
 #pragma unroll
-    for (int r = 0; r < E; ++r) {
-        slot[r] = 0;
-        if (r * 64 + lane < n) {
-            const unsigned b = bucket_of(k[r]);
-            const unsigned old = atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) << 4));
-            slot[r] = (unsigned short)((old >> ((b & 1u) << 4)) & 0xffffu);
+        for (int r = 0; r < E; ++r) {
+            slot[r] = 0;
+            if (r * 64 + lane < n) {
+                const unsigned b = bk[r];
+                const unsigned old = atomicAdd(&cnt[b >> 1], 1u << ((b & 1u) << 4));
+                slot[r] = (unsigned short)((old >> ((b & 1u) << 4)) & 0xffffu);
+            }
         }
-    }
-    gs2m_wave_sync();
-    // lane l owns buckets [l E, (l + 1) E) = words [l E / 2, (l + 1) E / 2)
-    unsigned cw[E / 2];
-    unsigned sum = 0u, mx = 0u;
+        gs2m_wave_sync();
+        unsigned cw[E / 2];
+        unsigned sum = 0u, mx = 0u;
 #pragma unroll
-    for (int w = 0; w < E / 2; ++w) {
-        cw[w] = s_cnt[lane * (E / 2) + w];
-        const unsigned c0 = cw[w] & 0xffffu, c1 = cw[w] >> 16;
-        sum += c0 + c1;
-        mx = c0 > mx ? c0 : mx;
-        mx = c1 > mx ? c1 : mx;
-    }
-    unsigned incl = sum;
+        for (int w = 0; w < E / 2; ++w) {
+            cw[w] = cnt[lane * (E / 2) + w];
+            const unsigned c0 = cw[w] & 0xffffu, c1 = cw[w] >> 16;
+            sum += c0 + c1;
+            mx = c0 > mx ? c0 : mx;
+            mx = c1 > mx ? c1 : mx;
+        }
+        unsigned incl = sum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned y = gs2m_shfl_up(incl, d);
-        if (lane >= d) incl += y;
-    }
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned y = gs2m_shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        const unsigned o = gs2m_shfl_xor(mx, m);
-        mx = o > mx ? o : mx;
-    }
-    if (mx > GS2M_WAVE_BUCKET_MAX) return false;   // wave-uniform
-    unsigned run = incl - sum;
+        for (int m = 32; m > 0; m >>= 1) {
+            const unsigned o = gs2m_shfl_xor(mx, m);
+            mx = o > mx ? o : mx;
+        }
+        unsigned run = incl - sum;
 #pragma unroll
-    for (int w = 0; w < E / 2; ++w) {
-        const unsigned c0 = cw[w] & 0xffffu, c1 = cw[w] >> 16;
-        s_cnt[lane * (E / 2) + w] = run | ((run + c0) << 16);   // starts (<= 512)
-        run += c0 + c1;
+        for (int w = 0; w < E / 2; ++w) {
+            const unsigned c0 = cw[w] & 0xffffu, c1 = cw[w] >> 16;
+            cnt[lane * (E / 2) + w] = run | ((run + c0) << 16);   // starts (<= 512)
+            run += c0 + c1;
+        }
+        if (lane == 63) cnt[NB / 2] = (unsigned)n;                 // sentinel: start of bucket NB
+        gs2m_wave_sync();
+        return (unsigned)gs2m_uniform((int)mx);
+    };
+    auto start_in = [&](const unsigned* cnt, unsigned b) -> unsigned { return (cnt[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; };
+#pragma unroll
+    for (int r = 0; r < E; ++r) bk[r] = r * 64 + lane < n ? bucket_of(k[r]) : 0u;
+    unsigned mx = count_and_scan(s_cnt);
+    // fine bucket of a key: its coarse bucket b split into c_b equal parts (reads the coarse starts: s_cnt stays as it is)
+    auto fine_of = [&](unsigned long long key) -> unsigned {
+        const float x = (float)((unsigned)(key >> 32) - dmin) * scale;
+        unsigned b = (unsigned)x;
+        b = b < (unsigned)NB ? b : (unsigned)NB - 1u;
+        const unsigned st = start_in(s_cnt, b), c = start_in(s_cnt, b + 1u) - st;
+        float frac = x - (float)b;                              // exact: both < 2^24, x - floor(x) is representable
+        frac = frac < 0.99999f ? frac : 0.99999f;               // (the clamped last bucket)
+        const unsigned sub = (unsigned)(frac * (float)c);
+        return st + (sub < c ? sub : c - 1u);                   // c >= 1 for the bucket of an existing key
+    };
+    const bool refined = mx > GS2M_WAVE_BUCKET_REFINE;        // wave-uniform
+    const unsigned* starts = s_cnt;
+    if (refined) {
+#pragma unroll
+        for (int w = 0; w < E / 2; ++w) s_fine[w * 64 + lane] = 0u;
+#pragma unroll
+        for (int r = 0; r < E; ++r) bk[r] = r * 64 + lane < n ? fine_of(k[r]) : 0u;
+        gs2m_wave_sync();
+        mx = count_and_scan(s_fine);
+        starts = s_fine;
     }
-    if (lane == 63) s_cnt[NB / 2] = (unsigned)n;                 // sentinel: start of bucket NB
-    gs2m_wave_sync();
-    auto start_of = [&](unsigned b) -> unsigned { return (s_cnt[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; };
+    if (mx > GS2M_WAVE_BUCKET_MAX) return false;   // wave-uniform (equal depths in bulk: the bitonic network)
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        const unsigned st = start_of(r * 64 + lane < n ? bucket_of(k[r]) : 0u);   // unconditional read: E reads in flight
+        const unsigned st = start_in(starts, bk[r]);   // unconditional read: E reads in flight (lanes without a key read bucket 0)
         if (r * 64 + lane < n) s_key[st + slot[r]] = k[r];
     }
     gs2m_wave_sync();
@@ -417,13 +457,13 @@ GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const bool in = r * 64 + lane < n;
-        const unsigned b = in ? bucket_of(key[r]) : 0u;
-        const unsigned st = start_of(b), en = start_of(b + 1u);
+        const unsigned b = in ? (refined ? fine_of(key[r]) : bucket_of(key[r])) : 0u;
+        const unsigned st = start_in(starts, b), en = start_in(starts, b + 1u);
         lo[r] = st;
         len[r] = in ? en - st : 0u;
         rank[r] = 0u;
     }
-    const unsigned rounds = (unsigned)gs2m_uniform((int)mx);
+    const unsigned rounds = mx;
     for (unsigned q = 0; q < rounds; ++q) {
 #pragma unroll
         for (int r = 0; r < E; ++r) {
@@ -527,9 +567,11 @@ k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __rest
                    unsigned cap, unsigned long long* __restrict__ tmp, const unsigned* __restrict__ sort_lists, int fold_rank) {
     __shared__ unsigned long long s_key_all[WPB][GS2M_SORT_WAVE];
     __shared__ unsigned s_cnt_all[WPB][GS2M_SORT_WAVE / 2 + 2];
+    __shared__ unsigned s_fine_all[WPB][GS2M_SORT_WAVE / 2 + 2];    // counters / starts of the refined (fine) buckets
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     unsigned long long* s_key = s_key_all[wave];
     unsigned* s_cnt = s_cnt_all[wave];
+    unsigned* s_fine = s_fine_all[wave];
     const int t = gs2m_uniform((int)blockIdx.x * WPB + wave), v = (int)blockIdx.y;
     if (t < tiles) {
         unsigned b = tile_start[(size_t)v * (tiles + 1) + t];
@@ -543,11 +585,11 @@ k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __rest
         } else if (n <= 64) {
             sort_wave_regs<1>(kv, n, lane);
         } else if (n <= 128) {
-            if (!sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt)) sort_wave_regs<2>(kv, n, lane);
+            if (!sort_wave_bucket<2>(kv, n, lane, s_key, s_cnt, s_fine)) sort_wave_regs<2>(kv, n, lane);
         } else if (n <= 256) {
-            if (!sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt)) sort_wave_regs<4>(kv, n, lane);
+            if (!sort_wave_bucket<4>(kv, n, lane, s_key, s_cnt, s_fine)) sort_wave_regs<4>(kv, n, lane);
         } else {
-            if (!sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt)) sort_wave_regs<8>(kv, n, lane);
+            if (!sort_wave_bucket<8>(kv, n, lane, s_key, s_cnt, s_fine)) sort_wave_regs<8>(kv, n, lane);
         }
     }
     // fold_rank: the previous call on the handle found every size class empty, so the class kernels are not launched; the first

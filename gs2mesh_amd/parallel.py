@@ -44,6 +44,50 @@ _OVERFLOW_TEXT = ((1, "block pool exhausted (raise max_blocks)"), (2, "hash tabl
                   (8, "a voxel did not fit the packed exchange form (weight > 1023 or colour sum >= 2^18)"))
 
 
+def _via_host(group, *tensors) -> bool:
+    """gloo takes device tensors for a few collectives only (all_reduce, broadcast): every other one -- and, to keep one code
+    path, all of them -- is staged through host memory when the group is a gloo group and the buffers live on a GPU.  That is
+    the REHEARSAL configuration (`bench.py --rehearsal`, tests/test_bench_gpu.py): the whole N > 1 control flow with the ranks
+    sharing one GPU.  Under RCCL (backend "nccl") nothing is staged."""
+    return dist.get_backend(group) == "gloo" and any(t.is_cuda for t in tensors)
+
+
+def _all_reduce(t, op, group):
+    if _via_host(group, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _reduce_scatter_tensor(out, inp, group):
+    if _via_host(group, out, inp):
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.reduce_scatter_tensor(ho, hi, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(ho)
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_to_all_single(out, inp, group, **kw):
+    if _via_host(group, out, inp):
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_to_all_single(ho, hi, group=group, **kw)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, inp, group=group, **kw)
+
+
+def _all_gather_into_tensor(out, inp, group):
+    if _via_host(group, out, inp):
+        ho, hi = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_gather_into_tensor(ho, hi, group=group)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def _mark(marks, name):
     """profiling aid (tools/reduce_breakdown.py): phase boundary, device drained; nothing happens without a list"""
     if marks is not None:
@@ -122,7 +166,7 @@ def _canonical_keys_gather(volume, group=None, always_collective: bool = False, 
     buf[K:].copy_(head_local)
     gathered = volume.exchange_buffer("keys_recv", (world * (K + 2), 3), torch.int32, buf.device)
     _mark(marks, "keys: local list + header")
-    dist.all_gather_into_tensor(gathered, buf, group=group)
+    _all_gather_into_tensor(gathered, buf, group)
     _mark(marks, "keys: all_gather")
     g = gathered.view(world, K + 2, 3)
     head = g[:, K:, :].cpu().numpy().astype(np.int64)         # the one host read of the exchange; [world, 2, 3]
@@ -172,7 +216,7 @@ def canonical_keys(volume, group=None, always_collective: bool = False, marks=No
     flags = int(bool(volume.replicated)) | (2 if volume.has_halo else 0)
     volume.block_map(cells, rank, world, flags)
     _mark(marks, "keys: local block map")
-    dist.all_reduce(cells, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(cells, dist.ReduceOp.MAX, group)
     _mark(marks, "keys: all_reduce(MAX, u8)")
     n_cells = nb - _MAP_HEADER - 8 * world
     kbuf = volume.exchange_buffer("keys_union", (min(world * K, n_cells), 3), torch.int32, dev)
@@ -211,7 +255,7 @@ def _agree_on_window(volume, group, world, dev):
     lo, dim = volume.exchange_window
     vals = [int(x) for x in (*lo, *dim, volume.max_blocks)]
     t = torch.tensor(vals + [-x for x in vals], dtype=torch.int64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(t, dist.ReduceOp.MAX, group)
     got = t.cpu().tolist()
     if any(got[i] != -got[7 + i] for i in range(7)):
         what = "max_blocks" if all(got[i] == -got[7 + i] for i in range(6)) else "exchange window (set_exchange_window)"
@@ -282,28 +326,28 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
             if algo == "direct":
                 # slice p of every rank's buffer goes straight to rank p (one all_to_all per dtype), which sums its R copies
                 fall = volume.exchange_buffer("a2a_f32", (world, per, planes, 4096), torch.float32, dev)
-                dist.all_to_all_single(fall.view(-1), fbuf.view(-1), group=group)
+                _all_to_all_single(fall.view(-1), fbuf.view(-1), group)
                 torch.sum(fall, dim=0, out=fout)
                 n_coll += 1
                 if packed:
                     iall = volume.exchange_buffer("a2a_i64", (world, per, 4096), torch.int64, dev)
-                    dist.all_to_all_single(iall.view(-1), ibuf.view(-1), group=group)
+                    _all_to_all_single(iall.view(-1), ibuf.view(-1), group)
                     torch.sum(iall, dim=0, out=iout)
                     n_coll += 1
             else:
-                dist.reduce_scatter_tensor(fout, fbuf, op=dist.ReduceOp.SUM, group=group)
+                _reduce_scatter_tensor(fout, fbuf, group)
                 n_coll += 1
                 if packed:
-                    dist.reduce_scatter_tensor(iout, ibuf, op=dist.ReduceOp.SUM, group=group)
+                    _reduce_scatter_tensor(iout, ibuf, group)
                     n_coll += 1
             fbuf, ibuf = fout, iout
             lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
             kpad = kpad[rank * per: (rank + 1) * per]
         else:
-            dist.all_reduce(fbuf, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce(fbuf, dist.ReduceOp.SUM, group)
             n_coll += 1
             if packed:
-                dist.all_reduce(ibuf, op=dist.ReduceOp.SUM, group=group)
+                _all_reduce(ibuf, dist.ReduceOp.SUM, group)
                 n_coll += 1
     _mark(marks, "collectives")
     if packed:
@@ -318,7 +362,7 @@ def reduce_volume(volume, group=None, mode: str = "reduce_scatter", always_colle
         volume.flags_device(flag)
         if collective and world > 1:
             flag &= 8
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            _all_reduce(flag, dist.ReduceOp.MAX, group)
             n_coll += 1
         bad = int(flag.item()) & 8
         if bad:
@@ -397,9 +441,9 @@ def exchange_halo(volume, info, group=None):
     if s_all.numel():
         volume.pack(keys[s_all].contiguous(), _lib.XFORM_RAW_F32, sbuf[: s_all.numel()])
     rbuf = volume.exchange_buffer("halo_recv", (max(int(r_all.numel()), 1), 5, 4096), torch.float32, dev)
-    dist.all_to_all_single(rbuf[: r_all.numel()].reshape(-1), sbuf[: s_all.numel()].reshape(-1),
-                           output_split_sizes=[c * 5 * 4096 for c in recv_counts],
-                           input_split_sizes=[c * 5 * 4096 for c in send_counts], group=group)
+    _all_to_all_single(rbuf[: r_all.numel()].reshape(-1), sbuf[: s_all.numel()].reshape(-1), group,
+                       output_split_sizes=[c * 5 * 4096 for c in recv_counts],
+                       input_split_sizes=[c * 5 * 4096 for c in send_counts])
     if r_all.numel():
         volume.unpack(keys[r_all].contiguous(), _lib.XFORM_RAW_F32, rbuf[: r_all.numel()], halo=True)
     volume.status()

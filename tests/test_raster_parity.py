@@ -326,6 +326,46 @@ def test_mid_size_lists_use_the_bucket_sort(backend, depths):
     assert_image_close(img, ref_img)
 
 
+@pytest.mark.parametrize("depths", ["two_shells", "shell_and_ties", "one_sliver"])
+def test_wave_sized_lists_with_clustered_depths_take_the_refined_buckets(backend, depths):
+    """64 < n <= 512 instances per tile with depths that CLUSTER (a trained splat sits on surfaces): the equal-width buckets of
+    the wave sort overflow and the list is refined (round 6: bucket b with c_b keys split into c_b sub-buckets, second counting
+    pass; raster_sort.h) instead of falling back to the bitonic network.  `two_shells`: two thin depth bands + a sparse rest;
+    `shell_and_ties`: a band + runs of exactly equal depths (ties resolved by Gaussian id, the fine buckets cannot split them);
+    `one_sliver`: 97 % of the keys within 1e-4 of one depth (refinement of a bucket that holds nearly everything).  The instance
+    lists must equal the oracle's exactly."""
+    W, H, f = 160, 96, 300.0
+    P = 5000
+    rng = np.random.default_rng(29)
+    xyz = rng.uniform(-1.0, 1.0, (P, 3)).astype(np.float32)
+    xyz[:, 1] *= 0.6
+    u = rng.uniform(size=P)
+    if depths == "two_shells":
+        xyz[:, 2] = np.where(u < 0.45, rng.normal(-0.4, 2e-3, P), np.where(u < 0.9, rng.normal(0.5, 2e-3, P), rng.uniform(-1, 1, P)))
+    elif depths == "shell_and_ties":
+        xyz[:, 2] = np.where(u < 0.5, rng.normal(0.2, 3e-3, P), np.round(rng.uniform(-1, 1, P) * 4) / 4)
+    else:
+        xyz[:, 2] = np.where(u < 0.97, rng.normal(0.3, 1e-4, P), rng.uniform(-1, 1, P))
+    xyz = xyz.astype(np.float32)
+    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
+    o = rng.uniform(0.02, 0.3, P).astype(np.float32)
+    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+    s = np.full((P, 3), 0.03, np.float32)
+    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
+    r, img, radii = run_forward(backend, cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
+    assert r.last_num_rendered == ref_n
+    geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
+                                 cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
+    ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
+    sizes = (ref_ranges[:, 1] - ref_ranges[:, 0]).astype(np.int64)
+    assert ((sizes > 64) & (sizes <= 512)).sum() >= 8 and ((sizes > 128) & (sizes <= 512)).sum() >= 2, sizes
+    pl, ranges = r.download_binning(0, ref_n, 10 * 6)
+    np.testing.assert_array_equal(ranges, ref_ranges)
+    np.testing.assert_array_equal(pl, ref_pl)
+    assert_image_close(img, ref_img)
+
+
 def test_dense_lists_use_the_large_bucket_class(backend):
     """4096 < n <= 8192 instances in a list on a FRESH handle (no class hint: the size-class kernels run, not the LDS-free
     stand-in): the <8192> bucket + rank sort with its capped bucket count (up to 2 keys per bucket on average), next to
