@@ -488,299 +488,324 @@ def main():
                       note=f"slope between the {K}-step and the {2 * K}-step job (both timed as the contract says): steady state = "
                            f"(T({2 * K}) - T({K})) / {K}; fill_drain = T({K}) - {K} x steady state (pipeline fill, last TSDF sweep, final sync)")
 
-    # ---- instrumented pass (hipEvents around every kernel launch, on the work stream) ---------
-    vol.reset()
-    vol.status()
-    R.set_option(_lib.OPT_STAGE_TIMING, 1)
-    vol.set_stage_timing(True)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    ppl = pairs_per_launch_used
-    for i in range(Wm, Wm + K, ppl):
-        step_serial(i, min(ppl, Wm + K - i))
-    serial_flush()
-    torch.cuda.synchronize()
-    dt_instr = time.perf_counter() - t1
-    st_r = R.stage_times()
-    st_t = vol.stage_times()
-    R.set_option(_lib.OPT_STAGE_TIMING, 0)
-    vol.set_stage_timing(False)
-    n_blocks, block_updates, _ = vol.status()
-    # raster stages: a launch covers `ppl` stereo pairs -> avg_us is quoted per PAIR (the unit of the algorithmic bytes) next to
-    # the launch duration itself; TSDF stages: a sweep counts as its frames (gs2m_tsdf_stage_times), avg_us is per frame
-    stages = {k: dict(avg_us=1e3 * ms / max(c, 1) / ppl, launch_us=1e3 * ms / max(c, 1), launches=int(c)) for k, (ms, c) in st_r.items()}
-    stages.update({k: dict(avg_us=1e3 * ms / max(c, 1), launch_us=None, launches=int(c)) for k, (ms, c) in st_t.items()})
-    # voxels that actually updated (pass sdf > -trunc): every update adds 1 to the voxel's weight
-    keys_h, tsdf_h, weight_h, _ = vol.download()
-    U_total = float(weight_h.sum())
-    U_frame = U_total / K
-    blocks_frame = block_updates / K
-
-    # ---- algorithmic bytes, per kernel launch = per stereo pair ------------------
-    N_eye = [float(x) for x in num_rendered0]           # instances produced by this build (culling mode)
-    alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye, U_frame)
-    t_raster = sum(stages[k]["avg_us"] for k in _lib.RASTER_STAGES) * 1e-6
-    t_tsdf = sum(stages[k]["avg_us"] for k in _lib.TSDF_STAGES) * 1e-6
-    dom = max(stages, key=lambda k: stages[k]["avg_us"] * stages[k]["launches"] * (ppl if stages[k]["launch_us"] else 1))
-    upl = ppl if stages[dom]["launch_us"] else 1        # units (stereo pairs) one launch of the dominant kernel covers
-    t_launch = (stages[dom]["launch_us"] or stages[dom]["avg_us"]) * 1e-6
-    achieved = alg[dom] * upl / t_launch               # algorithmic bytes per launch / live launch duration
-    traffic, traffic_source, valu = None, None, None
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
+    # Everything from here to the JSON line is DIAGNOSTICS of the timed job above (instrumented pass, byte models, parity, CPU baseline,
+    # sub-lines): rank 0 only -- the other ranks of a multi-GPU job go straight to the final barrier -- and behind one try / except:
+    # the 8-rank rehearsal (round 6) lost a rank to a division by zero in here; a diagnostic must never cost the driver its line.
+    diag_error = None
+    N_eye = [float(x) for x in num_rendered0]
+    tsdf, per_kernel, roofline, raster_roofline, par, cpu, c3, trained, dt_instr = None, None, None, None, None, None, None, None, 0.0
+    if rank == 0:
         try:
-            tr = json.load(open(prof))
-            ent = tr.get(args.config, {}).get(dom)
-            if ent and ent.get("cull") == args.cull and ent.get("blend_variant", 4) == args.blend:
-                # the committed counters are per launch of the PROFILED command (its launches cover `pairs_per_launch` pairs,
-                # 1 in the entries of round 3): scaled to the launches of this run
-                scale = upl / max(1, int(ent.get("pairs_per_launch", 1)))
-                traffic = int(ent["hbm_bytes_per_launch"] * scale)
-                traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 2')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                  f"passes of tools/profile_round.sh, ({ent.get('read_factor', 2.0)} * FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')} "
-                                  f"[read factor per access pattern: streams 2, gathers 1, profiles/r5_gather_fetch_calibration.json] "
-                                  f"({ent.get('pairs_per_launch', 1)} stereo pair(s) per launch there, {upl} here); "
-                                  "committed profile, not measured in this run")
-                if ent.get("valu_insts_per_launch"):
-                    # the dominant kernel is VALU-bound: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC
-                    # pass) / live launch time, against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
-                    n_valu = ent["valu_insts_per_launch"] * scale
-                    rate = n_valu / t_launch
-                    valu = dict(insts_per_launch=int(n_valu), achieved_Ginst_s=round(rate / 1e9, 1),
-                                peak_Ginst_s=1228.8, frac=round(rate / 1228.8e9, 4),
-                                measured_plain_fp32_Ginst_s=1010.0,
-                                note="tools/ubench/valu_rates.hip on this chip, 7 waves/SIMD: plain fp32 VALU op 2.4 cycles per "
-                                     "wave64 instruction per SIMD (1010 G inst/s), v_exp_f32 8.1, v_cmp / v_cndmask through a lane "
-                                     "mask ~4, v_pk_fma_f32 7.0")
-                    for name in ("salu_insts_per_launch", "branch_insts_per_launch"):
-                        if ent.get(name):
-                            valu[name] = int(ent[name] * scale)
-                    if ent.get("salu_insts_per_launch") and ent.get("branch_insts_per_launch"):
-                        valu["scalar_plus_branch_per_valu"] = round((ent["salu_insts_per_launch"] + ent["branch_insts_per_launch"]) /
-                                                                    ent["valu_insts_per_launch"], 3)
-                    if ent.get("valu_trans_per_launch"):
-                        # lower bound of the VALU issue time of this instruction mix: transcendental ops at 8.1 cycles,
-                        # everything else priced as a plain op (the lane-mask compares / selects cost more)
-                        tr_n = ent["valu_trans_per_launch"] * scale
-                        cyc = 8.1 * tr_n + 2.4 * (n_valu - tr_n)
-                        valu["trans_insts_per_launch"] = int(tr_n)
-                        valu["issue_bound_us_at_2p4GHz"] = round(cyc / 1024 / 2.4e3, 1)
-                        valu["frac_of_issue_bound"] = round(valu["issue_bound_us_at_2p4GHz"] / (t_launch * 1e6), 3)
-        except Exception:
-            traffic = None
-    # `bound` names what limits the kernel; achieved / peak / frac stay the HBM figures the contract asks for
-    roofline = dict(kernel=dom, bound=("valu" if dom == "blend" else "hbm"), frac_basis="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_source,
-                    traffic_over_algorithmic=(round(traffic / (alg[dom] * upl), 3) if traffic else None),
-                    algorithmic_bytes_per_launch=int(alg[dom] * upl), avg_launch_us=round(t_launch * 1e6, 2),
-                    stereo_pairs_per_launch=upl, valu=valu,
-                    note="blend is VALU-bound (exp + 10 VALU ops per contributing pixel x instance, data served from LDS); "
-                         "HBM fraction reported as the contract asks, see DESIGN.md")
-    tr_all = committed_traffic(args.config)
-    def stage_traffic(k):
-        """committed PMC traffic of stage k, per unit of `avg_us` (a stereo pair; a FRAME for the TSDF stages, whose launches
-        cover `frames_per_launch` frames)"""
-        ent = tr_all.get(k, {})
-        if ent.get("cull") != args.cull or ent.get("hbm_bytes_per_launch") is None:
-            return None
-        return int(ent["hbm_bytes_per_launch"] / max(1, int(ent.get("frames_per_launch", ent.get("pairs_per_launch", 1)))))
-
-    per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launch_us=(round(v["launch_us"], 2) if v["launch_us"] else None), launches=v["launches"],
-                          alg_GBps=round(alg[k] / max(v["avg_us"], 1e-9) / 1e3, 1),
-                          frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4),
-                          traffic=stage_traffic(k))
-                  for k, v in stages.items()}
-    if "tsdf_integrate" in per_kernel:
-        # SURVEY.md 8(d) asks for BOTH byte models of the TSDF: the per-frame streaming model (what Open3D does: state read +
-        # written per frame, 40 B x updated voxels + 7 B x pixels) and the job-level lower bound (state of every touched voxel
-        # read + written ONCE per job, 20 B x voxels of the touched blocks, + the 7 B x pixels of every frame).  The
-        # voxel-stationary sweep moves the state once per sweep, so it is priced against the second; the first says what the
-        # frame-by-frame algorithm would have to move.
-        e = per_kernel["tsdf_integrate"]
-        t_frame = max(e["avg_us"], 1e-9) * 1e-6
-        B_frame = alg["tsdf_integrate"]
-        B_job_frame = (20.0 * n_blocks * 4096 + 7.0 * Wd * Ht * K) / max(K, 1)
-        e.update(frac_hbm_frame_model=round(B_frame / t_frame / HBM_PEAK, 4), alg_bytes_frame_model=int(B_frame),
-                 frac_hbm_job_bound=round(B_job_frame / t_frame / HBM_PEAK, 4), alg_bytes_job_bound_per_frame=int(B_job_frame),
-                 traffic_over_job_bound=(round(e["traffic"] / B_job_frame, 2) if e.get("traffic") else None),
-                 note="per FRAME: frame model = 40 B x updated voxels + 7 B x pixels (Open3D's per-frame streaming); job bound = "
-                      "(20 B x voxels of the touched blocks + 7 B x pixels x frames) / frames; traffic = committed PMC bytes of "
-                      "a sweep / its frames")
-    raster_roofline = dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
-                           achieved_GBps=round(B_pair / t_raster / 1e9, 1), frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4),
-                           frac_of_6p29TBps=round(B_pair / t_raster / 6.29e12, 4),
-                           render_only_pairs_per_s=round(1.0 / t_raster, 1))
-    tsdf = dict(mvoxel_updates_per_s_job=round(K_total * blocks_frame * 4096 / dt / 1e6, 1),
-                mvoxel_updates_per_s_kernels=round(blocks_frame * 4096 / t_tsdf / 1e6, 1),
-                blocks_per_frame=round(blocks_frame, 1), updated_voxels_per_frame=round(U_frame, 1),
-                allocated_blocks=int(n_blocks), voxel_length=cfg.voxel_length, sdf_trunc=cfg.sdf_trunc,
-                unit="Mvoxel-updates/s (4096 per touched 16^3 block per frame)")
-    if rank == 0 and world == 1:
-        # mesh extraction of the fused volume, OUTSIDE the timed metric (once per scene, tsdf_utils.py:108 + :133): marching cubes
-        # + vertex welding on the device, indexed mesh over PCIe, connected components on the device
-        try:
+            # ---- instrumented pass (hipEvents around every kernel launch, on the work stream) ---------
+            vol.reset()
+            vol.status()
+            R.set_option(_lib.OPT_STAGE_TIMING, 1)
+            vol.set_stage_timing(True)
             torch.cuda.synchronize()
-            tm0 = time.perf_counter()
-            mesh = vol.extract_triangle_mesh()
-            tm1 = time.perf_counter()
-            m_labels, m_counts, _ = mesh.cluster_connected_triangles()
-            tm2 = time.perf_counter()
-            tsdf["mesh"] = dict(triangles=int(mesh.triangles.shape[0]), vertices=int(mesh.vertices.shape[0]),
-                                clusters=int(len(m_counts)), largest_cluster=int(m_counts.max()) if len(m_counts) else 0,
-                                extract_weld_ms=round(1e3 * (tm1 - tm0), 2), cluster_ms=round(1e3 * (tm2 - tm1), 2),
-                                bytes_over_pcie=int(mesh.vertices.nbytes + mesh.vertex_colors.nbytes + mesh.edge_index.nbytes +
-                                                    mesh.triangles.nbytes + m_labels.nbytes + m_counts.nbytes),
-                                soup_bytes_round4=int(mesh.triangles.shape[0]) * (2 * 72 + 48),
-                                note="gs2m_tsdf_extract_mesh + gs2m_tsdf_mesh_copy, gs2m_mesh_cluster; wall times incl. the "
-                                     "host allocations and copies; not part of `value`")
-            del mesh
-        except Exception as e:   # the mesh is an extra of the line, never a reason to lose it
-            tsdf["mesh"] = dict(error=str(e)[:200])
-    if red is not None:
-        tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
-                              union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),
-                              collectives=int(red.get("collectives", 0)), payload=red.get("payload"), algo=red.get("algo"),
-                              frames_total=int(red.get("frames_total", 0)), halo_blocks_after=halo_blocks,
-                              world=world, always_collective=bool(args.always_collective),
-                              note="bytes_per_rank = packed union blocks one rank contributes (12 B / voxel packed, 20 B / voxel f32); "
-                                   "a reduce-scatter moves (N-1)/N of it over xGMI")
+            t1 = time.perf_counter()
+            ppl = pairs_per_launch_used
+            for i in range(Wm, Wm + K, ppl):
+                step_serial(i, min(ppl, Wm + K - i))
+            serial_flush()
+            torch.cuda.synchronize()
+            dt_instr = time.perf_counter() - t1
+            st_r = R.stage_times()
+            st_t = vol.stage_times()
+            R.set_option(_lib.OPT_STAGE_TIMING, 0)
+            vol.set_stage_timing(False)
+            n_blocks, block_updates, _ = vol.status()
+            # raster stages: a launch covers `ppl` stereo pairs -> avg_us is quoted per PAIR (the unit of the algorithmic bytes) next to
+            # the launch duration itself; TSDF stages: a sweep counts as its frames (gs2m_tsdf_stage_times), avg_us is per frame
+            stages = {k: dict(avg_us=1e3 * ms / max(c, 1) / ppl, launch_us=1e3 * ms / max(c, 1), launches=int(c)) for k, (ms, c) in st_r.items()}
+            stages.update({k: dict(avg_us=1e3 * ms / max(c, 1), launch_us=None, launches=int(c)) for k, (ms, c) in st_t.items()})
+            # voxels that actually updated (pass sdf > -trunc): every update adds 1 to the voxel's weight
+            keys_h, tsdf_h, weight_h, _ = vol.download()
+            U_total = float(weight_h.sum())
+            U_frame = U_total / K
+            blocks_frame = block_updates / K
 
-    # ---- oracle legs (rank 0, N = 1 only): parity of the first timed pair, CPU baseline --------------------------
-    cpu, par = None, None
-    if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity):
-        import oracle
-    if rank == 0 and world == 1 and not args.no_parity:
-        # the first timed pair as the timed configuration renders it (this handle: tile_rows, cull, packed SH, fused
-        # activations), against the CPU oracle (the reference's own kernels when oracle/_ref is prebuilt)
-        from oracle import parity
-        rr = R.render_views(gd, cams[Wm], out_color=color, out_rgb8=rgb8, want_radii=True)
-        par = parity.pair_parity(g, cams_np[Wm], Wd, Ht, color.cpu().numpy(), rgb8.cpu().numpy(), rr["radii"].cpu().numpy(),
-                                 flips=True)
-        par["what"] = (f"first timed {args.config} pair (both eyes, worst case), fp32 image on [0,1] vs the CPU oracle; "
-                       "radii: fused exp/normalize/sigmoid vs numpy's; flip_pixels = pixels where a decision of renderCUDA "
-                       "(power > 0, alpha < 1/255, T(1-alpha) < 1e-4) sits within 1e-5 of its threshold in the oracle's own "
-                       "replay; max_abs_clean = max |delta| on all other pixels (bar 2e-4); unexplained_pixels = pixels beyond "
-                       "the bound of the contributions that can flip")
-        N_ref = par.get("oracle_num_rendered")
-        if isinstance(N_ref, list):
-            _, B_pair_ref = alg_bytes(cfg, p_vis, p_vis_union, [float(x) for x in N_ref])
-            raster_roofline["with_reference_instance_count"] = dict(
-                num_rendered_per_eye=N_ref, B_pair_bytes=int(B_pair_ref),
-                frac_of_8TBps=round(B_pair_ref / t_raster / HBM_PEAK, 4),
-                note="same measured time, B_pair evaluated with the reference's num_rendered (16x16 tiles, no culling)")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        left_u8 = rgb8[0].cpu().numpy()
+            # ---- algorithmic bytes, per kernel launch = per stereo pair ------------------
+            N_eye = [float(x) for x in num_rendered0]           # instances produced by this build (culling mode)
+            alg, B_pair = alg_bytes(cfg, p_vis, p_vis_union, N_eye, U_frame)
+            t_raster = sum(stages[k]["avg_us"] for k in _lib.RASTER_STAGES) * 1e-6
+            t_tsdf = sum(stages[k]["avg_us"] for k in _lib.TSDF_STAGES) * 1e-6
+            # the dominant kernel = the stage with the most GPU time among those that move algorithmic bytes (the scans carry none: under
+            # contention -- the 8-rank rehearsal on one GPU -- a scan's launch latency once topped the list and the byte ratio below divided
+            # by zero on one rank: a diagnostic must never take a rank of the driver's multi-GPU run down)
+            dom = max((k for k in stages if alg.get(k, 0.0) > 0.0),
+                      key=lambda k: stages[k]["avg_us"] * stages[k]["launches"] * (ppl if stages[k]["launch_us"] else 1))
+            upl = ppl if stages[dom]["launch_us"] else 1        # units (stereo pairs) one launch of the dominant kernel covers
+            t_launch = (stages[dom]["launch_us"] or stages[dom]["avg_us"]) * 1e-6
+            achieved = alg[dom] * upl / t_launch               # algorithmic bytes per launch / live launch duration
+            traffic, traffic_source, valu = None, None, None
+            prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(prof):
+                try:
+                    tr = json.load(open(prof))
+                    ent = tr.get(args.config, {}).get(dom)
+                    if ent and ent.get("cull") == args.cull and ent.get("blend_variant", 4) == args.blend:
+                        # the committed counters are per launch of the PROFILED command (its launches cover `pairs_per_launch` pairs,
+                        # 1 in the entries of round 3): scaled to the launches of this run
+                        scale = upl / max(1, int(ent.get("pairs_per_launch", 1)))
+                        traffic = int(ent["hbm_bytes_per_launch"] * scale)
+                        traffic_source = (f"{ent.get('source')} ({ent.get('date', 'round 2')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          f"passes of tools/profile_round.sh, ({ent.get('read_factor', 2.0)} * FETCH_SIZE + WRITE_SIZE) KiB per launch of {ent.get('kernel')} "
+                                          f"[read factor per access pattern: streams 2, gathers 1, profiles/r5_gather_fetch_calibration.json] "
+                                          f"({ent.get('pairs_per_launch', 1)} stereo pair(s) per launch there, {upl} here); "
+                                          "committed profile, not measured in this run")
+                        if ent.get("valu_insts_per_launch"):
+                            # the dominant kernel is VALU-bound: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC
+                            # pass) / live launch time, against 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+                            n_valu = ent["valu_insts_per_launch"] * scale
+                            rate = n_valu / t_launch
+                            valu = dict(insts_per_launch=int(n_valu), achieved_Ginst_s=round(rate / 1e9, 1),
+                                        peak_Ginst_s=1228.8, frac=round(rate / 1228.8e9, 4),
+                                        measured_plain_fp32_Ginst_s=1010.0,
+                                        note="tools/ubench/valu_rates.hip on this chip, 7 waves/SIMD: plain fp32 VALU op 2.4 cycles per "
+                                             "wave64 instruction per SIMD (1010 G inst/s), v_exp_f32 8.1, v_cmp / v_cndmask through a lane "
+                                             "mask ~4, v_pk_fma_f32 7.0")
+                            for name in ("salu_insts_per_launch", "branch_insts_per_launch"):
+                                if ent.get(name):
+                                    valu[name] = int(ent[name] * scale)
+                            if ent.get("salu_insts_per_launch") and ent.get("branch_insts_per_launch"):
+                                valu["scalar_plus_branch_per_valu"] = round((ent["salu_insts_per_launch"] + ent["branch_insts_per_launch"]) /
+                                                                            ent["valu_insts_per_launch"], 3)
+                            if ent.get("valu_trans_per_launch"):
+                                # lower bound of the VALU issue time of this instruction mix: transcendental ops at 8.1 cycles,
+                                # everything else priced as a plain op (the lane-mask compares / selects cost more)
+                                tr_n = ent["valu_trans_per_launch"] * scale
+                                cyc = 8.1 * tr_n + 2.4 * (n_valu - tr_n)
+                                valu["trans_insts_per_launch"] = int(tr_n)
+                                valu["issue_bound_us_at_2p4GHz"] = round(cyc / 1024 / 2.4e3, 1)
+                                valu["frac_of_issue_bound"] = round(valu["issue_bound_us_at_2p4GHz"] / (t_launch * 1e6), 3)
+                except Exception:
+                    traffic = None
+            # `bound` names what limits the kernel; achieved / peak / frac stay the HBM figures the contract asks for
+            roofline = dict(kernel=dom, bound=("valu" if dom == "blend" else "hbm"), frac_basis="hbm", achieved=round(achieved / 1e9, 2), peak=HBM_PEAK / 1e9, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK, 4), traffic=traffic, traffic_source=traffic_source,
+                            traffic_over_algorithmic=(round(traffic / (alg[dom] * upl), 3) if traffic and alg[dom] * upl > 0 else None),
+                            algorithmic_bytes_per_launch=int(alg[dom] * upl), avg_launch_us=round(t_launch * 1e6, 2),
+                            stereo_pairs_per_launch=upl, valu=valu,
+                            note="blend is VALU-bound (exp + 10 VALU ops per contributing pixel x instance, data served from LDS); "
+                                 "HBM fraction reported as the contract asks, see DESIGN.md")
+            tr_all = committed_traffic(args.config)
+            def stage_traffic(k):
+                """committed PMC traffic of stage k, per unit of `avg_us` (a stereo pair; a FRAME for the TSDF stages, whose launches
+                cover `frames_per_launch` frames)"""
+                ent = tr_all.get(k, {})
+                if ent.get("cull") != args.cull or ent.get("hbm_bytes_per_launch") is None:
+                    return None
+                return int(ent["hbm_bytes_per_launch"] / max(1, int(ent.get("frames_per_launch", ent.get("pairs_per_launch", 1)))))
 
-        def prep(i):
-            d = depths[i].cpu().numpy()
-            d = np.where(d < np.float32(min_depth), 0, d).astype(np.float32)
-            return oracle.ScalableTSDFVolume.convert_depth(d, 1.0, depth_trunc)
+            per_kernel = {k: dict(avg_us=round(v["avg_us"], 2), launch_us=(round(v["launch_us"], 2) if v["launch_us"] else None), launches=v["launches"],
+                                  alg_GBps=round(alg[k] / max(v["avg_us"], 1e-9) / 1e3, 1),
+                                  frac_hbm=round(alg[k] / max(v["avg_us"], 1e-9) * 1e6 / HBM_PEAK, 4),
+                                  traffic=stage_traffic(k))
+                          for k, v in stages.items()}
+            if "tsdf_integrate" in per_kernel:
+                # SURVEY.md 8(d) asks for BOTH byte models of the TSDF: the per-frame streaming model (what Open3D does: state read +
+                # written per frame, 40 B x updated voxels + 7 B x pixels) and the job-level lower bound (state of every touched voxel
+                # read + written ONCE per job, 20 B x voxels of the touched blocks, + the 7 B x pixels of every frame).  The
+                # voxel-stationary sweep moves the state once per sweep, so it is priced against the second; the first says what the
+                # frame-by-frame algorithm would have to move.
+                e = per_kernel["tsdf_integrate"]
+                t_frame = max(e["avg_us"], 1e-9) * 1e-6
+                B_frame = alg["tsdf_integrate"]
+                B_job_frame = (20.0 * n_blocks * 4096 + 7.0 * Wd * Ht * K) / max(K, 1)
+                e.update(frac_hbm_frame_model=round(B_frame / t_frame / HBM_PEAK, 4), alg_bytes_frame_model=int(B_frame),
+                         frac_hbm_job_bound=round(B_job_frame / t_frame / HBM_PEAK, 4), alg_bytes_job_bound_per_frame=int(B_job_frame),
+                         traffic_over_job_bound=(round(e["traffic"] / B_job_frame, 2) if e.get("traffic") else None),
+                         note="per FRAME: frame model = 40 B x updated voxels + 7 B x pixels (Open3D's per-frame streaming); job bound = "
+                              "(20 B x voxels of the touched blocks + 7 B x pixels x frames) / frames; traffic = committed PMC bytes of "
+                              "a sweep / its frames")
+            raster_roofline = dict(B_pair_bytes=int(B_pair), t_pair_us=round(t_raster * 1e6, 1),
+                                   achieved_GBps=round(B_pair / t_raster / 1e9, 1), frac_of_8TBps=round(B_pair / t_raster / HBM_PEAK, 4),
+                                   frac_of_6p29TBps=round(B_pair / t_raster / 6.29e12, 4),
+                                   render_only_pairs_per_s=round(1.0 / t_raster, 1))
+            tsdf = dict(mvoxel_updates_per_s_job=round(K_total * blocks_frame * 4096 / dt / 1e6, 1),
+                        mvoxel_updates_per_s_kernels=round(blocks_frame * 4096 / t_tsdf / 1e6, 1),
+                        blocks_per_frame=round(blocks_frame, 1), updated_voxels_per_frame=round(U_frame, 1),
+                        allocated_blocks=int(n_blocks), voxel_length=cfg.voxel_length, sdf_trunc=cfg.sdf_trunc,
+                        unit="Mvoxel-updates/s (4096 per touched 16^3 block per frame)")
+            if rank == 0 and world == 1:
+                # mesh extraction of the fused volume, OUTSIDE the timed metric (once per scene, tsdf_utils.py:108 + :133): marching cubes
+                # + vertex welding on the device, indexed mesh over PCIe, connected components on the device
+                try:
+                    torch.cuda.synchronize()
+                    tm0 = time.perf_counter()
+                    mesh = vol.extract_triangle_mesh()
+                    tm1 = time.perf_counter()
+                    m_labels, m_counts, _ = mesh.cluster_connected_triangles()
+                    tm2 = time.perf_counter()
+                    tsdf["mesh"] = dict(triangles=int(mesh.triangles.shape[0]), vertices=int(mesh.vertices.shape[0]),
+                                        clusters=int(len(m_counts)), largest_cluster=int(m_counts.max()) if len(m_counts) else 0,
+                                        extract_weld_ms=round(1e3 * (tm1 - tm0), 2), cluster_ms=round(1e3 * (tm2 - tm1), 2),
+                                        bytes_over_pcie=int(mesh.vertices.nbytes + mesh.vertex_colors.nbytes + mesh.edge_index.nbytes +
+                                                            mesh.triangles.nbytes + m_labels.nbytes + m_counts.nbytes),
+                                        soup_bytes_round4=int(mesh.triangles.shape[0]) * (2 * 72 + 48),
+                                        note="gs2m_tsdf_extract_mesh + gs2m_tsdf_mesh_copy, gs2m_mesh_cluster; wall times incl. the "
+                                             "host allocations and copies; not part of `value`")
+                    del mesh
+                except Exception as e:   # the mesh is an extra of the line, never a reason to lose it
+                    tsdf["mesh"] = dict(error=str(e)[:200])
+            if red is not None:
+                tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
+                                      union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),
+                                      collectives=int(red.get("collectives", 0)), payload=red.get("payload"), algo=red.get("algo"),
+                                      frames_total=int(red.get("frames_total", 0)), halo_blocks_after=halo_blocks,
+                                      world=world, always_collective=bool(args.always_collective),
+                                      note="bytes_per_rank = packed union blocks one rank contributes (12 B / voxel packed, 20 B / voxel f32); "
+                                           "a reduce-scatter moves (N-1)/N of it over xGMI")
 
-        # upstream runs `#pragma omp parallel for` over the 16 x-slices of one block with all host threads;
-        # on a many-core host that oversubscribes (C4 frames took minutes with 256 threads), so probe {16, min(64, cores)} on
-        # one frame and keep the faster
-        best_threads, best_t = None, None
-        d0 = prep(Wm)
-        probes = {}
+            # ---- oracle legs (rank 0, N = 1 only): parity of the first timed pair, CPU baseline --------------------------
+            cpu, par = None, None
+            if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_parity):
+                import oracle
+            if rank == 0 and world == 1 and not args.no_parity:
+                # the first timed pair as the timed configuration renders it (this handle: tile_rows, cull, packed SH, fused
+                # activations), against the CPU oracle (the reference's own kernels when oracle/_ref is prebuilt)
+                from oracle import parity
+                rr = R.render_views(gd, cams[Wm], out_color=color, out_rgb8=rgb8, want_radii=True)
+                par = parity.pair_parity(g, cams_np[Wm], Wd, Ht, color.cpu().numpy(), rgb8.cpu().numpy(), rr["radii"].cpu().numpy(),
+                                         flips=True)
+                par["what"] = (f"first timed {args.config} pair (both eyes, worst case), fp32 image on [0,1] vs the CPU oracle; "
+                               "radii: fused exp/normalize/sigmoid vs numpy's; flip_pixels = pixels where a decision of renderCUDA "
+                               "(power > 0, alpha < 1/255, T(1-alpha) < 1e-4) sits within 1e-5 of its threshold in the oracle's own "
+                               "replay; max_abs_clean = max |delta| on all other pixels (bar 2e-4); unexplained_pixels = pixels beyond "
+                               "the bound of the contributions that can flip")
+                N_ref = par.get("oracle_num_rendered")
+                if isinstance(N_ref, list):
+                    _, B_pair_ref = alg_bytes(cfg, p_vis, p_vis_union, [float(x) for x in N_ref])
+                    raster_roofline["with_reference_instance_count"] = dict(
+                        num_rendered_per_eye=N_ref, B_pair_bytes=int(B_pair_ref),
+                        frac_of_8TBps=round(B_pair_ref / t_raster / HBM_PEAK, 4),
+                        note="same measured time, B_pair evaluated with the reference's num_rendered (16x16 tiles, no culling)")
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                cores = os.cpu_count() or 1
+                left_u8 = rgb8[0].cpu().numpy()
 
-        def probe_one(nt):
-            probe = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
-            probe.set_threads(nt)
-            tc = time.perf_counter()
-            nb = probe.integrate(d0, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[Wm])
-            tp = time.perf_counter() - tc
-            probes[nt] = dict(threads=nt, value=round(nb * 4096 / tp / 1e6, 2), unit="Mvoxel-updates/s", sample=f"1 frame, {tp:.2f} s")
-            return tp
+                def prep(i):
+                    d = depths[i].cpu().numpy()
+                    d = np.where(d < np.float32(min_depth), 0, d).astype(np.float32)
+                    return oracle.ScalableTSDFVolume.convert_depth(d, 1.0, depth_trunc)
 
-        for nt in sorted({min(16, cores), min(64, cores)}):
-            tp = probe_one(nt)
-            if best_t is None or tp < best_t:
-                best_threads, best_t = nt, tp
-        # SURVEY.md 8(d): "threads = all host cores" -- reported next to the faster setting (one frame; skipped when the
-        # 16-thread frame already takes seconds: 256 threads on 16 x-slices only oversubscribe)
-        if cores not in probes:
-            if cores <= 64 and best_t < 2.0:
-                probe_one(cores)
-            else:
-                # measured once in round 5 (profiles/r5_bench_C2_with_all_cores_probe.json): 256 OpenMP threads over the 16
-                # x-slices of a block = 218 s for ONE C2 frame (0.03 Mvoxel-updates/s; 16 threads: 0.07 s, 64: 0.30 s) --
-                # the team spins at ~1800 barriers per frame.  Not repeated in every bench run.
-                probes[cores] = dict(threads=cores, skipped="oversubscribed: upstream parallelises the 16 x-slices of one block; "
-                                     "measured 0.03 Mvoxel-updates/s (218 s per C2 frame) at 256 threads, "
-                                     "profiles/r5_bench_C2_with_all_cores_probe.json")
-        ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
-        ref.set_threads(best_threads)
-        t_cpu, n_cpu, blocks_cpu = 0.0, 0, 0
-        for i in range(Wm, Wm + K):
-            d = prep(i)
-            tc = time.perf_counter()
-            blocks_cpu += ref.integrate(d, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[i])
-            t_cpu += time.perf_counter() - tc
-            n_cpu += 1
-            if t_cpu > args.cpu_seconds:
-                break
-        cpu = dict(value=round(blocks_cpu * 4096 / t_cpu / 1e6, 2), unit="Mvoxel-updates/s", cores=best_threads,
-                   host_cores=cores, kind="port", all_cores=probes.get(cores), by_threads=[probes[k] for k in sorted(probes)],
-                   label="restated Open3D 0.17 ScalableTSDFVolume::Integrate (oracle/tsdf_oracle.cpp, OpenMP over the "
-                         "16 x-slices of a block like upstream; thread count = faster of {16, min(64, host cores)})",
-                   sample=f"{n_cpu} of the {K} timed {args.config} frames ({Wd}x{Ht}), integrate() only, {t_cpu:.1f} s")
-        # render half: the REFERENCE'S OWN rasteriser kernels compiled for the CPU (oracle/_ref, built in the dev
-        # container from /root/reference; the prebuilt library travels to the GPU box), one eye of the first timed pair
-        try:
-            if oracle.ref_available(build=False):
-                s_a, q_a, o_a = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
-                shs_a = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
-                lcam = cams_np[Wm][0]
-                tc = time.perf_counter()
-                rr = oracle.ref_forward(g["xyz"], o_a, lcam.world_view_transform, lcam.full_proj_transform,
-                                        lcam.camera_center, Wd, Ht, lcam.tanfovx, lcam.tanfovy, np.zeros(3, np.float32),
-                                        shs=shs_a, scales=s_a, rotations=q_a)
-                t_eye = time.perf_counter() - tc
-                cpu["raster_reference"] = dict(
-                    value=round(0.5 / t_eye, 4), unit="stereo-pairs/s (render only)", cores=cores, kind="reference",
-                    label="diff-gaussian-rasterization forward.cu + rasterizer_impl.cu kernels compiled for the CPU "
-                          "(oracle/build_ref.py: CUDA execution shim, blocks over OpenMP threads)",
-                    sample=f"left eye of the first timed {args.config} pair ({int(rr['num_rendered'])} instances), {t_eye:.1f} s")
-        except Exception as e:  # the reference build is optional test infrastructure
-            cpu["raster_reference"] = dict(error=str(e)[:200])
+                # upstream runs `#pragma omp parallel for` over the 16 x-slices of one block with all host threads;
+                # on a many-core host that oversubscribes (C4 frames took minutes with 256 threads), so probe {16, min(64, cores)} on
+                # one frame and keep the faster
+                best_threads, best_t = None, None
+                d0 = prep(Wm)
+                probes = {}
 
-    # ---- C3 sub-line: the HBM-bound 2 M-Gaussian configuration, render only ----------------------------------------
-    c3 = None
-    if rank == 0 and world == 1 and not args.no_c3 and args.config != "C3":
-        try:
-            del pipe
-            vol.close()
-        except Exception:
-            pass
-        torch.cuda.empty_cache()
-        try:
-            c3 = raster_only(args, "C3", dev, local_rank)
-        except Exception as e:   # never lose the main line to the sub-measurement
-            c3 = dict(error=str(e)[:300])
+                def probe_one(nt):
+                    probe = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
+                    probe.set_threads(nt)
+                    tc = time.perf_counter()
+                    nb = probe.integrate(d0, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[Wm])
+                    tp = time.perf_counter() - tc
+                    probes[nt] = dict(threads=nt, value=round(nb * 4096 / tp / 1e6, 2), unit="Mvoxel-updates/s", sample=f"1 frame, {tp:.2f} s")
+                    return tp
 
-    # ---- trained-like sub-line (VERDICT r5 item 3): the headline's size (C2) with the statistics of a TRAINED splat -- strongly
-    # anisotropic scales, 30 % of the opacities at the 0.99 cap, screen-filling background splats, depth ties -- render only
-    trained = None
-    if rank == 0 and world == 1 and not args.no_trained_like and args.config == "C2":
-        try:
-            del pipe
-            vol.close()
-        except Exception:
-            pass
-        torch.cuda.empty_cache()
-        try:
-            trained = raster_only(args, "C2", dev, local_rank, scene="trained_like", with_parity=not args.no_parity)
-            t_syn = sum(v["avg_us"] for k, v in per_kernel.items() if not k.startswith("tsdf"))
-            t_tr = trained["raster_roofline"]["t_pair_us"]
-            n_syn, n_tr = sum(N_eye), sum(trained["num_rendered_per_eye"])
-            trained["vs_synth_v1"] = dict(raster_us_per_pair=round(t_tr, 1), synth_v1_raster_us_per_pair=round(t_syn, 1),
-                                          time_ratio=round(t_tr / t_syn, 3), num_rendered_ratio=round(n_tr / n_syn, 3),
-                                          time_per_instance_ratio=round((t_tr / n_tr) / (t_syn / n_syn), 3),
-                                          note="bar (VERDICT r5 item 3): <= 1.25 x the synth_v1 C2 time per pair at equal "
-                                               "num_rendered scale; DESIGN.md section 6 says where the rest goes")
-        except Exception as e:   # never lose the main line to the sub-measurement
-            trained = dict(error=str(e)[:300])
+                for nt in sorted({min(16, cores), min(64, cores)}):
+                    tp = probe_one(nt)
+                    if best_t is None or tp < best_t:
+                        best_threads, best_t = nt, tp
+                # SURVEY.md 8(d): "threads = all host cores" -- reported next to the faster setting (one frame; skipped when the
+                # 16-thread frame already takes seconds: 256 threads on 16 x-slices only oversubscribe)
+                if cores not in probes:
+                    if cores <= 64 and best_t < 2.0:
+                        probe_one(cores)
+                    else:
+                        # measured once in round 5 (profiles/r5_bench_C2_with_all_cores_probe.json): 256 OpenMP threads over the 16
+                        # x-slices of a block = 218 s for ONE C2 frame (0.03 Mvoxel-updates/s; 16 threads: 0.07 s, 64: 0.30 s) --
+                        # the team spins at ~1800 barriers per frame.  Not repeated in every bench run.
+                        probes[cores] = dict(threads=cores, skipped="oversubscribed: upstream parallelises the 16 x-slices of one block; "
+                                             "measured 0.03 Mvoxel-updates/s (218 s per C2 frame) at 256 threads, "
+                                             "profiles/r5_bench_C2_with_all_cores_probe.json")
+                ref = oracle.ScalableTSDFVolume(cfg.voxel_length, cfg.sdf_trunc, 1)
+                ref.set_threads(best_threads)
+                t_cpu, n_cpu, blocks_cpu = 0.0, 0, 0
+                for i in range(Wm, Wm + K):
+                    d = prep(i)
+                    tc = time.perf_counter()
+                    blocks_cpu += ref.integrate(d, left_u8, Wd, Ht, cfg.focal, cfg.focal, cx, cy, Es[i])
+                    t_cpu += time.perf_counter() - tc
+                    n_cpu += 1
+                    if t_cpu > args.cpu_seconds:
+                        break
+                cpu = dict(value=round(blocks_cpu * 4096 / t_cpu / 1e6, 2), unit="Mvoxel-updates/s", cores=best_threads,
+                           host_cores=cores, kind="port", all_cores=probes.get(cores), by_threads=[probes[k] for k in sorted(probes)],
+                           label="restated Open3D 0.17 ScalableTSDFVolume::Integrate (oracle/tsdf_oracle.cpp, OpenMP over the "
+                                 "16 x-slices of a block like upstream; thread count = faster of {16, min(64, host cores)})",
+                           sample=f"{n_cpu} of the {K} timed {args.config} frames ({Wd}x{Ht}), integrate() only, {t_cpu:.1f} s")
+                # render half: the REFERENCE'S OWN rasteriser kernels compiled for the CPU (oracle/_ref, built in the dev
+                # container from /root/reference; the prebuilt library travels to the GPU box), one eye of the first timed pair
+                try:
+                    if oracle.ref_available(build=False):
+                        s_a, q_a, o_a = oracle.activate(g["scaling"], g["rotation"], g["opacity"])
+                        shs_a = np.ascontiguousarray(np.concatenate([g["features_dc"], g["features_rest"]], axis=1))
+                        lcam = cams_np[Wm][0]
+                        tc = time.perf_counter()
+                        rr = oracle.ref_forward(g["xyz"], o_a, lcam.world_view_transform, lcam.full_proj_transform,
+                                                lcam.camera_center, Wd, Ht, lcam.tanfovx, lcam.tanfovy, np.zeros(3, np.float32),
+                                                shs=shs_a, scales=s_a, rotations=q_a)
+                        t_eye = time.perf_counter() - tc
+                        cpu["raster_reference"] = dict(
+                            value=round(0.5 / t_eye, 4), unit="stereo-pairs/s (render only)", cores=cores, kind="reference",
+                            label="diff-gaussian-rasterization forward.cu + rasterizer_impl.cu kernels compiled for the CPU "
+                                  "(oracle/build_ref.py: CUDA execution shim, blocks over OpenMP threads)",
+                            sample=f"left eye of the first timed {args.config} pair ({int(rr['num_rendered'])} instances), {t_eye:.1f} s")
+                except Exception as e:  # the reference build is optional test infrastructure
+                    cpu["raster_reference"] = dict(error=str(e)[:200])
+
+            # ---- C3 sub-line: the HBM-bound 2 M-Gaussian configuration, render only ----------------------------------------
+            c3 = None
+            if rank == 0 and world == 1 and not args.no_c3 and args.config != "C3":
+                try:
+                    del pipe
+                    vol.close()
+                except Exception:
+                    pass
+                torch.cuda.empty_cache()
+                try:
+                    c3 = raster_only(args, "C3", dev, local_rank)
+                except Exception as e:   # never lose the main line to the sub-measurement
+                    c3 = dict(error=str(e)[:300])
+
+            # ---- trained-like sub-line (VERDICT r5 item 3): the headline's size (C2) with the statistics of a TRAINED splat -- strongly
+            # anisotropic scales, 30 % of the opacities at the 0.99 cap, screen-filling background splats, depth ties -- render only
+            trained = None
+            if rank == 0 and world == 1 and not args.no_trained_like and args.config == "C2":
+                try:
+                    del pipe
+                    vol.close()
+                except Exception:
+                    pass
+                torch.cuda.empty_cache()
+                try:
+                    trained = raster_only(args, "C2", dev, local_rank, scene="trained_like", with_parity=not args.no_parity)
+                    t_syn = sum(v["avg_us"] for k, v in per_kernel.items() if not k.startswith("tsdf"))
+                    t_tr = trained["raster_roofline"]["t_pair_us"]
+                    n_syn, n_tr = sum(N_eye), sum(trained["num_rendered_per_eye"])
+                    trained["vs_synth_v1"] = dict(raster_us_per_pair=round(t_tr, 1), synth_v1_raster_us_per_pair=round(t_syn, 1),
+                                                  time_ratio=round(t_tr / t_syn, 3), num_rendered_ratio=round(n_tr / n_syn, 3),
+                                                  time_per_instance_ratio=round((t_tr / n_tr) / (t_syn / n_syn), 3),
+                                                  note="bar (VERDICT r5 item 3): <= 1.25 x the synth_v1 C2 time per pair at equal "
+                                                       "num_rendered scale; DESIGN.md section 6 says where the rest goes")
+                except Exception as e:   # never lose the main line to the sub-measurement
+                    trained = dict(error=str(e)[:300])
+
+        except Exception as e:
+            import traceback
+            diag_error = "".join(traceback.format_exception_only(type(e), e)).strip()[:400]
+            sys.stderr.write("bench.py: diagnostics failed (the timed value stands):\n" + traceback.format_exc() + "\n")
+            roofline = roofline or dict(error=diag_error)
+            cpu = cpu or dict(error=diag_error)
+            if tsdf is None:
+                tsdf = dict(error=diag_error)
+                if red is not None:
+                    tsdf["reduce"] = dict(mode=args.reduce, seconds=round(t_red, 6), frac_of_timed_region=round(t_red / dt, 4),
+                                          union_blocks=int(red["n_blocks_union"]), bytes_per_rank=int(red["bytes_per_rank"]),
+                                          payload=red.get("payload"), algo=red.get("algo"), world=world)
 
     if rank == 0:
         out = dict(
@@ -801,7 +826,7 @@ def main():
                         host_enqueue_ms_per_step=round(1e3 * statistics.median(enq) / K, 4)),   # host side of the K steps: launches only, no sync
             num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis,
             tsdf=tsdf, stages=per_kernel, roofline=roofline, raster_roofline=raster_roofline, parity=par, cpu_baseline=cpu,
-            c3=c3, trained_like=trained, volume_check=volume_check, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
+            c3=c3, trained_like=trained, volume_check=volume_check, diagnostics_error=diag_error, instrumented_ms_per_step=round(1e3 * dt_instr / K, 4),
             note_stages="`stages` / `roofline` / `instrumented_ms_per_step`: second pass, serial on one stream with hipEvents "
                         "around every launch, `pairs_per_launch` stereo pairs per chain of launches = the launch shapes of the "
                         "timed pass (kernels in isolation; raster `avg_us` = launch_us / pairs_per_launch, TSDF `avg_us` per frame); "

@@ -12,7 +12,11 @@ ap.add_argument("--configs", default="C2,C3")
 ap.add_argument("--modes", default="2,0,2,0", help="GS2M_OPT_BLEND_MODE per pass")
 ap.add_argument("--scene", default="synth", choices=["synth", "trained"])
 ap.add_argument("--groups", type=int, default=6)
+ap.add_argument("--libs", default="", help="comma-separated extra builds of libgs2mesh_amd.so (A/B of two trees in one process); a mode "
+                                          "entry `2@1` runs mode 2 on the first of them, `2` / `2@0` on the tree's own build")
 a = ap.parse_args()
+import ctypes
+LIBS = [None] + [_lib.bind(ctypes.CDLL(os.path.abspath(p))) for p in a.libs.split(",") if p]
 for cname in a.configs.split(","):
     cfg = synthetic.CONFIGS[cname]
     g = (synthetic.trained_like if a.scene == "trained" else synthetic.synth_v1)(cfg.P, cfg.seed, cfg.log_s_mu)
@@ -28,8 +32,8 @@ for cname in a.configs.split(","):
     ref = None
     torch.cuda.synchronize()
     for mname in a.modes.split(","):
-        mode = int(mname)
-        R = Rasterizer(0)
+        mode = int(mname.split("@")[0])
+        R = Rasterizer(0, lib=LIBS[int(mname.split("@")[1])] if "@" in mname else None)
         R.set_option(_lib.OPT_EXACT_TILE_CULL, 1)
         R.set_option(_lib.OPT_TILE_ROWS, 2)
         R.set_option(_lib.OPT_PAIR_BATCH, 2)
