@@ -44,6 +44,7 @@ OPT_BLEND_MODE = 11
 TSDF_MAP_HEADER_BYTES = 32
 OPT_BLEND_PROFILE = 12
 OPT_BIN_LANE_TILES = 13
+OPT_PROJECT_SHARED_READ = 14
 BLEND_PROF_COUNTERS = ("waves", "wave_cycles", "dma_wait", "staging", "prefetch_issue", "loop", "epilogue", "batches",
                        "staged_instances", "listed_instances")
 XFORM_SUM_F32, XFORM_RAW_F32, XFORM_SUM_PACKED = 0, 1, 2

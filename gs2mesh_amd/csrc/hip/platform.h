@@ -73,6 +73,7 @@ GS2M_DEVICE float gs2m_fast_log2(float x) { return __log2f(x); }
 #define GS2M_KEEP_F32(x) asm volatile("" : "+v"(x))
 // a wave-uniform int the compiler must treat as an opaque scalar register (stops re-association of mask tests)
 #define GS2M_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
+#define GS2M_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))   // a per-lane value the compiler must re-read (stops hoisting of loads addressed by it)
 // instruction-scheduling fence (nothing moves across it)
 // keeps a rarely taken, wave-uniform branch a BRANCH (stops the compiler turning it into selects executed every time)
 #define GS2M_NO_IF_CONVERT() asm volatile("" ::: "memory")

@@ -42,6 +42,7 @@ struct gs2m_raster {
     int opt_exact_cull = 0, opt_blend = 4, opt_debug = 0, opt_timing = 0, opt_tile_rows = 1, opt_pair_batch = 0;
     int opt_bin_workgroups = 256, opt_bin_wg_threads = 1024, opt_blend_mode = 2;   // tuning options (gs2m_raster_set_option)
     int opt_blend_profile = 0;
+    int opt_project_shared = 0;     // GS2M_OPT_PROJECT_SHARED_READ: 0 auto (by model size), 1 always, 2 never
     int opt_bin_lane_tiles = 4;     // rects of at most this many binning tiles are walked by their own lane (round 6)
     unsigned long long* d_blend_prof = nullptr;   // [GS2M_BLEND_PROF_COUNTERS] phase-cycle sums of the profile build (GS2M_OPT_BLEND_PROFILE)
     struct EvPair {
@@ -224,6 +225,13 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             }
             r->opt_bin_lane_tiles = value;
             return 0;
+        case GS2M_OPT_PROJECT_SHARED_READ:
+            if (value < 0 || value > 2) {
+                gs2m_set_error("GS2M_OPT_PROJECT_SHARED_READ must be 0 (by model size), 1 (always) or 2 (never)");
+                return 1;
+            }
+            r->opt_project_shared = value;
+            return 0;
         case GS2M_OPT_BLEND_PROFILE:
             r->opt_blend_profile = value != 0;
             if (value && !r->d_blend_prof) {
@@ -397,7 +405,7 @@ static int run_views(gs2m_raster* r, const GaussIn& g, int nv, int pairs, int W,
     // its own LDS atomics and tile tests, not by re-reading the records; 128 VGPRs for 1024-thread workgroups.  Not kept.)
     {
         StageTimer tm(r, st, GS2M_STAGE_PROJECT);
-        gs2m_launch_project(nv, pairs, st, g, r->d_cams, recs, out_radii, cull_arg_p, host_cams);
+        gs2m_launch_project(nv, pairs, st, g, r->d_cams, recs, out_radii, cull_arg_p, host_cams, r->opt_project_shared);
     }
     if (dbg_check(r, st, "project")) return 1;
     {

@@ -9,7 +9,7 @@ size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads);
 // host_cams: null (the uniforms are already in `cams`, device memory) or the nv * pairs host-side uniforms of the pass (carried in
 // the launch packet; the kernel also stores them to `cams`)
 void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRecs recs, int* radii,
-                         int exact_cull, const CamUniform* host_cams);
+                         int exact_cull, const CamUniform* host_cams, int shared_read);
 int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,
                             const CamUniform* cams, int chunk, unsigned* hist, unsigned long long* tilemask,
                             int exact_cull, int interleave, int lane_tiles);

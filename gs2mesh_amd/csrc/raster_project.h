@@ -148,14 +148,20 @@ GS2M_DEVICE unsigned wave_inclusive_scan(unsigned x) {
 // Projection + colour, one thread per Gaussian -- a streaming kernel (no LDS, no loop): activations, Sigma once
 // for all views of the batch, EWA projection, SH colour, the (cull-tightened) tile rect -> GeomRec.
 #define GS2M_PROJECT_THREADS 256
-// One Gaussian (array position gi) for the NV views of the batch: parameter loads (+ fused activations), Sigma once, EWA
-// projection, SH colour, the (cull-tightened) tile rect, the GeomRec stores.  On return pv[v] holds what was stored (rect
-// zeroed and ok = false when nothing of the Gaussian reaches view v) and op the activated opacity: the fused
-// projection + counting kernel continues from these registers.  s_sh = this wave's DMA landing zone, [12][64] float4 (DMA_SH only).
-template <int NV, bool DMA_SH, bool STREAM = true>
-GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict__ cams, const GeomRecs recs,
+// One Gaussian (array position gi) for the `groups` x NV views of the launch: parameter loads (+ fused activations) and Sigma
+// ONCE, then per group of NV views (a stereo pair) the EWA projection, SH colour, the (cull-tightened) tile rect and the GeomRec
+// stores.  Round 6: the groups of a launch (GS2M_OPT_PAIR_BATCH) used to be blockIdx.y -- every group re-read the 44 B of
+// parameters and the 192-B SH row of every Gaussian, 71 % of the kernel's bytes; now the thread that owns the Gaussian walks the
+// groups (LOOP), the row stays in LDS (DMA_SH) or is re-read through the caches (streamed path): C3 project 113.5 -> 86.5 us per
+// pair.  The loop costs registers (84 -> 128, 106 -> 152: 4 -> 3 waves per SIMD on the streamed path) and halves the waves of the
+// launch, and a model that fits the 256 MB last-level cache re-reads cheaply anyway (C2: 18.4 -> 19.5 us with the loop): the
+// launcher keeps the groups on blockIdx.y (LOOP = false, `groups` = 1) for models below GS2M_PROJECT_LOOP_MIN_P Gaussians.
+// s_sh = this wave's DMA landing zone, [12][64] float4 (DMA_SH only).
+#define GS2M_PROJECT_LOOP_MIN_P 1000000
+template <int NV, bool DMA_SH, bool STREAM = true, bool LOOP = false>
+GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRecs recs,
                                   int* __restrict__ radii, int exact_cull, int gi, bool valid, float4* s_sh, int lane_id,
-                                  ProjView* pv, float& op, float& thr) {
+                                  int groups) {
     const int ncoef = (g.D + 1) * (g.D + 1);
     constexpr bool dma_sh = DMA_SH;
     {
@@ -164,14 +170,6 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
 #pragma unroll
             for (int k = 0; k < 12; ++k)
                 if (k * 4 < ncoef * 3) gs2m_global_load_lds16(s4 + k * 64, &s_sh[k * 64]);
-        }
-        op = 0.0f;
-        thr = 0.0f;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            pv[v].ok = false;
-            pv[v].x0 = pv[v].y0 = pv[v].x1 = pv[v].y1 = 0;
-            pv[v].mx = pv[v].my = pv[v].ca = pv[v].cb = pv[v].cc = 0.0f;
         }
         if (valid) {
             const float px = g.xyz[3 * (size_t)gi], py = g.xyz[3 * (size_t)gi + 1], pz = g.xyz[3 * (size_t)gi + 2];
@@ -196,8 +194,25 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                 }
                 cov3d_from_scale_rot(sx, sy, sz, g.scale_modifier, qr, qx, qy, qz, cov3);
             }
-            op = g.opac[gi];
+            float op = g.opac[gi];
             if (g.raw) op = 1.0f / (1.0f + expf(-op));  // gaussian_model.py:113-115 sigmoid
+            const float thr = exact_cull ? cull_threshold(op) : 0.0f;
+            const CamUniform* __restrict__ cams0 = cams;
+            const GeomRecs recs0 = recs;
+            int* __restrict__ const radii0 = radii;
+#pragma unroll 1
+            for (int grp = 0; grp < (LOOP ? groups : 1); ++grp) {
+            cams = cams0 + NV * grp;
+            recs = gs2m_recs_at(recs0, (size_t)NV * grp * g.P);
+            radii = radii0 ? radii0 + (size_t)NV * grp * g.P : nullptr;
+            // the SH row is loop-invariant: re-read it per group (LDS / caches) instead of letting the compiler hoist 48 registers
+            // of it over the loop (4 -> 3 waves per SIMD)
+            int gi_sh = gi, lane_sh = lane_id;
+            if (LOOP) {
+                GS2M_OPAQUE_VGPR(gi_sh);
+                GS2M_OPAQUE_VGPR(lane_sh);
+            }
+            ProjView pv[NV];
             bool any = false;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -212,7 +227,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
             float rgb_v[NV][3];
 #pragma unroll
             for (int v = 0; v < NV; ++v) rgb_v[v][0] = rgb_v[v][1] = rgb_v[v][2] = 0.0f;
-            if (dma_sh) gs2m_wait_dma();   // this lane's row has landed (a lane only reads its own column: no barrier)
+            if (dma_sh && grp == 0) gs2m_wait_dma();   // this lane's row has landed (a lane only reads its own column: no barrier)
             if (stream_sh && any && !dma_sh) {
                 float dirs[NV][3];
 #pragma unroll
@@ -226,10 +241,10 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                 }
                 if (g.shs_packed) {
                     // wave-transposed copy (k_pack_sh): float4 j of 64 consecutive Gaussians is 1 KiB contiguous
-                    const float4* s4 = reinterpret_cast<const float4*>(g.shs_packed) + (size_t)(gi >> 6) * (12 * 64) + (gi & 63);
+                    const float4* s4 = reinterpret_cast<const float4*>(g.shs_packed) + (size_t)(gi_sh >> 6) * (12 * 64) + (gi_sh & 63);
                     sh_rgb_stream<NV>(g.D, [&](int j) { return s4[j * 64]; }, dirs, rgb_v);
                 } else {
-                    const float4* s4 = reinterpret_cast<const float4*>(g.shs + 48 * (size_t)gi);   // 192-B row, 16-B aligned
+                    const float4* s4 = reinterpret_cast<const float4*>(g.shs + 48 * (size_t)gi_sh);   // 192-B row, 16-B aligned
                     sh_rgb_stream<NV>(g.D, [&](int j) { return s4[j]; }, dirs, rgb_v);
                 }
             }
@@ -237,13 +252,13 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
             const bool need_sh = !STREAM && any && (g.colors_precomp == nullptr) && !stream_sh;
             if constexpr (!STREAM) if (need_sh) {
                 if (g.shs_rest == nullptr) {
-                    const float* s = g.shs + (size_t)gi * g.M * 3;
+                    const float* s = g.shs + (size_t)gi_sh * g.M * 3;
 #pragma unroll
                     for (int k = 0; k < 48; ++k)
                         if (k < ncoef * 3) sh[k] = s[k];
                 } else {
-                    const float* s0 = g.shs + (size_t)gi * 3;
-                    const float* s1 = g.shs_rest + (size_t)gi * (g.M - 1) * 3;
+                    const float* s0 = g.shs + (size_t)gi_sh * 3;
+                    const float* s1 = g.shs_rest + (size_t)gi_sh * (g.M - 1) * 3;
                     sh[0] = s0[0];
                     sh[1] = s0[1];
                     sh[2] = s0[2];
@@ -252,7 +267,6 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                         if (k < ncoef * 3) sh[k] = s1[k - 3];
                 }
             }
-            if (exact_cull) thr = cull_threshold(op);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const size_t ri = (size_t)v * g.P + gi;
@@ -280,7 +294,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                     dirs[0][0] = dx / len;
                     dirs[0][1] = dy / len;
                     dirs[0][2] = dz / len;
-                    sh_rgb_stream<1>(g.D, [&](int j) { return s_sh[j * 64 + lane_id]; }, dirs, col);
+                    sh_rgb_stream<1>(g.D, [&](int j) { return s_sh[j * 64 + lane_sh]; }, dirs, col);
                     cr = col[0][0];
                     cg = col[0][1];
                     cb = col[0][2];
@@ -340,6 +354,7 @@ GS2M_DEVICE void project_gaussian(const GaussIn& g, const CamUniform* __restrict
                 recs.ab[2 * ri + 1] = w1;
                 recs.c[ri] = w2;
             }
+            }   // groups
         }
     }
 }
@@ -358,39 +373,39 @@ struct CamUniformArg {
 // 1 KiB per wave), issued BEFORE the parameter loads and the projection: one memory round trip per thread instead of two in
 // sequence (the wave spent 69 % of its life waiting, PMC) and no 48 registers holding the row while it is in flight.  The
 // colour pass then reads the 16 coefficients of one channel at a time back from LDS.
-template <int NV, bool DMA_SH, bool STREAM, bool HOSTCAMS>
+template <int NV, bool DMA_SH, bool STREAM, bool HOSTCAMS, bool LOOP>
 GS2M_DEVICE void project_kernel_body(const GaussIn& g, const CamUniform* __restrict__ cams, GeomRecs recs,
-                                     int* __restrict__ radii, int exact_cull, CamUniform* __restrict__ cams_out) {
+                                     int* __restrict__ radii, int exact_cull, CamUniform* __restrict__ cams_out, int groups) {
     __shared__ float4 s_sh[DMA_SH ? GS2M_PROJECT_THREADS / 64 : 1][DMA_SH ? 12 : 1][DMA_SH ? 64 : 1];
-    // blockIdx.y = group of NV views of the launch (GS2M_OPT_PAIR_BATCH: two stereo pairs per launch)
-    cams += NV * blockIdx.y;
+    // the groups of NV views of the launch (GS2M_OPT_PAIR_BATCH: two stereo pairs per launch): LOOP -- all `groups` of them are
+    // walked by the thread that owns the Gaussian (project_gaussian); else blockIdx.y = the group of this workgroup
+    const int g0 = LOOP ? 0 : (int)blockIdx.y, ng = LOOP ? groups : 1;
+    cams += NV * g0;
     if (HOSTCAMS && blockIdx.x == 0) {
-        // the uniforms of this group of views -> device memory, for the later kernels of the pass (dword copy)
+        // the uniforms of this workgroup's views -> device memory, for the later kernels of the pass (dword copy)
         const unsigned* src = reinterpret_cast<const unsigned*>(cams);
-        unsigned* dst = reinterpret_cast<unsigned*>(cams_out + NV * blockIdx.y);
-        for (unsigned i = threadIdx.x; i < NV * sizeof(CamUniform) / 4u; i += GS2M_PROJECT_THREADS) dst[i] = src[i];
+        unsigned* dst = reinterpret_cast<unsigned*>(cams_out + NV * g0);
+        for (unsigned i = threadIdx.x; i < (unsigned)(ng * NV) * (unsigned)(sizeof(CamUniform) / 4u); i += GS2M_PROJECT_THREADS) dst[i] = src[i];
     }
-    recs = gs2m_recs_at(recs, (size_t)NV * blockIdx.y * g.P);
-    if (radii) radii += (size_t)NV * blockIdx.y * g.P;
+    recs = gs2m_recs_at(recs, (size_t)NV * g0 * g.P);
+    if (radii) radii += (size_t)NV * g0 * g.P;
     const int gi = (int)(blockIdx.x * (unsigned)GS2M_PROJECT_THREADS + threadIdx.x);
     const int wave_id = (int)(threadIdx.x >> 6), lane_id = (int)(threadIdx.x & 63u);
-    ProjView pv[NV];
-    float op, thr;
-    project_gaussian<NV, DMA_SH, STREAM>(g, cams, recs, radii, exact_cull, gi, gi < g.P, &s_sh[DMA_SH ? wave_id : 0][0][0], lane_id, pv, op, thr);
+    project_gaussian<NV, DMA_SH, STREAM, LOOP>(g, cams, recs, radii, exact_cull, gi, gi < g.P, &s_sh[DMA_SH ? wave_id : 0][0][0], lane_id, ng);
 }
 // uniforms in device memory (operator-level API: the caller's matrices are device tensors, k_pack_camera)
-template <int NV, bool DMA_SH, bool STREAM = true>
+template <int NV, bool DMA_SH, bool STREAM = true, bool LOOP = false>
 GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)   // forcing 5 waves per SIMD on the round-2 kernel (96 VGPRs, spills): C2 30 -> 36 us, C3 149 -> 204
 k_project(GaussIn g, const CamUniform* __restrict__ cams, GeomRecs recs, int* __restrict__ radii,
-          int exact_cull) {
-    project_kernel_body<NV, DMA_SH, STREAM, false>(g, cams, recs, radii, exact_cull, nullptr);
+          int exact_cull, int groups) {
+    project_kernel_body<NV, DMA_SH, STREAM, false, LOOP>(g, cams, recs, radii, exact_cull, nullptr, groups);
 }
 // uniforms in the kernel arguments (pipeline-level API, host-side cameras)
-template <int NV, bool DMA_SH, bool STREAM = true>
+template <int NV, bool DMA_SH, bool STREAM = true, bool LOOP = false>
 GS2M_KERNEL void __launch_bounds__(GS2M_PROJECT_THREADS)
 k_project_hc(GaussIn g, CamUniformArg hc, CamUniform* __restrict__ cams_out, GeomRecs recs, int* __restrict__ radii,
-             int exact_cull) {
-    project_kernel_body<NV, DMA_SH, STREAM, true>(g, &hc.c[0], recs, radii, exact_cull, cams_out);
+             int exact_cull, int groups) {
+    project_kernel_body<NV, DMA_SH, STREAM, true, LOOP>(g, &hc.c[0], recs, radii, exact_cull, cams_out, groups);
 }
 
 // Gaussian -> workgroup assignment of the counting sort (k_count_tiles and k_scatter must agree: the histogram row of a

@@ -17,10 +17,9 @@ size_t gs2m_scatter_lds_bytes(int nv, int tiles, int threads) {
 }
 
 void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, CamUniform* cams, GeomRecs recs, int* radii,
-                         int exact_cull, const CamUniform* host_cams) {
+                         int exact_cull, const CamUniform* host_cams, int shared_read) {
     const unsigned nx = (unsigned)((g.P + 255) / 256);
     if (nx == 0) return;
-    const dim3 n(nx, (unsigned)pairs);   // blockIdx.y = group of nv views (GS2M_OPT_PAIR_BATCH)
     // SH rows through LDS (k_project<.., true>): with the spatially ordered packed model (large models, where (almost) every
     // Gaussian is visible: C3 148 -> 136 us); a model that only has the packed SH copy keeps the register path, which reads
     // no row of a culled Gaussian and runs 16 instead of 12 waves per CU (C2: 28 vs 30 us)
@@ -28,24 +27,31 @@ void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, Ca
     // the colour pass streams the SH row three float4 at a time where the row is 16-B aligned (packed copy, [P,16,3]) or not
     // needed (precomputed colours); dc + rest split layouts / M != 16 keep the 48-register path (k_project<.., .., false>)
     const bool stream = g.colors_precomp != nullptr || g.shs_packed != nullptr || (g.shs_rest == nullptr && g.M == 16);
+    // the `pairs` groups of nv views of the launch (GS2M_OPT_PAIR_BATCH): walked inside the kernel by the thread that owns the
+    // Gaussian (one model read per launch) for large models, one grid row per group otherwise (project_gaussian)
+    const bool loop = pairs > 1 && (shared_read == 1 || (shared_read == 0 && g.P >= GS2M_PROJECT_LOOP_MIN_P)) && host_cams != nullptr && nv == 2 &&
+                      (dma || stream);
+    const dim3 n(nx, loop ? 1u : (unsigned)pairs);
     if (host_cams) {
         // pipeline-level API: the uniforms of the nv * pairs views travel in the launch packet (k_project_hc stores them to
         // `cams` for the later kernels of the pass)
         CamUniformArg a;
         const int n_views = nv * pairs;
         for (int k = 0; k < GS2M_MAX_PASS_VIEWS; ++k) a.c[k] = host_cams[k < n_views ? k : 0];
-        if (nv == 2 && dma) GS2M_LAUNCH((k_project_hc<2, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
-        else if (nv == 2 && stream) GS2M_LAUNCH((k_project_hc<2, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
-        else if (nv == 2) GS2M_LAUNCH((k_project_hc<2, false, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
-        else if (dma) GS2M_LAUNCH((k_project_hc<1, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
-        else if (stream) GS2M_LAUNCH((k_project_hc<1, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
-        else GS2M_LAUNCH((k_project_hc<1, false, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull);
+        if (nv == 2 && dma && loop) GS2M_LAUNCH((k_project_hc<2, true, true, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else if (nv == 2 && stream && loop) GS2M_LAUNCH((k_project_hc<2, false, true, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else if (nv == 2 && dma) GS2M_LAUNCH((k_project_hc<2, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else if (nv == 2 && stream) GS2M_LAUNCH((k_project_hc<2, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else if (nv == 2) GS2M_LAUNCH((k_project_hc<2, false, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else if (dma) GS2M_LAUNCH((k_project_hc<1, true>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else if (stream) GS2M_LAUNCH((k_project_hc<1, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
+        else GS2M_LAUNCH((k_project_hc<1, false, false>), n, dim3(256), 0, st, g, a, cams, recs, radii, exact_cull, pairs);
         return;
     }
     // operator-level API (one view, uniforms written to `cams` by k_pack_camera from the caller's device tensors)
-    if (dma) GS2M_LAUNCH((k_project<1, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else if (stream) GS2M_LAUNCH((k_project<1, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
-    else GS2M_LAUNCH((k_project<1, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull);
+    if (dma) GS2M_LAUNCH((k_project<1, true>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull, pairs);
+    else if (stream) GS2M_LAUNCH((k_project<1, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull, pairs);
+    else GS2M_LAUNCH((k_project<1, false, false>), n, dim3(256), 0, st, g, cams, recs, radii, exact_cull, pairs);
 }
 
 int gs2m_launch_count_tiles(int nv, int pairs, int n_wg, int threads, size_t lds_bytes, hipStream_t st, GeomRecs recs, int P,

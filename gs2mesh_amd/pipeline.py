@@ -27,12 +27,12 @@ from .rasterizer import Rasterizer
 class RenderFusePipeline:
     """``raster_options``: ``gs2m_raster_set_option`` values of every slot's handle, by name -- ``exact_tile_cull`` (default
     "auto" = ``rasterizer.auto_cull_level``: 1, or 2 for models of >= 1 M Gaussians), ``tile_rows`` (default 2: 16 x 32 binning
-    tiles, same image, fewer instances), ``blend_variant``, ``bin_lane_tiles``."""
+    tiles, same image, fewer instances), ``blend_variant``, ``bin_lane_tiles``, ``project_shared_read``."""
 
     RASTER_OPTION_IDS = dict(exact_tile_cull=_lib.OPT_EXACT_TILE_CULL, tile_rows=_lib.OPT_TILE_ROWS,
                              blend_variant=_lib.OPT_BLEND_VARIANT, blend_mode=_lib.OPT_BLEND_MODE,
                              bin_workgroups=_lib.OPT_BIN_WORKGROUPS, bin_wg_threads=_lib.OPT_BIN_WG_THREADS,
-                             bin_lane_tiles=_lib.OPT_BIN_LANE_TILES)
+                             bin_lane_tiles=_lib.OPT_BIN_LANE_TILES, project_shared_read=_lib.OPT_PROJECT_SHARED_READ)
 
     def __init__(self, gaussians: dict, width: int, height: int, volume: ScalableTSDFVolume | None = None,
                  intrinsic: PinholeCameraIntrinsic | None = None, inflight: int = 2, device: int = 0, *, fuse_batch=1,

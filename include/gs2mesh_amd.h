@@ -34,7 +34,7 @@ extern "C" {
 #define GS2M_VERSION 600 /* 0.6.0: round-6 ABI = the round-4 ABI (401) + the round-5 entry points that 401 never counted
                             (gs2m_tsdf_block_map / _map_keys / _map_bytes / _replace / _extract_mesh / _mesh_copy,
                             gs2m_mesh_cluster, gs2m_raster_blend_cycles, GS2M_OPT_BLEND_MODE / _PROFILE) + round 6
-                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES, GS2M_OPT_EXACT_TILE_CULL level 2; GS2M_OPT_BLEND_MODE 1
+                            (gs2m_tsdf_flags_device, GS2M_OPT_BIN_LANE_TILES, GS2M_OPT_PROJECT_SHARED_READ, GS2M_OPT_EXACT_TILE_CULL level 2; GS2M_OPT_BLEND_MODE 1
                             removed).  The Python binding checks it at load time */
 
 typedef void* gs2m_stream; /* hipStream_t */
@@ -94,6 +94,11 @@ enum {
                                      walked by its own lane in the counting / scatter kernels -- exact tile test in registers, the kept
                                      tiles as a small bit mask -- instead of through the wave-balanced staged walk; 0 = only the thin
                                      rects of round 4 (one tile wide or high, <= 4 tiles) */
+    GS2M_OPT_PROJECT_SHARED_READ = 14, /* tuning (results never change): the stereo pairs of a launch (GS2M_OPT_PAIR_BATCH) share ONE read of
+                                     the model in the projection kernel -- the thread that owns a Gaussian projects it for every pair of
+                                     the launch -- instead of one grid row per pair.  0 (default) = for models of >= 1 000 000 Gaussians
+                                     (a smaller model re-reads from the last-level cache and prefers twice the waves), 1 = always,
+                                     2 = never */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and

@@ -118,6 +118,7 @@ static inline float gs2m_fast_log2(float x) { return log2f(x); }
 #define GS2M_KEEP_F32(x) ((void)0)
 #define GS2M_NO_IF_CONVERT() ((void)0)
 #define GS2M_OPAQUE_SGPR(x) ((void)0)
+#define GS2M_OPAQUE_VGPR(x) asm volatile("" : "+r"(x))
 #define GS2M_SCHED_BARRIER() ((void)0)
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 static inline int __ffsll(unsigned long long m) { return __builtin_ffsll((long long)m); }

@@ -440,7 +440,9 @@ def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, r
     grid.  Everything a call returns or leaves behind is identical to one pair per launch: images, u8 images, radii, instance
     counts, and -- per view -- the projected records and the instance lists.  ppl 2: 5 views = one batched pass + one single
     view; 6: a batched pass + a plain pair; 8: two batched passes.  ppl 4: 8 views = one pass of four pairs; 7 = a pass of three
-    pairs + a single view.  ppl 3, 8 views: a pass of three pairs + a plain pair."""
+    pairs + a single view.  ppl 3, 8 views: a pass of three pairs + a plain pair.  GS2M_OPT_PROJECT_SHARED_READ (round 6): the
+    batched launches once with one grid row per pair (2 = never shared) and once with the pairs walked by the thread that owns
+    the Gaussian (1 = always: one model read per launch; the default only does that for models of >= 1 M Gaussians)."""
     W, H, f = 176, 112, 150.0
     g, s, q, o, shs, left, right = scene(2600, 33, W, H, f, log_s=math.log(0.05))
     *_rest, left2, right2 = scene(10, 34, W, H, f, az=0.9)       # a second pair of cameras
@@ -452,23 +454,25 @@ def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, r
               raw=True, sh_degree=3)
     tiles = ((W + 15) // 16) * (((H + 15) // 16 + rows - 1) // rows)
     outs = []
-    for batch in (0, ppl):
+    for batch, shared in ((0, 0), (ppl, 2), (ppl, 1)):
         r = Rasterizer(0, lib=be.lib)
         r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
         r.set_option(_lib.OPT_TILE_ROWS, rows)
         r.set_option(_lib.OPT_PAIR_BATCH, batch)
+        r.set_option(_lib.OPT_PROJECT_SHARED_READ, shared)
         if packed:
             r.pack_model(gd)
         for rep in range(2):          # second call: class hints of the sort come from the first
             res = r.render_views(gd, cams, want_radii=True, want_rgb8=True)
         nr = list(res["num_rendered"])
         outs.append((be.host(res["color"]).copy(), be.host(res["rgb8"]).copy(), be.host(res["radii"]).copy(), nr, r))
-    a, b = outs
-    assert a[3] == b[3] and min(a[3]) > 1000
-    np.testing.assert_array_equal(a[2], b[2])
-    np.testing.assert_array_equal(a[0], b[0])
-    np.testing.assert_array_equal(a[1], b[1])
-    if n_views == 4 and ppl == 2:
+    a = outs[0]
+    for b in outs[1:]:
+        assert a[3] == b[3] and min(a[3]) > 1000
+        np.testing.assert_array_equal(a[2], b[2])
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    for b in (outs[1:] if n_views == 4 and ppl == 2 else []):
         # one pair per launch leaves views 2, 3 in the arenas (as views 0, 1 of its last pass); two pairs per launch all four
         ra, rb = a[4], b[4]
         for v in range(2):
@@ -703,6 +707,8 @@ def test_lane_tiles_settings_give_identical_lists(backend, rows):
                 np.testing.assert_array_equal(got[3], base[3])
     with pytest.raises(RuntimeError):
         Rasterizer(0, lib=be.lib).set_option(_lib.OPT_BIN_LANE_TILES, 17)
+    with pytest.raises(RuntimeError):
+        Rasterizer(0, lib=be.lib).set_option(_lib.OPT_PROJECT_SHARED_READ, 3)
 
 
 @pytest.mark.parametrize("cull", [0, 1])

@@ -3,7 +3,7 @@ at the default launch shape (2 stereo pairs per launch, 16 x 32 binning tiles, e
 interleaved in one process (the first kernels of a process run slow), + a check that the instance lists do not change.
 
     python tools/ab_binning.py --configs C2,C3 --settings "L0X1,L4X1,L4X2,L8X2" --rounds 3
-    setting = L<lane tiles>[X<exact cull level 1 | 2>][W<bin workgroups>]
+    setting = L<lane tiles>[X<exact cull level 1 | 2>][W<bin workgroups>][@<k>]   (@k: on the k-th build of --libs, A/B of two trees)
 """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,13 +20,16 @@ ap.add_argument("--groups", type=int, default=6)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--scene", default="synth", choices=["synth", "trained"])
 ap.add_argument("--morton", default="auto", choices=["auto", "0", "1"])
+ap.add_argument("--libs", default="", help="comma-separated extra builds of libgs2mesh_amd.so; a setting `L4X2@1` runs on the first of them")
 a = ap.parse_args()
+import ctypes
+LIBS = [None] + [_lib.bind(ctypes.CDLL(os.path.abspath(p))) for p in a.libs.split(",") if p]
 STAGES = ("project", "count_tiles", "hist_colscan", "tile_scan", "scatter", "sort_tiles", "blend")
 
 
 def parse(s):
-    m = re.fullmatch(r"L(\d+)(?:X(\d))?(?:W(\d+))?", s)
-    return dict(name=s, lane=int(m.group(1)), cull=int(m.group(2) or 1), wg=int(m.group(3) or 0))
+    m = re.fullmatch(r"L(\d+)(?:X(\d))?(?:W(\d+))?(?:@(\d+))?", s)
+    return dict(name=s, lane=int(m.group(1)), cull=int(m.group(2) or 1), wg=int(m.group(3) or 0), lib=int(m.group(4) or 0))
 
 
 for cname in a.configs.split(","):
@@ -45,7 +48,7 @@ for cname in a.configs.split(","):
     n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 31) // 32)
     rast, ref = {}, None
     for st in [parse(s) for s in a.settings.split(",")]:
-        R = Rasterizer(0)
+        R = Rasterizer(0, lib=LIBS[st["lib"]])
         R.set_option(_lib.OPT_EXACT_TILE_CULL, st["cull"])
         R.set_option(_lib.OPT_TILE_ROWS, 2)
         R.set_option(_lib.OPT_PAIR_BATCH, 2)
