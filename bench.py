@@ -157,6 +157,15 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", wit
                       traffic=(int(tr[k]["hbm_bytes_per_launch"] / max(1, int(tr[k].get("pairs_per_launch", 1))))   # per stereo pair
                                if tr.get(k, {}).get("cull") == cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
               for k, (ms, c) in st.items()}
+    if ppl > 1 and cfg.P >= 1_000_000 and "project" in stages:
+        # round 6 (GS2M_OPT_PROJECT_SHARED_READ, auto for >= 1 M Gaussians): the `ppl` pairs of a launch share ONE read of the model
+        # (44 B + the 192-B SH row per Gaussian).  `frac_hbm` stays SURVEY 8(d)'s per-pair figure / time -- it can exceed what one
+        # pair alone could reach; `launch_bytes_per_pair` is what a launch actually has to move per pair.
+        shared = (44.0 * cfg.P + 192.0 * p_vis_union) * (1.0 - 1.0 / ppl)
+        e = stages["project"]
+        e["launch_bytes_per_pair"] = int(alg["project"] - shared)
+        e["frac_hbm_launch_bytes"] = round((alg["project"] - shared) / max(1e-9, e["avg_us"] * 1e-6) / HBM_PEAK, 4)
+        e["note"] = f"the {ppl} stereo pairs of a launch share one read of the model (round 6)"
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
     return dict(workload=f"{cfg_name}: {cfg.P} {scene} Gaussians, {cfg.width}x{cfg.height}, render only, {n_pairs} pairs, "
                          f"serial on one stream, {ppl} stereo pair(s) per launch (stage times per pair)", pairs_per_launch=ppl,
