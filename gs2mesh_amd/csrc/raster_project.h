@@ -785,16 +785,25 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
                 const unsigned long long key = ((unsigned long long)dbits << 32) | kid;
                 int tile = y0 * gx + x0;
                 unsigned rx = 0u;
-                for (unsigned t = 0; t < area_l; ++t) {
-                    if ((msk_pre >> t) & 1ull) {
-                        const unsigned pos = atomicAdd(&cur[tile], 1u);
-                        if (pos < cap) kv[pos] = key;
+                // four tiles per round: the (returning) LDS atomics of a round are issued back to back and waited for ONCE, then
+                // the key stores (rounds 4-5 ran one atomic -> wait -> store chain per tile: four LDS round trips in sequence
+                // for a 2 x 2 rect)
+                for (unsigned t0 = 0; t0 < area_l; t0 += 4u) {
+                    unsigned pos[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const unsigned t = t0 + (unsigned)u;
+                        pos[u] = cap;
+                        if (t < area_l && ((msk_pre >> t) & 1ull) != 0ull) pos[u] = atomicAdd(&cur[tile], 1u);
+                        ++tile;
+                        if (++rx == w) {
+                            rx = 0u;
+                            tile += gx - (int)w;
+                        }
                     }
-                    ++tile;
-                    if (++rx == w) {
-                        rx = 0u;
-                        tile += gx - (int)w;
-                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (pos[u] < cap) kv[pos[u]] = key;
                 }
             }
             const bool small = area != 0u && area <= 64u && !lane_rect;
@@ -821,12 +830,15 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
                 }
                 gs2m_wave_sync();
                 int kbase = 0;
-                for (unsigned b0 = 0; b0 < total; b0 += 64u) {
+                // one 64-item batch: owner lookup, mask bit, cursor bump -> (position, key) of this lane's item (position `cap`: none)
+                auto emit = [&](unsigned b0, unsigned& pos, unsigned long long& key) __attribute__((always_inline)) {
                     const unsigned long long H =
                         (unsigned long long)stage->heads[b0 >> 5] | ((unsigned long long)stage->heads[(b0 >> 5) + 1] << 32);
                     const int kk = kbase + gs2m_popc64(H & lanes_le(lane)) - 1;
                     kbase += gs2m_popc64(H);
                     const unsigned item = b0 + (unsigned)lane;
+                    pos = cap;
+                    key = 0ull;
                     if (item < total) {
                         const unsigned swh = stage->swh[kk];
                         const unsigned li = item - (swh & 0xffffu);
@@ -837,11 +849,24 @@ k_scatter(GeomRecs recs, int P, const CamUniform* __restrict__ cams, int chunk, 
                             rect_coords(li, ow, gs2m_fast_rcp((float)ow), rx, ry);
                             const unsigned oxy = stage->xy0[kk];
                             const int tx = (int)(oxy & 0xffffu) + (int)rx, ty = (int)(oxy >> 16) + (int)ry;
-                            const unsigned pos = atomicAdd(&cur[ty * gx + tx], 1u);
-                            if (pos < cap) kv[pos] = ((unsigned long long)stage->dbits[kk] << 32) | stage->gid[kk];
+                            key = ((unsigned long long)stage->dbits[kk] << 32) | stage->gid[kk];
+                            pos = atomicAdd(&cur[ty * gx + tx], 1u);
                         }
                     }
+                };
+                // two batches per round, the key store of a batch BEHIND the next batch's cursor bump: the returning LDS atomic of
+                // batch A is waited for together with the stage reads of batch B (LDS operations return in order), not on its own
+                // (rounds 1-5: reads -> wait -> atomic -> wait -> store, per batch)
+                unsigned pos_a, pos_b = cap;
+                unsigned long long key_a, key_b = 0ull;
+                for (unsigned b0 = 0; b0 < total; b0 += 128u) {
+                    emit(b0, pos_a, key_a);
+                    if (pos_b < cap) kv[pos_b] = key_b;
+                    pos_b = cap;
+                    if (b0 + 64u < total) emit(b0 + 64u, pos_b, key_b);
+                    if (pos_a < cap) kv[pos_a] = key_a;
                 }
+                if (pos_b < cap) kv[pos_b] = key_b;
             }
             // rects of more than 64 tiles (rare): the whole wave walks one owner at a time, repeating the test
             unsigned long long bigs = gs2m_ballot(area > 64u ? 1 : 0);
