@@ -227,12 +227,15 @@ def main():
     ap.add_argument("--no-trained-like", action="store_true", help="skip the trained-like (C2-sized) render-only sub-measurement")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the 2K-step job of the steady-state probe")
     ap.add_argument("--volume-check", action="store_true", help="add an order-independent fingerprint of the fused volume (summed over the ranks) to the line")
+    ap.add_argument("--raster-opts", default=os.environ.get("GS2M_BENCH_RASTER_OPTS", ""),
+                    help="development sweeps: extra RenderFusePipeline raster_options of the timed pass, e.g. bin_workgroups=512,bin_wg_threads=512")
     ap.add_argument("--rehearsal", action="store_true", default=bool(int(os.environ.get("GS2M_BENCH_REHEARSAL", "0"))),
                     help="run the whole --gpus N control flow (self-spawn, barriers, dt all-reduce, reduce_volume, rank-0-only line) "
                          "with all N ranks sharing GPU 0 over the gloo backend (RCCL refuses two ranks on one device; the exchange "
                          "buffers are staged through host memory): a dress rehearsal of the driver's multi-GPU run on a one-GPU "
                          "box -- the value it prints is NOT a scaling number")
     args = ap.parse_args()
+    extra_raster_opts = {k: int(v) for k, v in (kv.split("=") for kv in args.raster_opts.split(",") if kv)}
     args.cull_arg = args.cull                      # as given (-1 = auto); args.cull = the level the timed configuration runs at
     if args.cull < 0:
         from gs2mesh_amd import synthetic as _syn
@@ -355,7 +358,7 @@ def main():
     # `inflight` stereo pairs in flight on separate streams (own rasteriser handle + images each), integration
     # in view order on a third stream (gs2mesh_amd/pipeline.py); inflight = 1 is the serial single-stream order
     pipe = RenderFusePipeline(gd, Wd, Ht, vol, intr, inflight=args.inflight, device=local_rank,
-                              raster_options=dict(exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows),
+                              raster_options=dict(exact_tile_cull=args.cull, blend_variant=args.blend, tile_rows=args.tile_rows, **extra_raster_opts),
                               fuse_batch=(fuse_plan if fuse_plan and len(fuse_plan) > 1 else args.fuse_batch),
                               spatial_order=("auto" if args.spatial_order < 0 else bool(args.spatial_order)),
                               pairs_per_launch=args.pairs_per_launch)

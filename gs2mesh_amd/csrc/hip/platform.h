@@ -69,6 +69,13 @@ GS2M_DEVICE float gs2m_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }  /
 GS2M_DEVICE float gs2m_fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32 (1 ulp)
 GS2M_DEVICE float gs2m_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32 (flushes denormal results)
 GS2M_DEVICE float gs2m_fast_log2(float x) { return __log2f(x); }
+// a + b rounded on its own: never contracted into an FMA with a neighbouring product (two code shapes that must round alike)
+// (HIP's __fadd_rn is a plain `a + b`, which -ffp-contract=fast may fuse with a product feeding it: one v_add_f32, by hand)
+GS2M_DEVICE float gs2m_add_rn(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // keep a loop-invariant float in its VGPR (stops the compiler re-materialising int->float converts in hot loops)
 #define GS2M_KEEP_F32(x) asm volatile("" : "+v"(x))
 // a wave-uniform int the compiler must treat as an opaque scalar register (stops re-association of mask tests)

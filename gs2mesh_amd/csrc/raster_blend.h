@@ -377,19 +377,24 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
                                 alpha = fminf(0.99f, alpha);              // alpha cap (forward.cu:343)
                                 alpha = qv > B.y ? 0.0f : alpha;          // power > 0: skipped (forward.cu:336-337)
                             }
-                            const float test_T = fmaf(-T[k], alpha, T[k]);
-                            float Tn = test_T;
-                            if (gs2m_any_active_lane(test_T < 0.0001f)) {   // a pixel saturates once: behind a wave-uniform branch
+                            // Round 6: w = alpha T (the reference's own weight, forward.cu:355) and T -= alpha T IN PLACE -- the round-5
+                            // form (T' = fma(-T, alpha, T), w = T - T') kept T and T' alive together and ended every contributing
+                            // quadrant on a register copy (1 of its 8 vector instructions).  A pixel that saturates (T - alpha T <
+                            // 1e-4: its contribution is dropped, it is finished and keeps T) takes the subtraction back in the rare
+                            // path: fl(fl(T - w) + w) may differ from T in the last bit, on a transmittance < ~1e-2 that only
+                            // enters out = C + T bg; MODE 0 does the same, lane for lane.
+                            float wT = T[k] * alpha;
+                            T[k] = fmaf(-T[k], alpha, T[k]);     // T - alpha T with one rounding
+                            if (gs2m_any_active_lane(T[k] < 0.0001f)) {   // a pixel saturates once: behind a wave-uniform branch
                                 GS2M_NO_IF_CONVERT();
-                                const bool sat = test_T < 0.0001f;
+                                const bool sat = T[k] < 0.0001f;
                                 thr[k] = sat ? THR_DONE : thr[k];
-                                Tn = sat ? T[k] : test_T;
+                                T[k] = sat ? gs2m_add_rn(T[k], wT) : T[k];
+                                wT = sat ? 0.0f : wT;
                             }
-                            const float wT = T[k] - Tn;
                             C0[k] = fmaf(B.z, wT, C0[k]);
                             C1[k] = fmaf(B.w, wT, C1[k]);
                             C2[k] = fmaf(CLx, wT, C2[k]);
-                            T[k] = Tn;
                         }
                     }
                 }
@@ -455,14 +460,17 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
                             candm = prem & ~gs2m_ballot_b(qv > B.y);       // power > 0: skipped (forward.cu:336-337)
                             alpha = fminf(0.99f, alpha);
                         }
-                        const float test_T = fmaf(-T[k], alpha, T[k]);
-                        const unsigned long long satm = gs2m_ballot_b(test_T < 0.0001f) & candm;
-                        const float Tn = gs2m_lanes(candm & ~satm) ? test_T : T[k];
-                        const float wT = T[k] - Tn;  // = alpha * T for an accepted contribution, else 0
+                        // the same arithmetic as MODE 2, lane for lane: w = alpha T, T - w with one rounding, and a saturating lane
+                        // takes the subtraction back (fl(fl(T - w) + w)); lanes that are no candidates keep T untouched
+                        const float w0 = T[k] * alpha;
+                        const float Ts = fmaf(-T[k], alpha, T[k]);
+                        const unsigned long long satm = gs2m_ballot_b(Ts < 0.0001f) & candm;
+                        const float Tn = gs2m_lanes(satm) ? gs2m_add_rn(Ts, w0) : Ts;
+                        const float wT = gs2m_lanes(candm & ~satm) ? w0 : 0.0f;
                         C0[k] = fmaf(B.z, wT, C0[k]);
                         C1[k] = fmaf(B.w, wT, C1[k]);
                         C2[k] = fmaf(CL.x, wT, C2[k]);
-                        T[k] = Tn;
+                        T[k] = gs2m_lanes(candm) ? Tn : T[k];
                         dn[k] |= satm;
                     }
                 }

@@ -109,6 +109,7 @@ static inline T gs2m_shfl_up(T v, int d) {
     int l = ::emu::lane();
     return gs2m_shfl(v, l - d >= 0 ? l - d : l);
 }
+static inline float gs2m_add_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline float gs2m_fast_exp(float x) { return expf(x); }
 static inline float gs2m_fast_log(float x) { return logf(x); }
 static inline float gs2m_fast_rcp(float x) { return 1.0f / x; }
