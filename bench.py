@@ -95,6 +95,9 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", wit
     R.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
     R.set_option(_lib.OPT_TILE_ROWS, int(args.tile_rows))
     R.set_option(_lib.OPT_BLEND_VARIANT, int(args.blend))
+    from gs2mesh_amd.rasterizer import auto_blend_mode
+    blend_mode = auto_blend_mode(gd)          # what RenderFusePipeline / Renderer.prepare_renderer pick for this model
+    R.set_option(_lib.OPT_BLEND_MODE, blend_mode)
     ppl = max(1, int(args.pairs_per_launch))
     if ppl > 1:
         R.set_option(_lib.OPT_PAIR_BATCH, ppl)
@@ -173,7 +176,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", wit
     t_raster = sum(v["avg_us"] for v in stages.values()) * 1e-6
     return dict(workload=f"{cfg_name}: {cfg.P} {scene} Gaussians, {cfg.width}x{cfg.height}, render only, {n_pairs} pairs, "
                          f"serial on one stream, {ppl} stereo pair(s) per launch (stage times per pair)", pairs_per_launch=ppl,
-                exact_tile_cull=cull, parity=par,
+                exact_tile_cull=cull, blend_mode=blend_mode, parity=par,
                 num_rendered_per_eye=[int(x) for x in N_eye], p_visible_per_eye=p_vis, overflow=bool(ov),
                 ms_per_pair_wall=round(1e3 * dt, 4), stages=stages,
                 traffic_source="profiles/pmc_traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, (2 * FETCH + WRITE) KiB per launch)",

@@ -212,8 +212,8 @@ extern "C" int gs2m_raster_set_option(gs2m_raster* r, int option, int value) {
             r->opt_bin_wg_threads = value ? value : 1024;
             return 0;
         case GS2M_OPT_BLEND_MODE:
-            if (value != 0 && value != 2) {
-                gs2m_set_error("GS2M_OPT_BLEND_MODE must be 0 or 2 (1 was removed in round 6)");
+            if (value != 0 && value != 2 && value != 3) {
+                gs2m_set_error("GS2M_OPT_BLEND_MODE must be 0, 2 or 3 (1 was removed in round 6)");
                 return 1;
             }
             r->opt_blend_mode = value;

@@ -150,7 +150,8 @@ struct BlendInst {
 
 // One wave composites one 16 x 16 tile (tx, ty) of view v.  MODE 0 = per-pixel decisions as lane masks in scalar registers +
 // per-instance quadrant mask ("reference-structure" loop of rounds 1-4, kept as the cross-check of MODE 2); MODE 2 (round 5,
-// the default) = all four quadrants per staged instance, flag-free runs.  (MODE 1, the execution-mask form of MODE 0, was never
+// the default) = all four quadrants per staged instance, flag-free runs; MODE 3 (round 6) = MODE 2 with the alpha cap applied to
+// every instance instead of splitting the runs at the capped ones (models with many saturated opacities).  (MODE 1, the execution-mask form of MODE 0, was never
 // the fastest anywhere and was removed in round 6.)
 template <int WPB, int LROWS, int MODE, int PROF>
 GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUniform& cam, const unsigned long long* __restrict__ keys,
@@ -158,7 +159,8 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
                             float* __restrict__ out_color, unsigned char* __restrict__ out_rgb8, const int* __restrict__ rank,
                             unsigned long long* __restrict__ prof, float4* __restrict__ s_a, float4* __restrict__ s_b,
                             float2* __restrict__ s_c, float4* __restrict__ s_raw, const int lane) {
-    static_assert(MODE == 0 || MODE == 2, "loop forms: 0 (lane masks in scalar registers), 2 (all quadrants, flag-free runs)");
+    static_assert(MODE == 0 || MODE == 2 || MODE == 3, "loop forms: 0 (lane masks in scalar registers), 2 (all quadrants, flag-free runs), 3 (2 + alpha cap for every instance)");
+    constexpr bool CAP_ALL = MODE == 3;   // see the staging step
     unsigned long long pt_wait = 0, pt_stage = 0, pt_issue = 0, pt_loop = 0, pn_batches = 0, pn_staged = 0;
     // Phase stamps of the profile build: the interval since the previous stamp is added to the phase that ENDS here.
     unsigned long long pt_pro = 0, pt_epi = 0;
@@ -273,7 +275,8 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
             // general path (power > 0 test + alpha cap) only where it can matter: opacity near the 0.99 cap, or a conic so
             // close to singular that rounding could make the quadratic form negative
             const bool singular = !(ra.z > 0.0f && rb.x > 0.0f && det >= 1.0e-3f * ra.z * rb.x);
-            const bool general = !(op <= 0.98f) || singular;   // MODE 2: resolved per RUN of the batch
+            const bool capped = !(op <= 0.98f);                // the alpha cap can bind (forward.cu:343)
+            const bool general = capped || singular;           // MODE 2: resolved per RUN of the batch
             BlendInst bi;
             bi.a = ra;
             bi.b = rb;
@@ -283,11 +286,11 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
             bi.b.y = lo;
             bi.c.x = rc.x;
             bi.c.y = __uint_as_float(m | (general ? 0x100u : 0u));
-            if (LROWS > 1 || MODE == 2) {
+            if (LROWS > 1 || MODE >= 2) {
                 // the list also serves the other half of the 16 x 32 tile: stage only the instances that reach this
                 // half (ballot compaction), so the compositing loop never iterates over the others
                 // MODE 2 has no per-instance mask test in the loop: instances that only reach finished quadrants go here too
-                const bool mine = (MODE == 2 ? (m & lq) != 0u : m != 0u) && have;
+                const bool mine = (MODE >= 2 ? (m & lq) != 0u : m != 0u) && have;
                 const unsigned long long keep = gs2m_ballot_b(mine);
                 const int slot = gs2m_popc64(keep & ((1ull << lane) - 1ull));
                 if (mine) {
@@ -296,10 +299,16 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
                     s_c[slot] = bi.c;
                 }
                 nb_staged = gs2m_popc64(keep);
-                if (MODE == 2) {
+                if (MODE >= 2) {
                     // slots (positions after compaction) of the instances that need the general path: scalar bit loop
                     // over the (few) flagged lanes -- slot = number of kept lanes below
-                    unsigned long long gl = gs2m_ballot_b(general && mine);
+                    // MODE 3 (round 6): only the near-singular instances (rare) split the batch into runs; the alpha cap is applied
+                    // to EVERY instance in the pipelined runs (min(0.99, alpha): +1 vector instruction per contributing quadrant,
+                    // the identity where the cap cannot bind -- same image).  A trained splat has ~30 % of its opacities at the
+                    // cap: as flagged instances they cut the batch every ~2.4 staged instances, i.e. no pipelined run at all
+                    // (C2-sized trained-like scene: 190 -> 172 us per pair; synth_v1, 2 % capped: 170 -> 176, so mode 2 stays the
+                    // default and the pipeline level picks by the model's share of capped opacities, rasterizer.auto_blend_mode).
+                    unsigned long long gl = gs2m_ballot_b((CAP_ALL ? singular : general) && mine);
                     gslots = 0ull;
                     while (gl != 0ull) {
                         const int g = __ffsll((long long)gl) - 1;
@@ -315,7 +324,7 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
         }
         gs2m_wave_sync();   // s_raw has been consumed, the staged batch is complete
         stamp(pt_stage);
-        const int nb = (LROWS > 1 || MODE == 2) ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
+        const int nb = (LROWS > 1 || MODE >= 2) ? nb_staged : ((int)(r1 - base) < 64 ? (int)(r1 - base) : 64);
         base += 64u;
         if (base + (unsigned)lane < r1) {  // records of the next batch -> LDS while this one is composited
             const float4* r4 = rv.ab + 2 * (size_t)gid_next;
@@ -335,7 +344,7 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
             pn_batches += 1;
             pn_staged += (unsigned long long)nb;
         }
-        if (MODE == 2) {
+        if (MODE >= 2) {
             // ---- MODE 2 (round 5): "evaluate all four quadrants".  The loop of MODE 0 spends more scalar than vector issue
             // (per instance-wave on C2: 134 vector cycles per SIMD, but 28 scalar-ALU instructions at ~4.2 SIMD-cycles each
             // when the CU's one scalar unit is the bottleneck + 12 branches; tools/ubench/salu_rates.hip, r5_rates.hip):
@@ -373,10 +382,8 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
                         GS2M_NO_IF_CONVERT();
                         if (cand) {
                             float alpha = gs2m_fast_exp2(qv);
-                            if (GTAG == 1) {
-                                alpha = fminf(0.99f, alpha);              // alpha cap (forward.cu:343)
-                                alpha = qv > B.y ? 0.0f : alpha;          // power > 0: skipped (forward.cu:336-337)
-                            }
+                            if (GTAG != 0) alpha = fminf(0.99f, alpha);                // alpha cap (forward.cu:343)
+                            if (GTAG == 1) alpha = qv > B.y ? 0.0f : alpha;            // power > 0: skipped (forward.cu:336-337)
                             // Round 6: w = alpha T (the reference's own weight, forward.cu:355) and T -= alpha T IN PLACE -- the round-5
                             // form (T' = fma(-T, alpha, T), w = T - T') kept T and T' alive together and ended every contributing
                             // quadrant on a register copy (1 of its 8 vector instructions).  A pixel that saturates (T - alpha T <
@@ -417,16 +424,16 @@ GS2M_DEVICE void blend_tile(const int v, const int tx, const int ty, const CamUn
                         B1 = spb[j + 1];
                         K1 = spc[j + 1].x;
                         GS2M_SCHED_BARRIER();
-                        quads2(std::integral_constant<int, 0>{}, p0, B0, K0);
+                        quads2(std::integral_constant<int, CAP_ALL ? 2 : 0>{}, p0, B0, K0);
                         const Pre2 p1 = pre2(A1, B1);
                         GS2M_SCHED_BARRIER();
                         A0 = spa[j + 2];
                         B0 = spb[j + 2];
                         K0 = spc[j + 2].x;
                         GS2M_SCHED_BARRIER();
-                        quads2(std::integral_constant<int, 0>{}, p1, B1, K1);
+                        quads2(std::integral_constant<int, CAP_ALL ? 2 : 0>{}, p1, B1, K1);
                     }
-                    if (j < j1) quads2(std::integral_constant<int, 0>{}, pre2(A0, B0), B0, K0);
+                    if (j < j1) quads2(std::integral_constant<int, CAP_ALL ? 2 : 0>{}, pre2(A0, B0), B0, K0);
                 }
                 if (j1 < nb) {
                     const float4 Ag = spa[j1], Bg = spb[j1];

@@ -15,13 +15,18 @@ int gs2m_launch_blend(hipStream_t st, int variant, int tile_rows, int nv, int gx
         // schedule: ceil(chunks / 8) chunks per XCD, GS2M_SCHED_CHUNK lists per chunk, tile_rows waves per list, 4 waves per workgroup
         const int nch = ((gx + GS2M_SCHED_CW - 1) / GS2M_SCHED_CW) * ((ltiles / gx + GS2M_SCHED_CH - 1) / GS2M_SCHED_CH);
         const dim3 g2(8u * ((unsigned)(((nch + 7) / 8) * GS2M_SCHED_CHUNK * tile_rows + 3) / 4u), nv);
-        if (mode == 2) {   // GS2M_OPT_BLEND_MODE 2 (round 5): all four quadrants per instance, flag-free runs; views interleaved along x
+        if (mode >= 2) {   // GS2M_OPT_BLEND_MODE 2 / 3 (round 5): all four quadrants per instance, flag-free runs; views interleaved along x
             // interleaved: one row of blocks, view = (blockIdx.x / 8) % nv; else the views along blockIdx.y
             const int nvx = interleave_views && nv > 1 ? nv : 0;
             const dim3 g1 = nvx ? dim3(g2.x * (unsigned)nv, 1) : g2;
             if (prof) {   // GS2M_OPT_BLEND_PROFILE: the same kernel with s_memtime phase stamps
                 if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 2, 1>), g1, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, prof, nvx);
                 else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 2, 1>), g1, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, prof, nvx);
+                return 0;
+            }
+            if (mode == 3) {   // mode 2 with the alpha cap for every instance (no run split at capped instances)
+                if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 3>), g1, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr, nvx);
+                else GS2M_LAUNCH((k_blend_wave4e<4, 1, 7, 3>), g1, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr, nvx);
                 return 0;
             }
             if (tile_rows == 2) GS2M_LAUNCH((k_blend_wave4e<4, 2, 7, 2>), g1, block, 0, st, keys, tile_start, recs, cams, P, cap, out_color, out_rgb8, rank, order, nullptr, nvx);

@@ -27,7 +27,8 @@ from .rasterizer import Rasterizer
 class RenderFusePipeline:
     """``raster_options``: ``gs2m_raster_set_option`` values of every slot's handle, by name -- ``exact_tile_cull`` (default
     "auto" = ``rasterizer.auto_cull_level``: 1, or 2 for models of >= 1 M Gaussians), ``tile_rows`` (default 2: 16 x 32 binning
-    tiles, same image, fewer instances), ``blend_variant``, ``bin_lane_tiles``, ``project_shared_read``."""
+    tiles, same image, fewer instances), ``blend_mode`` (default "auto" = ``rasterizer.auto_blend_mode``: 2, or 3 for models with
+    >= 10 % of their opacities at the alpha cap), ``blend_variant``, ``bin_lane_tiles``, ``project_shared_read``."""
 
     RASTER_OPTION_IDS = dict(exact_tile_cull=_lib.OPT_EXACT_TILE_CULL, tile_rows=_lib.OPT_TILE_ROWS,
                              blend_variant=_lib.OPT_BLEND_VARIANT, blend_mode=_lib.OPT_BLEND_MODE,
@@ -64,6 +65,10 @@ class RenderFusePipeline:
             from .rasterizer import auto_cull_level
             opts["exact_tile_cull"] = auto_cull_level(int(gaussians["xyz"].shape[0]))
         self.exact_tile_cull = int(opts["exact_tile_cull"] or 0)
+        if opts.get("blend_mode", "auto") in ("auto", -1):
+            from .rasterizer import auto_blend_mode
+            opts["blend_mode"] = auto_blend_mode(gaussians)
+        self.blend_mode = int(opts["blend_mode"])
         unknown = set(opts) - set(self.RASTER_OPTION_IDS)
         if unknown:
             raise ValueError(f"unknown raster_options {sorted(unknown)}; known: {sorted(self.RASTER_OPTION_IDS)}")

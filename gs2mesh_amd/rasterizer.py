@@ -8,6 +8,7 @@ This is plumbing between torch tensors (device memory, current stream) and
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -55,6 +56,25 @@ def auto_cull_level(P: int) -> int:
     pair, rasteriser 478 -> 452) and costs ~1 % on a scene of larger / anisotropic splats (3 % more instances to composite):
     chosen by model size, the same rule as ``spatial_order="auto"``."""
     return 2 if int(P) >= 1_000_000 else 1
+
+
+def auto_blend_mode(gaussians: dict, share: float = 0.10) -> int:
+    """``GS2M_OPT_BLEND_MODE`` of the pipeline-level callers (same image either way): 2, or 3 when at least ``share`` of the
+    model's opacities can reach the reference's alpha cap (opacity > 0.98).  Mode 2 splits a staged batch into software-pipelined
+    runs at every such instance (it needs ``min(0.99, alpha)``); mode 3 applies the cap to every instance instead.  Measured on
+    MI355X (profiles/r6_experiments.txt B17): a trained-like splat with 30 % of its opacities at the cap composites in 172 instead
+    of 190 us per pair with mode 3, `synth_v1` (2 %) in 176 instead of 170 -- break-even near 10 %.  ``gaussians`` = the dict
+    ``render_views`` takes (``opacity``: logits when ``raw`` is set, activated values otherwise)."""
+    op = gaussians.get("opacity")
+    if op is None:
+        return 2
+    thr = math.log(0.98 / 0.02) if gaussians.get("raw") else 0.98
+    if _is_torch(op):
+        frac = float((op.reshape(-1) > thr).float().mean().item()) if op.numel() else 0.0
+    else:
+        a = np.asarray(op).reshape(-1)
+        frac = float((a > thr).mean()) if a.size else 0.0
+    return 3 if frac >= share else 2
 
 
 def make_camera(width, height, tanfovx, tanfovy, viewmatrix, projmatrix, campos) -> _lib.Camera:

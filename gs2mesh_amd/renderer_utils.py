@@ -158,8 +158,9 @@ class Renderer:
         self.background = torch.tensor(bg, dtype=torch.float32, device=dev)
         self._bg_host = tuple(float(b) for b in bg)
         self._raster = Rasterizer(torch.device(dev).index or 0)
-        from .rasterizer import auto_cull_level
+        from .rasterizer import auto_blend_mode, auto_cull_level
         raw = self.gaussians.raw()
+        self._raster.set_option(_lib.OPT_BLEND_MODE, auto_blend_mode(raw))   # same image; a trained splat has many opacities at the cap
         self._raster.set_option(_lib.OPT_EXACT_TILE_CULL, auto_cull_level(int(raw["xyz"].shape[0])))   # image-preserving; fewer instances to sort/blend
         self._raster.set_option(_lib.OPT_TILE_ROWS, 2)            # 16 x 32 binning tiles: same image, ~30 % fewer instances
         # one-time re-layout: Morton-ordered packed copy of the splat (a trained splat is stored in densification order,

@@ -1058,8 +1058,9 @@ def test_trained_like_splats_with_flip_attribution(backend, rows, cull):
 
 @pytest.mark.parametrize("rows,cull,log_s", [(1, 0, math.log(0.03)), (2, 1, math.log(0.03)), (2, 1, math.log(0.006))])
 def test_blend_loop_forms_are_bit_identical(backend, rows, cull, log_s):
-    """GS2M_OPT_BLEND_MODE 0 / 2 are two loop forms of the same arithmetic (raster_blend.h): lane masks in scalar registers, and
-    "all four quadrants + flag-free runs" (round 5; mode 1, the execution-mask form, was removed in round 6).  On `synthetic.trained_like` --
+    """GS2M_OPT_BLEND_MODE 0 / 2 / 3 are loop forms of the same arithmetic (raster_blend.h): lane masks in scalar registers,
+    "all four quadrants + flag-free runs" (round 5; mode 1, the execution-mask form, was removed in round 6), and mode 2 with the
+    alpha cap applied to every instance instead of a run split at every capped one (round 6).  On `synthetic.trained_like` --
     30 % of the opacities at the alpha cap (the general path of every mode), saturating pixels, near-singular conics, lists
     longer than one staging batch -- the images must be equal bit for bit, at both binning tile sizes."""
     W, H, f = 200, 136, 180.0
@@ -1073,21 +1074,24 @@ def test_blend_loop_forms_are_bit_identical(backend, rows, cull, log_s):
     be = backend
     d = be.dev
     imgs = []
-    for mode in (0, 2, 2, 3):     # 3 = mode 2 through the instrumented build (phase counters)
+    for mode in (0, 2, 3, "2p"):     # 3 = mode 2 with the alpha cap for every instance (round 6); 2p = mode 2 through the instrumented build
         r = Rasterizer(0, lib=be.lib)
         r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
         r.set_option(_lib.OPT_TILE_ROWS, rows)
-        r.set_option(_lib.OPT_BLEND_MODE, 2 if mode else 0)
-        if mode == 3:
+        r.set_option(_lib.OPT_BLEND_MODE, 2 if mode == "2p" else mode)
+        if mode == "2p":
             r.set_option(_lib.OPT_BLEND_PROFILE, 1)
         img, _ = r.forward(d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
                            d(bg), W, H, cam.tanfovx, cam.tanfovy, shs=d(shs), scales=d(s), rotations=d(q))
         imgs.append(np.array(be.host(img)))
-        if mode == 3:
+        if mode == "2p":
             c = r.blend_cycles()
     assert np.array_equal(imgs[0], imgs[1])
     assert np.array_equal(imgs[0], imgs[2])
     assert np.array_equal(imgs[0], imgs[3])
+    from gs2mesh_amd.rasterizer import auto_blend_mode
+    assert auto_blend_mode(dict(opacity=g["opacity"], raw=True)) == 3 and auto_blend_mode(dict(opacity=o)) == 3     # 30 % at the cap
+    assert auto_blend_mode(dict(opacity=np.full(100, 0.5, np.float32))) == 2 and auto_blend_mode({}) == 2
     assert c["batches"] > 0 and 0 < c["staged_instances"] <= c["listed_instances"] * (2 if rows == 2 else 1)
     assert (imgs[0] != bg[:, None, None]).any()
     with pytest.raises(RuntimeError):

@@ -24,7 +24,7 @@ for it in range(40):
     imgs = {}
     for rows in (1, 2):
         for cull in (0, 1, 2):
-            for mode in (0, 2):
+            for mode in (0, 2, 3):
                 r = Rasterizer(0)
                 r.set_option(_lib.OPT_EXACT_TILE_CULL, cull); r.set_option(_lib.OPT_TILE_ROWS, rows); r.set_option(_lib.OPT_BLEND_MODE, mode)
                 img, _ = r.forward(d(g["xyz"]), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center), d(bg), W, H,
@@ -36,4 +36,4 @@ for it in range(40):
         if not np.array_equal(v, ref):
             bad += 1
             print("MISMATCH", it, W, H, P, k, float(np.abs(v - ref).max()), int((v != ref).sum()))
-print("fuzz done: 40 scenes x 12 settings (tile rows x cull level x loop form), mismatches:", bad)
+print("fuzz done: 40 scenes x 18 settings (tile rows x cull level x loop form), mismatches:", bad)
