@@ -398,7 +398,7 @@ def test_dense_lists_use_the_large_bucket_class(backend):
     assert_image_close(img, ref_img)
 
 
-@pytest.mark.parametrize("n", [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 8191, 8192, 8193])
+@pytest.mark.parametrize("n", [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193])
 @pytest.mark.parametrize("ties", [False, True])
 def test_list_sizes_at_the_boundaries_of_the_sort_paths(backend, n, ties):
     """One list of exactly n instances, n on both sides of every hand-over of the per-tile sort: register network of 1 / 2 /
