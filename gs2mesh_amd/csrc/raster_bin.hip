@@ -20,13 +20,9 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
     // find nothing to do (C2 has no list above 512: 3 x ~35 us of stream latency per pair under the pipelined load).
     // every size class was empty last time: no class kernels; the first workgroups of the small-list kernel still sort whatever
     // larger lists they find, exactly and in bounded time even when the hint is stale (sort_class_lists_rank)
-    // round 6: per class -- a class that was empty last time is not launched (a launch on this chain costs ~3 us even when it finds
-    // nothing); the stand-in covers exactly those classes (bit c of `fold`)
-    int fold = 0;
-    for (int c = 0; c < 3; ++c)
-        if (class_hint && class_hint[c] == 0) fold |= 1 << c;
+    const int fold = class_hint && class_hint[0] == 0 && class_hint[1] == 0 && class_hint[2] == 0;
     GS2M_LAUNCH(k_sort_tiles_small<4>, dim3((tiles + 3) / 4, nv), dim3(256), 0, st, keys, tile_start, tiles, cap, tmp, sort_lists, fold);
-    if (fold == 7) return;
+    if (fold) return;
     const int full[3] = {tiles < 1024 ? tiles : 1024, tiles < 512 ? tiles : 512, tiles < 512 ? tiles : 512};
     int g[3];
     for (int c = 0; c < 3; ++c) {
@@ -37,7 +33,7 @@ void gs2m_launch_sort_tiles(hipStream_t st, int nv, unsigned long long* keys, un
         }
         if (g[c] < 1) g[c] = 1;
     }
-    if (!(fold & 1)) GS2M_LAUNCH(k_sort_tiles_bucket_4096x8, dim3(g[0], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    if (!(fold & 2)) GS2M_LAUNCH(k_sort_tiles_bucket_8192x8, dim3(g[1], nv), dim3(1024), 0, st, keys, tile_start, tiles, cap, sort_lists);
-    if (!(fold & 4)) GS2M_LAUNCH(k_sort_tiles, dim3(g[2], nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH(k_sort_tiles_bucket_4096x8, dim3(g[0], nv), dim3(512), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH(k_sort_tiles_bucket_8192x8, dim3(g[1], nv), dim3(1024), 0, st, keys, tile_start, tiles, cap, sort_lists);
+    GS2M_LAUNCH(k_sort_tiles, dim3(g[2], nv), dim3(256), 0, st, keys, tmp, tile_start, tiles, cap, sort_lists);
 }

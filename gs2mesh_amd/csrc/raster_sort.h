@@ -495,9 +495,8 @@ GS2M_DEVICE bool sort_wave_bucket(unsigned long long* __restrict__ kv, const int
 GS2M_DEVICE void sort_class_lists_rank(unsigned long long* __restrict__ keys, unsigned long long* __restrict__ tmp,
                                        const unsigned* __restrict__ tile_start, int tiles, unsigned cap,
                                        const unsigned* __restrict__ sort_lists, const int v, const unsigned first, const unsigned stride,
-                                       const int tid, const int class_mask) {
+                                       const int tid) {
     for (int cls = 0; cls < GS2M_SORT_CLASSES; ++cls) {
-        if (!((class_mask >> cls) & 1)) continue;   // this class has a kernel of its own in this pass
         const unsigned* list = sort_lists + ((size_t)v * GS2M_SORT_CLASSES + cls) * (tiles + 1);
         const unsigned count = list[0];
         for (unsigned li = first; li < count; li += stride) {
@@ -595,10 +594,9 @@ k_sort_tiles_small(unsigned long long* __restrict__ keys, const unsigned* __rest
     }
     // fold_rank: the previous call on the handle found every size class empty, so the class kernels are not launched; the first
     // workgroups sort whatever larger lists there are after all (sort_class_lists_rank: exact, bounded; needs 256 threads)
-    // (round 6: per class -- bit c of fold_rank = class c was empty last time and has no launch of its own in this pass)
     if (WPB == 4 && fold_rank && blockIdx.x < GS2M_SORT_RANK_BLOCKS)
         sort_class_lists_rank(keys, tmp, tile_start, tiles, cap, sort_lists, v, blockIdx.x,
-                              gridDim.x < GS2M_SORT_RANK_BLOCKS ? gridDim.x : GS2M_SORT_RANK_BLOCKS, (int)threadIdx.x, fold_rank);
+                              gridDim.x < GS2M_SORT_RANK_BLOCKS ? gridDim.x : GS2M_SORT_RANK_BLOCKS, (int)threadIdx.x);
 }
 
 template <int E>

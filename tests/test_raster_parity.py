@@ -398,49 +398,6 @@ def test_dense_lists_use_the_large_bucket_class(backend):
     assert_image_close(img, ref_img)
 
 
-def test_a_class_that_was_empty_last_time_is_still_sorted(backend):
-    """Round 6: a size class of the per-tile sort that was empty in the handle's previous pass has no launch of its own in the
-    next one (a launch on the chain costs ~3 us even when it finds nothing); the stand-in in the first workgroups of the
-    small-list kernel covers exactly those classes.  The hint can be stale: pass 1 has lists in the <4096> class only, pass 2
-    (same handle, same image size) moves ~6000 instances into ONE list -- the <8192> class, not launched -- and keeps one list
-    in the <4096> class, which IS launched.  Both passes' instance lists equal the oracle's exactly."""
-    W, H, f = 48, 32, 60.0
-    cam = Camera(0, np.eye(3), np.array([0, 0, 4.0]), 2 * math.atan2(W, 2 * f), 2 * math.atan2(H, 2 * f), W, H)
-    rng = np.random.default_rng(29)
-    P = 9000
-    base = rng.normal(0, 0.02, (P, 3)).astype(np.float32)
-    base[:, 2] = rng.uniform(-0.2, 0.2, P)
-    o = rng.uniform(0.02, 0.4, P).astype(np.float32)
-    cols = rng.uniform(0, 1, (P, 3)).astype(np.float32)
-    s = np.full((P, 3), 0.012, np.float32)
-    q = np.tile([1, 0, 0, 0], (P, 1)).astype(np.float32)
-    xyz1 = base.copy()                                            # pass 1: three lists of ~3000 (512 < n <= 4096)
-    xyz1[:, 1] -= 0.53
-    xyz1[3000:6000, 0] += 1.07
-    xyz1[6000:, 0] -= 1.07
-    xyz2 = base.copy()                                            # pass 2: ~6000 in one list (4096 < n <= 8192) + ~3000 in another
-    xyz2[:, 1] -= 0.53
-    xyz2[6000:, 0] += 1.07
-    be = backend
-    d = be.dev
-    r = Rasterizer(0, lib=be.lib)
-    for xyz, want_big in ((xyz1, False), (xyz1, False), (xyz2, True)):     # pass 2 of xyz1: its class counts have landed in the mirror
-        img, radii = r.forward(d(xyz), d(o), d(cam.world_view_transform), d(cam.full_proj_transform), d(cam.camera_center),
-                               d(np.zeros(3, np.float32)), W, H, cam.tanfovx, cam.tanfovy, colors_precomp=d(cols), scales=d(s),
-                               rotations=d(q))
-        ref_img, ref_radii, ref_n = oracle_forward(cam, xyz, o, [0, 0, 0], colors_precomp=cols, scales=s, rotations=q)
-        assert r.last_num_rendered == ref_n
-        geom_ref = oracle.preprocess(xyz, s, q, o, None, cam.world_view_transform, cam.full_proj_transform,
-                                     cam.camera_center, W, H, cam.tanfovx, cam.tanfovy, colors_precomp=cols)
-        ref_pl, ref_ranges = oracle.bin_instances(geom_ref, W, H)
-        sizes = (ref_ranges[:, 1] - ref_ranges[:, 0]).astype(np.int64)
-        assert ((sizes > 512) & (sizes <= 4096)).any() and bool(((sizes > 4096) & (sizes <= 8192)).any()) == want_big, sizes
-        pl, ranges = r.download_binning(0, ref_n, 3 * 2)
-        np.testing.assert_array_equal(ranges, ref_ranges)
-        np.testing.assert_array_equal(pl, ref_pl)
-        assert_image_close(be.host(img), ref_img)
-
-
 @pytest.mark.parametrize("n", [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193])
 @pytest.mark.parametrize("ties", [False, True])
 def test_list_sizes_at_the_boundaries_of_the_sort_paths(backend, n, ties):
