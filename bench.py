@@ -65,6 +65,12 @@ def committed_traffic(cfg_name):
         return {}
 
 
+def pairs_per_launch_for(args, P):
+    """--pairs-per-launch 0 (auto): 4 stereo pairs per launch for models of >= 1 M Gaussians, else 2 (the argument's help says why)."""
+    a = int(getattr(args, "ppl_arg", args.pairs_per_launch))
+    return a if a > 0 else (4 if int(P) >= 1_000_000 else 2)
+
+
 def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", with_parity=False):
     """Render-only sub-measurement (no TSDF, serial on one stream, hipEvents per launch, the default launch shape:
     `--pairs-per-launch` stereo pairs per chain of launches): the C3 sub-line and (scene "trained_like": anisotropic, saturated
@@ -98,7 +104,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", wit
     from gs2mesh_amd.rasterizer import auto_blend_mode
     blend_mode = auto_blend_mode(gd)          # what RenderFusePipeline / Renderer.prepare_renderer pick for this model
     R.set_option(_lib.OPT_BLEND_MODE, blend_mode)
-    ppl = max(1, int(args.pairs_per_launch))
+    ppl = pairs_per_launch_for(args, cfg.P)
     if ppl > 1:
         R.set_option(_lib.OPT_PAIR_BATCH, ppl)
     if args.spatial_order > 0 or (args.spatial_order < 0 and cfg.P >= 1_000_000):
@@ -221,9 +227,12 @@ def main():
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
                          "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
-    ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "2")), choices=[1, 2, 4],
-                    help="2 (default) = two consecutive stereo pairs share every launch of the binning chain and the compositing "
-                         "(GS2M_OPT_PAIR_BATCH; same images and volume; C2 0.315 -> 0.305 ms per step); 1 = one pair per launch")
+    ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "0")), choices=[0, 1, 2, 4],
+                    help="consecutive stereo pairs that share every launch of the binning chain and the compositing (GS2M_OPT_PAIR_BATCH; "
+                         "same images and volume).  0 (default) = by model size (pairs_per_launch_for): 2, or 4 from 1 M Gaussians -- a "
+                         "spatially ordered large model reads its parameters once per launch and its longer compositing grids lose less "
+                         "to ramp and tail (round 6, 24-step jobs: C3 2546 -> 2627, C4 1922 -> 1945, C5 3277 -> 3330 pairs/s), while an "
+                         "unordered small model pays for eight open key arrays in the scatter (C2 3647 -> 3583); 1 = one pair per launch")
     ap.add_argument("--min-repeats", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -328,6 +337,8 @@ def main():
         # decreasing size (10, 5, 3, 2: only a small sweep after the last render) 0.356 vs 0.348 ms.
         n_sweeps = max(1, -(-K // 32))
         args.fuse_batch = max(1, -(-K // n_sweeps))
+    args.ppl_arg = int(args.pairs_per_launch)            # as given (0 = auto): the sub-lines resolve it for THEIR model
+    args.pairs_per_launch = pairs_per_launch_for(args, synthetic.CONFIGS[args.config].P)
     if args.pairs_per_launch > 1:
         # two pairs per launch render into consecutive buffers of the pending sweep: even sweep sizes (an odd last view is
         # flushed on its own); nothing to pair up in a one-view job or without the pipeline
