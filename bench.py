@@ -65,10 +65,16 @@ def committed_traffic(cfg_name):
         return {}
 
 
+def spatial_order_for(args, P):
+    """--spatial-order -1 (auto): the pipeline's rule (gs2mesh_amd.rasterizer.auto_spatial_order)."""
+    from gs2mesh_amd.rasterizer import auto_spatial_order
+    return bool(args.spatial_order) if args.spatial_order >= 0 else auto_spatial_order(P)
+
+
 def pairs_per_launch_for(args, P):
-    """--pairs-per-launch 0 (auto): 4 stereo pairs per launch for models of >= 1 M Gaussians, else 2 (the argument's help says why)."""
+    """--pairs-per-launch 0 (auto): 4 stereo pairs per launch with a spatially ordered model, else 2 (the argument's help says why)."""
     a = int(getattr(args, "ppl_arg", args.pairs_per_launch))
-    return a if a > 0 else (4 if int(P) >= 1_000_000 else 2)
+    return a if a > 0 else (4 if spatial_order_for(args, P) else 2)
 
 
 def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", with_parity=False):
@@ -107,7 +113,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", wit
     ppl = pairs_per_launch_for(args, cfg.P)
     if ppl > 1:
         R.set_option(_lib.OPT_PAIR_BATCH, ppl)
-    if args.spatial_order > 0 or (args.spatial_order < 0 and cfg.P >= 1_000_000):
+    if spatial_order_for(args, cfg.P):
         R.pack_model(gd)
     else:
         R.pack_sh(gd)
@@ -170,7 +176,7 @@ def raster_only(args, cfg_name, dev, local_rank, pairs=12, scene="synth_v1", wit
                       traffic=(int(tr[k]["hbm_bytes_per_launch"] / max(1, int(tr[k].get("pairs_per_launch", 1))))   # per stereo pair
                                if tr.get(k, {}).get("cull") == cull and tr[k].get("hbm_bytes_per_launch") is not None else None))
               for k, (ms, c) in st.items()}
-    if ppl > 1 and cfg.P >= 1_000_000 and "project" in stages:
+    if ppl > 1 and spatial_order_for(args, cfg.P) and "project" in stages:
         # round 6 (GS2M_OPT_PROJECT_SHARED_READ, auto for >= 1 M Gaussians): the `ppl` pairs of a launch share ONE read of the model
         # (44 B + the 192-B SH row per Gaussian).  `frac_hbm` stays SURVEY 8(d)'s per-pair figure / time -- it can exceed what one
         # pair alone could reach; `launch_bytes_per_pair` is what a launch actually has to move per pair.
@@ -226,13 +232,13 @@ def main():
                          "0 (default) = the K views of a job in equal sweeps of at most 32 views")
     ap.add_argument("--spatial-order", type=int, default=int(os.environ.get("GS2M_BENCH_SPATIAL_ORDER", "-1")),
                     help="1 = Morton-ordered packed copy of the model in the handles (gs2m_raster_pack_model, one-time prepare, same "
-                         "results); 0 = SH packing only; -1 (default) = the pipeline's rule: models of >= 1 M Gaussians")
+                         "results); 0 = SH packing only; -1 (default) = the pipeline's rule (rasterizer.auto_spatial_order: >= 32 768 Gaussians)")
     ap.add_argument("--pairs-per-launch", type=int, default=int(os.environ.get("GS2M_BENCH_PAIRS_PER_LAUNCH", "0")), choices=[0, 1, 2, 4],
                     help="consecutive stereo pairs that share every launch of the binning chain and the compositing (GS2M_OPT_PAIR_BATCH; "
-                         "same images and volume).  0 (default) = by model size (pairs_per_launch_for): 2, or 4 from 1 M Gaussians -- a "
-                         "spatially ordered large model reads its parameters once per launch and its longer compositing grids lose less "
-                         "to ramp and tail (round 6, 24-step jobs: C3 2546 -> 2627, C4 1922 -> 1945, C5 3277 -> 3330 pairs/s), while an "
-                         "unordered small model pays for eight open key arrays in the scatter (C2 3647 -> 3583); 1 = one pair per launch")
+                         "same images and volume).  0 (default) = 4 with a spatially ordered model (the pipeline's default from 32 768 "
+                         "Gaussians), else 2: the ordered model reads its parameters once per launch and its longer compositing grids "
+                         "lose less to ramp and tail (round 6: C2 3787 -> 3842, C3 2546 -> 2627, C5 3540 -> 3643 pairs/s), while an "
+                         "UNORDERED model pays for eight open key arrays in the scatter (C2 3643 -> 3547); 1 = one pair per launch")
     ap.add_argument("--min-repeats", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="accumulated timed region to reach")
     ap.add_argument("--max-repeats", type=int, default=400)

@@ -29,8 +29,10 @@ void gs2m_launch_project(int nv, int pairs, hipStream_t st, const GaussIn& g, Ca
     const bool stream = g.colors_precomp != nullptr || g.shs_packed != nullptr || (g.shs_rest == nullptr && g.M == 16);
     // the `pairs` groups of nv views of the launch (GS2M_OPT_PAIR_BATCH): walked inside the kernel by the thread that owns the
     // Gaussian (one model read per launch) for large models, one grid row per group otherwise (project_gaussian)
-    const bool loop = pairs > 1 && (shared_read == 1 || (shared_read == 0 && g.P >= GS2M_PROJECT_LOOP_MIN_P)) && host_cams != nullptr && nv == 2 &&
-                      (dma || stream);
+    // auto: with the DMA path (spatially ordered packed model: its LDS bounds the occupancy at 3 waves per SIMD anyway, so the loop's
+    // registers cost nothing -- C2 ordered, 4 pairs per launch: 16.8 -> 15.5 us) or from GS2M_PROJECT_LOOP_MIN_P Gaussians
+    const bool loop = pairs > 1 && (shared_read == 1 || (shared_read == 0 && (dma || g.P >= GS2M_PROJECT_LOOP_MIN_P))) && host_cams != nullptr &&
+                      nv == 2 && (dma || stream);
     const dim3 n(nx, loop ? 1u : (unsigned)pairs);
     if (host_cams) {
         // pipeline-level API: the uniforms of the nv * pairs views travel in the launch packet (k_project_hc stores them to

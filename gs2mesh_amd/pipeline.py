@@ -46,7 +46,8 @@ class RenderFusePipeline:
         # 115 -> 62 us); below that the XCD-contiguous rows already merge the key stores and the ordered model only adds
         # LDS-atomic conflicts to the counting kernel (C2, 300 k Gaussians: count 29 -> 35 us, scatter 26 -> 25 us).
         if spatial_order == "auto":
-            spatial_order = int(gaussians["xyz"].shape[0]) >= 1_000_000
+            from .rasterizer import auto_spatial_order
+            spatial_order = auto_spatial_order(int(gaussians["xyz"].shape[0]))
         self.spatial_order = bool(spatial_order)
         self.W, self.H = int(width), int(height)
         self.volume, self.intrinsic = volume, intrinsic

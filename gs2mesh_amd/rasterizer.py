@@ -54,8 +54,21 @@ def auto_cull_level(P: int) -> int:
     corners is tested tile by tile; 2 = rects of at most 4 binning tiles keep all their tiles.  Level 2 pays on models of small
     splats, where the test removes ~2 % of the instances at 60 % of the counting kernel's instructions (C3: count 49 -> 28 us per
     pair, rasteriser 478 -> 452) and costs ~1 % on a scene of larger / anisotropic splats (3 % more instances to composite):
-    chosen by model size, the same rule as ``spatial_order="auto"``."""
+    chosen by model size (C2 with the ordered model, round 6: level 2 +0.5 %, inside the run-to-run spread)."""
     return 2 if int(P) >= 1_000_000 else 1
+
+
+SPATIAL_ORDER_MIN_P = 32768
+
+
+def auto_spatial_order(P: int) -> bool:
+    """``spatial_order="auto"`` of the pipeline-level callers: the Morton-ordered packed copy of the model
+    (``Rasterizer.pack_model``: one-off prepare, every output bit-identical) for every model of at least 32 768 Gaussians.
+    Rounds 2-5 applied it from 1 M Gaussians, judged by the ISOLATED stage times of a 300 k model (scatter - 4, counting + 4 us
+    per pair); round 6 measured the pipelined job: the unordered model's scattered 8-byte key stores (3.9 x write amplification)
+    cost the kernels of the other stream as well -- C2 3643 -> 3787 pairs/s with the ordered model, 3842-3858 with four pairs per
+    launch on top; C5 3263 -> 3623-3643 (profiles/r6_experiments.txt C20)."""
+    return int(P) >= SPATIAL_ORDER_MIN_P
 
 
 def auto_blend_mode(gaussians: dict, share: float = 0.10) -> int:

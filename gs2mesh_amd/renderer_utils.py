@@ -165,7 +165,8 @@ class Renderer:
         self._raster.set_option(_lib.OPT_TILE_ROWS, 2)            # 16 x 32 binning tiles: same image, ~30 % fewer instances
         # one-time re-layout: Morton-ordered packed copy of the splat (a trained splat is stored in densification order,
         # i.e. spatially random) + wave-transposed SH; images / radii are those of the model as loaded
-        if int(raw["xyz"].shape[0]) >= 1_000_000:    # same rule as RenderFusePipeline(spatial_order="auto")
+        from .rasterizer import auto_spatial_order
+        if auto_spatial_order(int(raw["xyz"].shape[0])):    # same rule as RenderFusePipeline(spatial_order="auto")
             self._raster.pack_model(raw)
         else:
             self._raster.pack_sh(raw)

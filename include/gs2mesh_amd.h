@@ -100,9 +100,9 @@ enum {
                                      rects of round 4 (one tile wide or high, <= 4 tiles) */
     GS2M_OPT_PROJECT_SHARED_READ = 14, /* tuning (results never change): the stereo pairs of a launch (GS2M_OPT_PAIR_BATCH) share ONE read of
                                      the model in the projection kernel -- the thread that owns a Gaussian projects it for every pair of
-                                     the launch -- instead of one grid row per pair.  0 (default) = for models of >= 1 000 000 Gaussians
-                                     (a smaller model re-reads from the last-level cache and prefers twice the waves), 1 = always,
-                                     2 = never */
+                                     the launch -- instead of one grid row per pair.  0 (default) = with a spatially ordered packed model
+                                     (gs2m_raster_pack_model) or from 1 000 000 Gaussians (a small unordered model re-reads from the
+                                     last-level cache and prefers twice the waves), 1 = always, 2 = never */
     GS2M_OPT_TILE_ROWS = 5        /* binning tile = 16 x (16 * rows) pixels.  1 (default) = the reference's 16 x 16
                                      tiles: instance lists / num_rendered are the reference's.  2 = two reference
                                      tiles stacked: ~30 % fewer (Gaussian, tile) instances to count, scatter and

@@ -44,7 +44,7 @@ for cname in a.configs.split(","):
         cams.append([camera_from(l), camera_from(r)])
     groups = [cams[i] + cams[i + 1] for i in range(0, len(cams), 2)]
     out = torch.empty((4, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
-    packed = cfg.P >= 1_000_000 if a.morton == "auto" else a.morton == "1"
+    packed = cfg.P >= 32768 if a.morton == "auto" else a.morton == "1"
     n_tiles = ((cfg.width + 15) // 16) * ((cfg.height + 31) // 32)
     rast, ref = {}, None
     for st in [parse(s) for s in a.settings.split(",")]:

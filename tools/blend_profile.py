@@ -31,7 +31,7 @@ for cname in a.configs.split(","):
     R.set_option(_lib.OPT_TILE_ROWS, 2)
     R.set_option(_lib.OPT_PAIR_BATCH, 2)
     R.set_option(_lib.OPT_BLEND_MODE, 2)
-    if cfg.P >= 1_000_000:
+    if cfg.P >= 32768:
         R.pack_model(gd)
     else:
         R.pack_sh(gd)

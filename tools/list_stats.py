@@ -26,7 +26,7 @@ for cname in a.configs.split(","):
     R = Rasterizer(0)
     R.set_option(_lib.OPT_EXACT_TILE_CULL, auto_cull_level(cfg.P))
     R.set_option(_lib.OPT_TILE_ROWS, 2)
-    packed = cfg.P >= 1_000_000
+    packed = cfg.P >= 32768
     (R.pack_model if packed else R.pack_sh)(gd)
     out = torch.empty((2, 3, cfg.height, cfg.width), dtype=torch.float32, device="cuda")
     res = R.render_views(gd, [camera_from(l), camera_from(r)], out_color=out)
