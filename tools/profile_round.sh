@@ -18,7 +18,7 @@ else
 fi
 # serial on one stream (--inflight 1) with the DEFAULT launch shapes (2 stereo pairs per launch); warm-up = steps so that every
 # TSDF sweep of the run covers the same 12 frames (per-launch averages are then per 12-frame sweep)
-ARGS="--config $CFG --no-cpu-baseline --no-parity --no-c3 --no-steady-state --inflight 1 --steps 12 --warmup 12 --min-repeats 2 --min-seconds 0.05"
+ARGS="--config $CFG --no-cpu-baseline --no-parity --no-c3 --no-trained-like --no-steady-state --inflight 1 --steps 12 --warmup 12 --min-repeats 2 --min-seconds 0.05"
 # kernel stats of the serial order (--inflight 1: kernels in isolation = what bench.py's `stages` time with hipEvents)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py $ARGS > $OUT/stats_bench.json 2> $OUT/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -28,7 +28,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVE
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_SQ2 -- python $R/bench.py $ARGS > /dev/null 2> $OUT/pmc_SQ2.err
 if [ "$CFG" = "C2" ]; then
   # kernel trace of the PIPELINED default (what runs when): tools/trace_summary.py -> trace_summary.txt + a condensed trace
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline --no-parity --no-c3 --no-steady-state --min-repeats 3 --min-seconds 0.02 > /dev/null 2> $OUT/trace.err
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python $R/bench.py --no-cpu-baseline --no-parity --no-c3 --no-trained-like --no-steady-state --min-repeats 3 --min-seconds 0.02 > /dev/null 2> $OUT/trace.err
   T=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
   [ -n "$T" ] && python $R/tools/trace_summary.py $T 20 > $OUT/trace_summary.txt 2>&1
   find $OUT/trace -name "*kernel_trace.csv" -delete    # the raw trace is large; the condensed window stays
