@@ -454,7 +454,7 @@ def test_two_pairs_per_launch_give_the_results_of_one_pair_per_launch(backend, r
               raw=True, sh_degree=3)
     tiles = ((W + 15) // 16) * (((H + 15) // 16 + rows - 1) // rows)
     outs = []
-    for batch, shared in ((0, 0), (ppl, 2), (ppl, 1)):
+    for batch, shared in ((0, 0), (ppl, 2), (ppl, 1), (ppl, 0)):     # 0 = auto: shared with a packed model, two groups per thread at ppl 4
         r = Rasterizer(0, lib=be.lib)
         r.set_option(_lib.OPT_EXACT_TILE_CULL, cull)
         r.set_option(_lib.OPT_TILE_ROWS, rows)
