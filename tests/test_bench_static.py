@@ -69,3 +69,27 @@ def test_the_json_line_is_the_only_thing_on_stdout_when_a_collective_library_is_
     i_dup, i_init = src.index("os.dup2(2, 1)"), src.index("dist.init_process_group(")
     assert i_dup < i_init
     assert "line_out = os.fdopen(os.dup(1), \"w\")" in src and "line_out.flush()" in src
+
+
+def test_launch_shape_rules_of_the_timed_pass():
+    """Round 6: the model order and the pairs per launch are chosen by rules measured on the pipelined job
+    (profiles/r6_experiments.txt C20): ordered model from 32 768 Gaussians, four pairs per launch with it, two without;
+    explicit arguments win; the sub-lines resolve the rule for THEIR model."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from gs2mesh_amd.rasterizer import auto_blend_mode, auto_cull_level, auto_spatial_order
+    assert not auto_spatial_order(10_000) and auto_spatial_order(32_768) and auto_spatial_order(300_000) and auto_spatial_order(2_000_000)
+    assert auto_cull_level(300_000) == 1 and auto_cull_level(2_000_000) == 2
+    auto = types.SimpleNamespace(spatial_order=-1, pairs_per_launch=0)
+    assert bench.spatial_order_for(auto, 300_000) and not bench.spatial_order_for(auto, 10_000)
+    assert bench.pairs_per_launch_for(auto, 300_000) == 4 and bench.pairs_per_launch_for(auto, 10_000) == 2
+    unordered = types.SimpleNamespace(spatial_order=0, pairs_per_launch=0)
+    assert bench.pairs_per_launch_for(unordered, 2_000_000) == 2
+    fixed = types.SimpleNamespace(spatial_order=-1, pairs_per_launch=1, ppl_arg=2)          # main() resolved 2 -> sub-lines see the argument as given
+    assert bench.pairs_per_launch_for(fixed, 300_000) == 2
+    import numpy as np
+    assert auto_blend_mode(dict(opacity=np.array([5.0, 5.0, -1.0, 0.0], np.float32), raw=True)) == 3      # half of them above logit(0.98)
+    assert auto_blend_mode(dict(opacity=np.array([0.5, 0.97], np.float32))) == 2
