@@ -6,6 +6,7 @@
 // unique 64-bit key depth_bits<<32 | id with a bitonic network in LDS.  Order = ascending depth,
 // ties by ascending Gaussian id = the reference's stable radix-sort order.
 #pragma once
+#include <type_traits>
 #include "raster_common.h"
 
 #define GS2M_SORT_WAVE 512           // lists up to here: one wave, register bitonic (k_sort_tiles_small)
@@ -635,17 +636,25 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
     constexpr int NW = THREADS / 64, E = CAP / THREADS;
     static_assert(E == 16 || E == 8, "8 or 16 keys per thread");
     const int lane = tid & 63, wave = tid >> 6;
+    // Round 6: a list of n keys only fills the first ER = ceil(n / THREADS) of a thread's E key slots (a 600-key list on the 512-thread
+    // class: 2 of 8; C3's 4 900-key lists on the 1024-thread class: 5 of 8).  The slots beyond are skipped by wave-uniform tests
+    // instead of being executed under an empty execution mask (the sort is ~775 vector instructions per wave and list, PMC).
+    // (the <8192 x 8> class keeps all E slots: its lists fill 5+ of 8, and the tests + the per-count copies of the rank loop cost it
+    // registers -- C3 55.1 -> 56.0, C4 65.9 -> 68.4 us with the skip everywhere; trained-like 26.8 -> 24.6, C5 33.2 -> 29.4)
+    constexpr bool SKIP_DEAD = CAP <= 4096;
+    const int ER = SKIP_DEAD ? (n + THREADS - 1) / THREADS : E;
     // ---- the keys (16 per thread, registers) and the depth range of the list
     unsigned long long k[E];
     unsigned dmin = 0xffffffffu, dmax = 0u;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int i = r * THREADS + tid;
-        k[r] = i < n ? kv[i] : ~0ull;
+        k[r] = ~0ull;
+        if (r < ER) k[r] = i < n ? kv[i] : ~0ull;
     }
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        if (r * THREADS + tid < n) {
+        if (r < ER && r * THREADS + tid < n) {
             const unsigned d = (unsigned)(k[r] >> 32);
             dmin = d < dmin ? d : dmin;
             dmax = d > dmax ? d : dmax;
@@ -687,7 +696,7 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
     for (int r = 0; r < E; ++r) {
         const int i = r * THREADS + tid;
         slot[r] = 0;
-        if (i < n) {
+        if (r < ER && i < n) {
             const unsigned b = bucket_of(k[r]);
             const unsigned old = atomicAdd(&s_cnt[b >> 1], 1u << ((b & 1u) << 4));
             slot[r] = (unsigned short)((old >> ((b & 1u) << 4)) & 0xffffu);
@@ -759,24 +768,27 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
     auto start_of = [&](unsigned b) -> unsigned { return (s_cnt[b >> 1] >> ((b & 1u) << 4)) & 0xffffu; };
 #pragma unroll
     for (int r = 0; r < E; ++r) {
-        const int i = r * THREADS + tid;
-        const unsigned st = start_of(i < n ? bucket_of(k[r]) : 0u);   // unconditional read: E reads in flight
-        if (i < n) s_key[st + slot[r]] = k[r];
+        if (r < ER) {   // wave-uniform
+            const int i = r * THREADS + tid;
+            const unsigned st = start_of(i < n ? bucket_of(k[r]) : 0u);   // unconditional read: the live reads in flight together
+            if (i < n) s_key[st + slot[r]] = k[r];
+        }
     }
     __syncthreads();
     // ---- rank inside the bucket -> final position; slot j of the bucket-ordered array goes to lo + rank
     // (as in sort_wave_bucket: keys and bucket bounds first, then the buckets of a thread's keys walked in lock step for
     // `wg_max` rounds -- 8 independent LDS reads per round; two passes of 8 keys when a thread holds 16)
     constexpr int RC = 8;
-#pragma unroll
-    for (int c = 0; c < E / RC; ++c) {
-        unsigned long long key[RC];
-        unsigned lo[RC], len[RC], rank[RC];
+    // one chunk of up to RC key slots per thread with LIVE of them in use (compile-time: the rounds loop stays branch-free)
+    auto rank_chunk = [&](const int c, auto live_tag) __attribute__((always_inline)) {
+        constexpr int LIVE = (int)decltype(live_tag)::value;
+        unsigned long long key[LIVE];
+        unsigned lo[LIVE], len[LIVE], rank[LIVE];
         // unconditional LDS reads (indices inside the arrays: j < CAP, buckets <= nb), lanes without a key get len = 0
 #pragma unroll
-        for (int r = 0; r < RC; ++r) key[r] = s_key[(c * RC + r) * THREADS + tid];
+        for (int r = 0; r < LIVE; ++r) key[r] = s_key[(c * RC + r) * THREADS + tid];
 #pragma unroll
-        for (int r = 0; r < RC; ++r) {
+        for (int r = 0; r < LIVE; ++r) {
             const bool in = (c * RC + r) * THREADS + tid < n;
             const unsigned b = in ? bucket_of(key[r]) : 0u;
             const unsigned st = start_of(b), en = start_of(b + 1u);
@@ -786,15 +798,30 @@ GS2M_DEVICE void sort_list_bucket(unsigned long long* __restrict__ kv, const int
         }
         for (unsigned q = 0; q < wg_max; ++q) {
 #pragma unroll
-            for (int r = 0; r < RC; ++r) {
+            for (int r = 0; r < LIVE; ++r) {
                 const bool more = q < len[r];
                 const unsigned long long other = s_key[more ? lo[r] + q : lo[r]];
                 rank[r] += (more && other < key[r]) ? 1u : 0u;
             }
         }
 #pragma unroll
-        for (int r = 0; r < RC; ++r)
+        for (int r = 0; r < LIVE; ++r)
             if ((c * RC + r) * THREADS + tid < n) kv[lo[r] + rank[r]] = key[r];
+    };
+#pragma unroll
+    for (int c = 0; c < E / RC; ++c) {
+        const int live = ER - c * RC;   // wave-uniform
+        if (live <= 0) break;
+        switch (live < RC ? live : RC) {
+            case 1: rank_chunk(c, std::integral_constant<int, 1>{}); break;
+            case 2: rank_chunk(c, std::integral_constant<int, 2>{}); break;
+            case 3: rank_chunk(c, std::integral_constant<int, 3>{}); break;
+            case 4: rank_chunk(c, std::integral_constant<int, 4>{}); break;
+            case 5: rank_chunk(c, std::integral_constant<int, 5>{}); break;
+            case 6: rank_chunk(c, std::integral_constant<int, 6>{}); break;
+            case 7: rank_chunk(c, std::integral_constant<int, 7>{}); break;
+            default: rank_chunk(c, std::integral_constant<int, 8>{}); break;
+        }
     }
 }
 
